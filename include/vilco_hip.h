@@ -1,0 +1,191 @@
+/*
+ * vilco_hip.h -- C ABI of libvilco_hip.so, the MI355X (gfx950) kernel library behind the
+ * drop-in MQ modules in vilco_amd/modeling.
+ *
+ * The reference (cruiseresearchgroup/ViLCo, MQ tree) has no C operator API for this path: its
+ * operators are torch.nn.functional calls inside MQ/libs/modeling (python) plus ONE compiled
+ * extension, nms_1d_cpu (MQ/libs/utils/csrc/nms_cpu.cpp:172-182).  Each entry point below cites
+ * the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer owned by the caller
+ *    (PyTorch caching allocator) unless stated; `stream` is a hipStream_t passed as void*.
+ *  - activations are TOKEN-MAJOR fp32: x[b][t][c] (c contiguous) -- the reference is channel-first
+ *    [B,C,T] (blocks.py:107-108); vilco_transpose2d converts at the module boundary.
+ *  - sequence masks are prefix masks (meta_archs.py:1175 `arange < len`), passed as int32 len[B].
+ *  - functions never allocate, never synchronise, never throw; they return 0 or a negative status.
+ */
+#ifndef VILCO_HIP_H
+#define VILCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum vilco_status {
+  VILCO_OK = 0,
+  VILCO_ERR_BADARG = -1,      /* null pointer / negative size / misaligned operand */
+  VILCO_ERR_UNSUPPORTED = -2, /* shape outside what the kernels implement */
+  VILCO_ERR_LAUNCH = -3,      /* hipLaunchKernel reported an error */
+  VILCO_ERR_WORKSPACE = -4    /* workspace too small */
+};
+
+const char* vilco_status_str(int status);
+/* library / target identification: "vilco_hip <ver> gfx950" */
+const char* vilco_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* GEMM family: every 1x1 conv, k=3 conv, nn.Linear, einsum projection and (round 1) the        */
+/* attention contractions.  C[m][n] = epilogue(alpha * sum_k A(m,k) B(k,n)).                    */
+/* Replaces aten::convolution / addmm / bmm / einsum under blocks.py:79,217-226,340-349,420-435, */
+/* 533-539, meta_archs.py:216-235,309-331, modeling_xlnet_x.py:284-325,437-443,474-489.         */
+/* bf16 MFMA (v_mfma_f32_16x16x32_bf16) with fp32 accumulate; precision 0 = split-bf16 (hi+lo, */
+/* 3 MFMAs, ~2^-16 relative: the fp32-parity mode), 1 = single bf16 pass.                       */
+/* ------------------------------------------------------------------------------------------ */
+enum { VILCO_ACT_NONE = 0, VILCO_ACT_RELU = 1, VILCO_ACT_GELU = 2 };
+enum { VILCO_TAP_NONE = 0, VILCO_TAP_A = 1, VILCO_TAP_B = 2 };
+
+typedef struct vilco_gemm_desc {
+  const float* A;
+  const float* B;
+  float* C;
+  int32_t M, N, K;
+  int32_t a_kcontig; /* 1: A(m,k) = A[m*lda + k];  0: A(m,k) = A[k*lda + m] */
+  int32_t b_kcontig; /* 1: B(k,n) = B[n*ldb + k];  0: B(k,n) = B[k*ldb + n] */
+  int64_t lda, ldb, ldc;
+  /* batch z = zo*batch_inner + zi ; pointer offset = zo*s?o + zi*s?i (elements) */
+  int32_t batch_outer, batch_inner;
+  int64_t sAo, sAi, sBo, sBi, sCo, sCi;
+  /* k=3 "same" conv as a GEMM over overlapped token rows (MaskedConv1D, blocks.py:79,114):
+   * the tapped operand's contiguous dim spans 3*tapC (taps t-1,t,t+1), its row index is a token
+   * (b*tapT + t); element address = base + row*ld + col - tapC, zero outside [0,tapT). */
+  int32_t tap_operand, tapC, tapT;
+  int32_t precision;
+  float alpha, beta; /* result += beta * C_old (after the whole epilogue) */
+  /* epilogue, applied in this order; each optional (null / 0 = off) */
+  const float* bias;      /* [N]                                       */
+  float* preact;          /* same layout as C: value before activation */
+  int32_t act;            /* VILCO_ACT_*                               */
+  const int32_t* row_len; /* row m -> b = m / rowT, t = m % rowT; zero the row when t >= row_len[b] */
+  int32_t rowT;
+  const float* colscale;  /* [N]  (AffineDropPath.scale, blocks.py:663-670) */
+  const float* residual;  /* same layout as C; added after scaling */
+  int32_t res_masked;     /* 1: residual is also zeroed on masked rows */
+} vilco_gemm_desc;
+
+int vilco_gemm(const vilco_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* LayerNorm over the channel dim of token-major rows: blocks.py:160-175 (biased variance, eps   */
+/* inside sqrt) and the stock nn.LayerNorm calls (blocks.py:446-451, modeling_xlnet_x.py:236,473). */
+/* relu=1 fuses the ReLU that follows every embed/head LN (backbones.py:219, meta_archs.py:270).  */
+/* ------------------------------------------------------------------------------------------ */
+int vilco_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, int64_t rows, int32_t C, float eps,
+                        int32_t relu, void* stream);
+size_t vilco_layernorm_bwd_workspace(int64_t rows, int32_t C);
+/* y (forward output) is only read when relu=1.  dgamma/dbeta are overwritten. */
+int vilco_layernorm_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+                        const float* mean, const float* rstd, float* dx, float* dgamma,
+                        float* dbeta, int64_t rows, int32_t C, int32_t relu, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Depthwise k=3 conv, stride 1|2, zero pad 1, no bias, output masked: MaskedMHCA's query/key/   */
+/* value convs (blocks.py:312-334,363-368 via MaskedConv1D.forward :106-130).                    */
+/* x[B][Tin][C], w[C][3], y[B][Tout][C], Tout = Tin/stride, valid(t') = stride*t' < in_len[b].   */
+/* ------------------------------------------------------------------------------------------ */
+int vilco_dwconv3_fwd(const float* x, const float* w, const int32_t* in_len, float* y, int32_t B,
+                      int32_t Tin, int32_t C, int32_t stride, void* stream);
+size_t vilco_dwconv3_bwd_workspace(int32_t B, int32_t Tin, int32_t C, int32_t stride);
+int vilco_dwconv3_bwd(const float* dy, const float* x, const float* w, const int32_t* in_len,
+                      float* dx, float* dw, int32_t B, int32_t Tin, int32_t C, int32_t stride,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* nn.MaxPool1d(3, 2, 1) skip path times the output mask (blocks.py:519-523,567). */
+int vilco_maxpool3s2_fwd(const float* x, const int32_t* in_len, float* y, int32_t B, int32_t Tin,
+                         int32_t C, void* stream);
+int vilco_maxpool3s2_bwd(const float* dy, const float* x, const int32_t* in_len, float* dx,
+                         int32_t B, int32_t Tin, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Row softmax over materialised attention scores S[B][H][Tq][Tk], in place.                     */
+/* mode 0: key j masked (-inf) when j >= kv_len[b]   (blocks.py:258-260, 390-392)                */
+/* mode 1: XLNet: score - 1e30 when (j >= kv_len[b] && j != i)  (modeling_xlnet_x.py:1184-1188,  */
+/*         298-307); mode 2: no mask (ChannelAttention, blocks.py:432).                          */
+/* ------------------------------------------------------------------------------------------ */
+int vilco_softmax_fwd(float* s, const int32_t* kv_len, int32_t B, int32_t H, int32_t Tq,
+                      int32_t Tk, int32_t mode, void* stream);
+/* dS = P * (dP - sum_j dP*P), written over dp */
+int vilco_softmax_bwd(float* dp, const float* p, int32_t B, int32_t H, int32_t Tq, int32_t Tk,
+                      void* stream);
+/* XLNet rel_shift_bnij fused with the add (modeling_xlnet_x.py:256-268,288,298):
+ * s[b][h][i][j] += scale * bd[b][h][i][T - i + j],  bd is [B][H][T][2T]. */
+int vilco_relshift_add(float* s, const float* bd, float scale, int32_t B, int32_t H, int32_t T,
+                       void* stream);
+/* adjoint: dbd[b][h][i][T-i+j] = scale * ds[b][h][i][j], all other entries 0 */
+int vilco_relshift_bwd(const float* ds, float* dbd, float scale, int32_t B, int32_t H, int32_t T,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Elementwise / reduction glue of TransformerBlock.forward (blocks.py:561-593).                 */
+/* ------------------------------------------------------------------------------------------ */
+/* out = a * (mask_a ? m : 1) + colscale[c] * rowscale[b] * bval ; colscale/rowscale/len optional */
+int vilco_scale_add_fwd(float* out, const float* a, const float* bval, const float* colscale,
+                        const float* rowscale, const int32_t* len, int32_t mask_a, int32_t B,
+                        int32_t T, int32_t C, void* stream);
+size_t vilco_colsum_workspace(int64_t rows, int32_t C);
+/* da = dout*(mask_a?m:1) ; db = dout*colscale*rowscale ; dcolscale = sum_rows dout*bval*rowscale.
+ * da / db / dcolscale may be null to skip. */
+int vilco_scale_add_bwd(const float* dout, const float* bval, const float* colscale,
+                        const float* rowscale, const int32_t* len, int32_t mask_a, float* da,
+                        float* db, float* dcolscale, int32_t B, int32_t T, int32_t C,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* out = alpha*a + beta*b (b may be null) */
+int vilco_axpby(float* out, const float* a, const float* b, float alpha, float beta, int64_t n,
+                void* stream);
+/* dz = dy * act'(aux) * rowmask ; aux = pre-activation (gelu) or output (relu); act NONE = mask only.
+ * Optional dbias[C] = column sums of dz (needs workspace). */
+int vilco_act_bwd(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
+                  const int32_t* len, int32_t T, int64_t rows, int32_t C, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* out[c] = sum_r x[r][c] */
+int vilco_colsum(const float* x, float* out, int64_t rows, int32_t C, void* workspace,
+                 size_t workspace_bytes, void* stream);
+/* x[b][t][:] *= (t < len[b]) ; optional add: out = x + pe[t][c] * m  (backbones.py:222-226) */
+int vilco_mask_rows(float* x, const int32_t* len, int32_t B, int32_t T, int32_t C, void* stream);
+int vilco_add_pe(float* out, const float* x, const float* pe, const int32_t* len, int32_t B,
+                 int32_t T, int32_t C, void* stream);
+/* batched 2-D transpose: in[z][R][S] -> out[z][S][R]  (channel-first <-> token-major boundary) */
+int vilco_transpose2d(const float* in, float* out, int32_t batch, int32_t R, int32_t S,
+                      void* stream);
+/* out[i][j][k] (contiguous, dims d0,d1,d2) = in[off + i*s0 + j*s1 + k*s2]  (conv weight permutes) */
+int vilco_permute3(const float* in, float* out, int32_t d0, int32_t d1, int32_t d2, int64_t off,
+                   int64_t s0, int64_t s1, int64_t s2, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* 1-D NMS on the device, replacing nms_1d_cpu (MQ/libs/utils/csrc/nms_cpu.cpp).                 */
+/* Segments of all classes are passed concatenated; seg_off[nseg+1] gives each class's range      */
+/* (batched_nms's per-class loop, nms.py:124-152, becomes one launch: one workgroup per class).   */
+/* Outputs are per class at the same offsets: out_idx (indices LOCAL to the class, int64, in the  */
+/* reference's return order) and out_cnt[nseg].  Index outputs are bit-exact vs the reference.    */
+/* ------------------------------------------------------------------------------------------ */
+size_t vilco_nms_workspace(int64_t n_total, int32_t nseg);
+/* nms_cpu.cpp:19-58.  segs[n][2], scores[n]. */
+int vilco_nms_1d(const float* segs, const float* scores, const int64_t* seg_off, int32_t nseg,
+                 int64_t n_total, float iou_threshold, int64_t* out_idx, int64_t* out_cnt,
+                 void* workspace, size_t workspace_bytes, void* stream);
+/* nms_cpu.cpp:67-160.  dets[n][3] rows 0..cnt-1 of each class = (x1, x2, decayed score).
+ * max_num > 0 stops each class after max_num picks (exact for the caller, nms.py:56-63). */
+int vilco_softnms_1d(const float* segs, const float* scores, const int64_t* seg_off, int32_t nseg,
+                     int64_t n_total, float iou_threshold, float sigma, float min_score,
+                     int32_t method, int64_t max_num, float* dets, int64_t* out_idx,
+                     int64_t* out_cnt, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VILCO_HIP_H */

@@ -1,0 +1,118 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's compiled 1-D NMS.
+
+Follows MQ/libs/utils/csrc/nms_cpu.cpp: `nms` = nms_1d_cpu (:19-58), `softnms` = softnms_1d_cpu
+(:67-160), and the python wrapper MQ/libs/utils/nms.py: `batched_nms` (:103-190) with NMSop (:8-35) /
+SoftNMSop (:38-64).  float32 arithmetic is kept step by step (np.float32 scalars) so scores and
+tie-breaks round like the C++.  Parity pinned: tests/test_oracle_nms.py checks these functions against
+the reference extension itself (oracle/_ref/nms_1d_cpu.so, built from the reference source) and
+against the committed goldens tests/golden/nms_*.npz generated from it.
+"""
+import numpy as np
+
+f32 = np.float32
+
+
+def nms(segs, scores, iou_threshold):
+    segs = np.asarray(segs, dtype=f32).reshape(-1, 2)
+    scores = np.asarray(scores, dtype=f32)
+    n = segs.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    x1, x2 = segs[:, 0].copy(), segs[:, 1].copy()
+    areas = (x2 - x1 + f32(1e-6)).astype(f32)
+    order = np.argsort(-scores, kind="stable")          # aten CPU sort(descending=True) is stable
+    keep = np.ones(n, dtype=bool)
+    thr = f32(iou_threshold)
+    for _i in range(n):
+        if not keep[_i]:
+            continue
+        i = order[_i]
+        for _j in range(_i + 1, n):
+            if not keep[_j]:
+                continue
+            j = order[_j]
+            inter = max(f32(0), f32(min(x2[i], x2[j]) - max(x1[i], x1[j])))
+            ovr = f32(inter / f32(f32(areas[i] + areas[j]) - inter))
+            if ovr >= thr:
+                keep[_j] = False
+    return order[keep].astype(np.int64)
+
+
+def softnms(segs, scores, iou_threshold, sigma, min_score, method, max_num=0):
+    """returns (inds, dets[K,3]).  max_num > 0 stops after max_num picks (exact for the caller)."""
+    segs = np.asarray(segs, dtype=f32).reshape(-1, 2)
+    n = segs.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int64), np.zeros((0, 3), dtype=f32)
+    x1, x2 = segs[:, 0].copy(), segs[:, 1].copy()
+    sc = np.asarray(scores, dtype=f32).copy()
+    areas = (x2 - x1 + f32(1e-6)).astype(f32)
+    inds = np.arange(n, dtype=np.int64)
+    dets = np.zeros((n, 3), dtype=f32)
+    thr, sigma, min_score = f32(iou_threshold), f32(sigma), f32(min_score)
+    nsegs, i = n, 0
+    while i < nsegs:
+        if max_num > 0 and i >= max_num:
+            break
+        mp = i + int(np.argmax(sc[i:nsegs]))             # first maximum == strict '<' scan
+        for arr in (x1, x2, sc, areas, inds):
+            arr[i], arr[mp] = arr[mp], arr[i]
+        dets[i] = (x1[i], x2[i], sc[i])
+        ix1, ix2, ia = x1[i], x2[i], areas[i]
+        pos = i + 1
+        while pos < nsegs:
+            inter = max(f32(0), f32(min(ix2, x2[pos]) - max(ix1, x1[pos])))
+            ovr = f32(inter / f32(f32(ia + areas[pos]) - inter))
+            w = f32(1)
+            if method == 0:
+                if ovr >= thr:
+                    w = f32(0)
+            elif method == 1:
+                if ovr >= thr:
+                    w = f32(1) - ovr
+            elif method == 2:
+                w = f32(np.exp(f32(-(ovr * ovr) / sigma)))
+            sc[pos] = f32(sc[pos] * w)
+            if sc[pos] < min_score:
+                last = nsegs - 1
+                for arr in (x1, x2, sc, areas, inds):
+                    arr[pos] = arr[last]
+                nsegs -= 1
+                pos -= 1
+            pos += 1
+        i += 1
+    return inds[:i].copy(), dets[:i].copy()
+
+
+def batched_nms(segs, scores, cls_idxs, iou_threshold, min_score, max_seg_num, use_soft_nms=True,
+                multiclass=True, sigma=0.5, voting_thresh=0.75):
+    segs = np.asarray(segs, dtype=f32).reshape(-1, 2)
+    scores = np.asarray(scores, dtype=f32)
+    cls_idxs = np.asarray(cls_idxs)
+    if segs.shape[0] == 0:
+        return np.zeros((0, 2), f32), np.zeros((0,), f32), np.zeros((0,), cls_idxs.dtype)
+
+    def one(s, sc, c):
+        if use_soft_nms:
+            inds, dets = softnms(s, sc, iou_threshold, sigma, min_score, 2)
+            k = min(len(inds), max_seg_num) if max_seg_num > 0 else len(inds)
+            return dets[:k, :2], dets[:k, 2], c[inds][:k]
+        if min_score > 0:
+            m = sc > f32(min_score)
+            s, sc, c = s[m], sc[m], c[m]
+        inds = nms(s, sc, iou_threshold)
+        if max_seg_num > 0:
+            inds = inds[:min(max_seg_num, len(inds))]
+        return s[inds], sc[inds], c[inds]
+
+    if multiclass:
+        parts = [one(segs[cls_idxs == k], scores[cls_idxs == k], cls_idxs[cls_idxs == k]) for k in np.unique(cls_idxs)]
+        new_segs = np.concatenate([p[0] for p in parts])
+        new_scores = np.concatenate([p[1] for p in parts])
+        new_cls = np.concatenate([p[2] for p in parts])
+    else:
+        new_segs, new_scores, new_cls = one(segs, scores, cls_idxs)
+        if voting_thresh > 0:
+            raise NotImplementedError("seg voting is checked through the torch path only")
+    order = np.argsort(-new_scores, kind="stable")[:min(max_seg_num, new_segs.shape[0])]
+    return new_segs[order], new_scores[order], new_cls[order]

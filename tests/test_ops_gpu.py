@@ -1,0 +1,242 @@
+"""HIP kernels (through the C ABI) vs plain fp32/fp64 PyTorch references of the same op, fwd + bwd.
+Tolerances: split-bf16 GEMM mode is ~2^-16 relative per product -> 2e-4 of the output scale;
+pure elementwise / reduction kernels 1e-5."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL_GEMM = 2e-4
+TOL_EW = 2e-5
+
+
+def rel(got, want):
+    want = want.double().cpu()
+    got = got.double().cpu()
+    return ((got - want).abs().max() / (want.abs().max() + 1e-12)).item()
+
+
+def run_pair(fn_hip, fn_ref, inputs, dev, tol, grad_inputs=None, seed=0):
+    """inputs: dict name -> cpu tensor (float64 reference copies are made); returns nothing, asserts."""
+    g = torch.Generator().manual_seed(seed)
+    cpu = {k: (v.double().requires_grad_(v.is_floating_point() and (grad_inputs is None or k in grad_inputs)))
+           for k, v in inputs.items()}
+    gpu = {k: (v.to(dev).requires_grad_(v.is_floating_point() and (grad_inputs is None or k in grad_inputs)))
+           for k, v in inputs.items()}
+    want = fn_ref(**cpu)
+    got = fn_hip(**gpu)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    e = rel(got, want)
+    assert e < tol, "forward rel err %.3e" % e
+    dout = torch.randn(want.shape, generator=g, dtype=torch.float64)
+    want.backward(dout)
+    got.backward(dout.float().to(dev))
+    for k in cpu:
+        if cpu[k].requires_grad:
+            assert gpu[k].grad is not None, "no grad for " + k
+            e = rel(gpu[k].grad, cpu[k].grad)
+            assert e < tol, "grad %s rel err %.3e" % (k, e)
+
+
+def lens_mask(lens, T):
+    return (torch.arange(T)[None, :] < lens[:, None])
+
+
+@pytest.mark.parametrize("M,N,K", [(150, 70, 72), (300, 260, 200), (128, 128, 32), (64, 22, 96), (257, 2, 64), (5, 300, 1000)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear(dev, M, N, K, act):
+    from vilco_amd import ops
+    torch.manual_seed(1)
+    x, w, b = torch.randn(2, M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+    lens = torch.tensor([M, M - 7], dtype=torch.int32)
+    m = lens_mask(lens, M)[..., None]
+
+    def ref(x, w, b):
+        z = x @ w.t() + b
+        z = [z, torch.relu(z), F.gelu(z)][act]
+        return z * m
+
+    def hip(x, w, b):
+        return ops.linear(x, w, b, act, lens.to(dev), M)
+    run_pair(hip, ref, dict(x=x, w=w, b=b), dev, TOL_GEMM)
+
+
+def test_linear_unaligned_k(dev):
+    from vilco_amd import ops
+    x, w = torch.randn(37, 50), torch.randn(30, 50)
+    run_pair(lambda x, w: ops.linear(x, w), lambda x, w: x @ w.t(), dict(x=x, w=w), dev, TOL_GEMM)
+
+
+def test_linear_kn(dev):
+    from vilco_amd import ops
+    x, w, b = torch.randn(3, 70, 64), torch.randn(64, 4, 24) / 8, torch.randn(4, 24)
+    run_pair(lambda x, w, b: ops.linear_kn(x, w, b),
+             lambda x, w, b: x @ w.reshape(64, 96) + b.reshape(96), dict(x=x, w=w, b=b), dev, TOL_GEMM)
+
+
+def test_bf16_mode(dev):
+    from vilco_amd import ops
+    x, w = torch.randn(200, 256), torch.randn(160, 256) / 16
+    ops.set_precision("bf16")
+    try:
+        run_pair(lambda x, w: ops.linear(x, w), lambda x, w: x @ w.t(), dict(x=x, w=w), dev, 2e-2)
+    finally:
+        ops.set_precision("split")
+
+
+@pytest.mark.parametrize("B,T,Cin,Cout", [(2, 64, 96, 64), (2, 160, 64, 24), (1, 300, 32, 136), (3, 16, 8, 2)])
+def test_conv3(dev, B, T, Cin, Cout):
+    from vilco_amd import ops
+    torch.manual_seed(2)
+    x, w, b = torch.randn(B, T, Cin), torch.randn(Cout, Cin, 3) / math.sqrt(3 * Cin), torch.randn(Cout)
+    lens = torch.tensor([T, max(1, T - 5), max(1, T // 2)][:B], dtype=torch.int32)
+    m = lens_mask(lens, T)[..., None]
+
+    def ref(x, w, b):
+        y = F.conv1d(x.transpose(1, 2), w, b, padding=1).transpose(1, 2)
+        return y * m
+    run_pair(lambda x, w, b: ops.conv3(x, w, b, lens.to(dev)), ref, dict(x=x, w=w, b=b), dev, TOL_GEMM)
+
+
+@pytest.mark.parametrize("C", [64, 256, 768, 1024, 2304])
+@pytest.mark.parametrize("relu", [False, True])
+def test_layernorm(dev, C, relu):
+    from vilco_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(3, 37, C) * 2 + 0.5
+    g, b = torch.randn(1, C, 1), torch.randn(1, C, 1)
+
+    def ref(x, g, b):
+        mu = x.mean(-1, keepdim=True)
+        r = x - mu
+        y = r / torch.sqrt((r ** 2).mean(-1, keepdim=True) + 1e-5) * g.view(C) + b.view(C)
+        return torch.relu(y) if relu else y
+    run_pair(lambda x, g, b: ops.layernorm(x, g, b, 1e-5, relu), ref, dict(x=x, g=g, b=b), dev, TOL_EW)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("B,T,C", [(2, 64, 64), (3, 30, 128), (1, 2, 8)])
+def test_dwconv3(dev, stride, B, T, C):
+    from vilco_amd import ops
+    torch.manual_seed(4)
+    x, w = torch.randn(B, T, C), torch.randn(C, 1, 3)
+    lens = torch.tensor([T, max(1, T - 3), max(1, T // 2 + 1)][:B], dtype=torch.int32)
+    To = T // stride
+    m = (stride * torch.arange(To)[None, :] < lens[:, None])[..., None]
+
+    def ref(x, w):
+        y = F.conv1d(x.transpose(1, 2), w, None, stride=stride, padding=1, groups=C).transpose(1, 2)
+        return y * m
+    run_pair(lambda x, w: ops.dwconv3(x, w, lens.to(dev), stride), ref, dict(x=x, w=w), dev, TOL_EW)
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 64, 64), (3, 30, 12), (1, 2, 8)])
+def test_maxpool(dev, B, T, C):
+    from vilco_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(B, T, C)
+    lens = torch.tensor([T, max(1, T - 3), max(1, T // 2 + 1)][:B], dtype=torch.int32)
+    m = (2 * torch.arange(T // 2)[None, :] < lens[:, None])[..., None]
+
+    def ref(x):
+        return F.max_pool1d(x.transpose(1, 2), 3, 2, 1).transpose(1, 2) * m
+    run_pair(lambda x: ops.maxpool3s2(x, lens.to(dev)), ref, dict(x=x), dev, TOL_EW)
+
+
+@pytest.mark.parametrize("C", [64, 22])
+def test_scale_add_axpby_pe(dev, C):
+    from vilco_amd import ops
+    torch.manual_seed(6)
+    B, T = 3, 20
+    a, b = torch.randn(B, T, C), torch.randn(B, T, C)
+    cs, rs = torch.randn(1, C, 1), torch.rand(B) + 0.5
+    lens = torch.tensor([20, 13, 1], dtype=torch.int32)
+    m = lens_mask(lens, T)[..., None]
+
+    run_pair(lambda a, b, cs: ops.scale_add(a, b, cs, rs.to(dev), lens.to(dev), True),
+             lambda a, b, cs: a * m + cs.view(C) * rs.double().view(B, 1, 1) * b, dict(a=a, b=b, cs=cs), dev, TOL_EW)
+    run_pair(lambda a, b: ops.scale_add(a, b), lambda a, b: a + b, dict(a=a, b=b), dev, TOL_EW)
+    run_pair(lambda a, b: ops.axpby(a, b, 0.8, 0.2), lambda a, b: 0.8 * a + 0.2 * b, dict(a=a, b=b), dev, TOL_EW)
+    pe = torch.randn(T, C)
+    run_pair(lambda a: ops.add_pe(a, pe.to(dev), lens.to(dev)), lambda a: a + pe.double() * m, dict(a=a), dev, TOL_EW)
+
+
+def test_transpose(dev):
+    from vilco_amd import ops
+    x = torch.randn(3, 70, 45)
+    run_pair(lambda x: ops.transpose(x), lambda x: x.transpose(1, 2), dict(x=x), dev, 1e-7)
+
+
+def _attn_ref(q, k, v, lens, H, scale, xl=False):
+    B, Tq, C = q.shape
+    Tk = k.shape[1]
+    hd = C // H
+    qh = q.view(B, Tq, H, hd).transpose(1, 2)
+    kh = k.view(B, Tk, H, hd).transpose(1, 2)
+    vh = v.view(B, Tk, H, hd).transpose(1, 2)
+    s = (qh * scale) @ kh.transpose(-1, -2)
+    km = lens_mask(lens, Tk)[:, None, None, :]
+    s = s.masked_fill(~km, float('-inf'))
+    p = torch.softmax(s, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Tq, C)
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H,hd", [(2, 64, 64, 4, 16), (2, 40, 77, 4, 16), (1, 130, 130, 2, 64), (2, 32, 5, 4, 8)])
+def test_attention(dev, B, Tq, Tk, H, hd):
+    from vilco_amd import ops
+    torch.manual_seed(7)
+    C = H * hd
+    q, k, v = torch.randn(B, Tq, C), torch.randn(B, Tk, C), torch.randn(B, Tk, C)
+    lens = torch.tensor([Tk, max(1, Tk - 9)][:B], dtype=torch.int32)
+    scale = 1 / math.sqrt(hd)
+    run_pair(lambda q, k, v: ops.attention(q, k, v, lens.to(dev), H, scale),
+             lambda q, k, v: _attn_ref(q, k, v, lens, H, scale), dict(q=q, k=k, v=v), dev, TOL_GEMM)
+
+
+def test_rel_attention(dev):
+    """XLNet core vs the published formula incl. rel_shift_bnij (modeling_xlnet_x.py:256-320)."""
+    from vilco_amd import ops
+    torch.manual_seed(8)
+    B, T, H, hd = 2, 48, 4, 16
+    C = H * hd
+    qw, qr, k, v = [torch.randn(B, T, C) for _ in range(4)]
+    kr = torch.randn(2 * T, C)
+    lens = torch.tensor([T, T - 11], dtype=torch.int32)
+    scale = 1 / math.sqrt(hd)
+
+    def ref(qw, qr, k, v, kr):
+        f = lambda x: x.view(B, T, H, hd).permute(1, 0, 2, 3)          # ibnd
+        ac = torch.einsum("ibnd,jbnd->bnij", f(qw), f(k))
+        krr = kr.view(2 * T, 1, H, hd).expand(2 * T, B, H, hd)
+        bd = torch.einsum("ibnd,jbnd->bnij", f(qr), krr)
+        xs = bd.shape
+        bd = bd.reshape(xs[0], xs[1], xs[3], xs[2])[:, :, 1:, :].reshape(xs[0], xs[1], xs[2], xs[3] - 1)[:, :, :, :T]
+        score = (ac + bd) * scale
+        pad = (~lens_mask(lens, T)).double()                          # [B, T(j)]
+        mask = ((pad[:, None, None, :] - torch.eye(T, dtype=torch.float64)[None, None]) > 0).double()
+        score = score - 1e30 * mask
+        p = torch.softmax(score, dim=3)
+        o = torch.einsum("bnij,jbnd->ibnd", p, f(v))
+        return o.permute(1, 0, 2, 3).reshape(B, T, C)
+    run_pair(lambda qw, qr, k, v, kr: ops.rel_attention(qw, qr, k, v, kr, lens.to(dev), H, scale), ref,
+             dict(qw=qw, qr=qr, k=k, v=v, kr=kr), dev, TOL_GEMM)
+
+
+def test_channel_attention(dev):
+    from vilco_amd import ops
+    torch.manual_seed(9)
+    B, T, H, hd = 2, 50, 4, 16
+    C = H * hd
+    qkv = torch.randn(B, T, 3 * C)
+    scale = hd ** -0.5
+
+    def ref(qkv):
+        x = qkv.reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = x[0], x[1], x[2]
+        att = ((k * scale).transpose(-1, -2) @ v).softmax(dim=-1)
+        o = (att @ q.transpose(-1, -2)).transpose(-1, -2)
+        return o.transpose(1, 2).reshape(B, T, C)
+    run_pair(lambda qkv: ops.channel_attention(qkv, H, scale), ref, dict(qkv=qkv), dev, TOL_GEMM)

@@ -1,0 +1,100 @@
+"""ctypes binding of libvilco_hip.so (C ABI: include/vilco_hip.h).
+
+The product path has NO fallback: if the library is missing or a kernel returns a status, we
+raise.  `load()` is lazy so that CPU-only tooling (config parsing, state_dict surgery, the
+`-m "not gpu"` symbol test) can import the package without a GPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvilco_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+TAP_NONE, TAP_A, TAP_B = 0, 1, 2
+
+c_fp = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+i32, i64, f32, sz = C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class GemmDesc(C.Structure):
+    """Mirror of `vilco_gemm_desc` (include/vilco_hip.h)."""
+    _fields_ = [
+        ("A", c_fp), ("B", c_fp), ("C", c_fp),
+        ("M", i32), ("N", i32), ("K", i32),
+        ("a_kcontig", i32), ("b_kcontig", i32),
+        ("lda", i64), ("ldb", i64), ("ldc", i64),
+        ("batch_outer", i32), ("batch_inner", i32),
+        ("sAo", i64), ("sAi", i64), ("sBo", i64), ("sBi", i64), ("sCo", i64), ("sCi", i64),
+        ("tap_operand", i32), ("tapC", i32), ("tapT", i32),
+        ("precision", i32),
+        ("alpha", f32), ("beta", f32),
+        ("bias", c_fp), ("preact", c_fp), ("act", i32),
+        ("row_len", c_fp), ("rowT", i32),
+        ("colscale", c_fp), ("residual", c_fp), ("res_masked", i32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/vilco_hip.h declares
+SIGNATURES = {
+    "vilco_status_str": (C.c_char_p, [C.c_int]),
+    "vilco_version": (C.c_char_p, []),
+    "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "vilco_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp]),
+    "vilco_layernorm_bwd_workspace": (sz, [i64, i32]),
+    "vilco_layernorm_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32,
+                                      i32, c_fp, sz, c_fp]),
+    "vilco_dwconv3_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
+    "vilco_dwconv3_bwd_workspace": (sz, [i32, i32, i32, i32]),
+    "vilco_dwconv3_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, sz, c_fp]),
+    "vilco_maxpool3s2_fwd": (C.c_int, [c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "vilco_maxpool3s2_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "vilco_softmax_fwd": (C.c_int, [c_fp, c_fp, i32, i32, i32, i32, i32, c_fp]),
+    "vilco_softmax_bwd": (C.c_int, [c_fp, c_fp, i32, i32, i32, i32, c_fp]),
+    "vilco_relshift_add": (C.c_int, [c_fp, c_fp, f32, i32, i32, i32, c_fp]),
+    "vilco_relshift_bwd": (C.c_int, [c_fp, c_fp, f32, i32, i32, i32, c_fp]),
+    "vilco_scale_add_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
+    "vilco_colsum_workspace": (sz, [i64, i32]),
+    "vilco_scale_add_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, i32,
+                                      c_fp, sz, c_fp]),
+    "vilco_axpby": (C.c_int, [c_fp, c_fp, c_fp, f32, f32, i64, c_fp]),
+    "vilco_act_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, c_fp, sz, c_fp]),
+    "vilco_colsum": (C.c_int, [c_fp, c_fp, i64, i32, c_fp, sz, c_fp]),
+    "vilco_mask_rows": (C.c_int, [c_fp, c_fp, i32, i32, i32, c_fp]),
+    "vilco_add_pe": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
+    "vilco_transpose2d": (C.c_int, [c_fp, c_fp, i32, i32, i32, c_fp]),
+    "vilco_permute3": (C.c_int, [c_fp, c_fp, i32, i32, i32, i64, i64, i64, i64, c_fp]),
+    "vilco_nms_workspace": (sz, [i64, i32]),
+    "vilco_nms_1d": (C.c_int, [c_fp, c_fp, c_fp, i32, i64, f32, c_fp, c_fp, c_fp, sz, c_fp]),
+    "vilco_softnms_1d": (C.c_int, [c_fp, c_fp, c_fp, i32, i64, f32, f32, f32, i32, i64, c_fp, c_fp, c_fp,
+                                   c_fp, sz, c_fp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvilco_hip.so (once).  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libvilco_hip.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C vilco_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(load().vilco_status_str(int(rc)).decode())
+
+
+def version():
+    return load().vilco_version().decode()

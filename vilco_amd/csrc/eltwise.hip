@@ -1,0 +1,421 @@
+// Memory-bound glue kernels: masked row softmax (materialised-score attention of round 1), the
+// XLNet relative shift, residual/scale/mask epilogues, activation backward, column reductions,
+// layout transposes.  All token-major, float4 where the channel count allows.
+#include "common.h"
+
+void vilco_reduce_rows(const float* ws, float* out0, float* out1, int nrows, int ncols, int split,
+                       hipStream_t s);
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+int ew_grid(long total) {
+  long b = (total + EW_THREADS - 1) / EW_THREADS;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- softmax over rows of S[B][H][Tq][Tk]
+// one wave per row; three passes over the row (max, sum, write) -- rows are <= 9 KB and stay in L1/L2.
+__global__ __launch_bounds__(EW_THREADS) void softmax_fwd_kernel(float* __restrict__ s,
+                                                                 const int* __restrict__ kv_len, int B,
+                                                                 int H, int Tq, int Tk, int mode) {
+  const int lane = threadIdx.x & 63;
+  const long nrows = (long)B * H * Tq;
+  const long wid = (long)blockIdx.x * (EW_THREADS / 64) + (threadIdx.x >> 6);
+  const long wstride = (long)gridDim.x * (EW_THREADS / 64);
+  for (long row = wid; row < nrows; row += wstride) {
+    float* p = s + row * Tk;
+    const int i = (int)(row % Tq);
+    const int b = (int)(row / ((long)H * Tq));
+    const int len = (mode == 2) ? Tk : kv_len[b];
+    // mode 0: columns >= len are excluded (-inf).  mode 1 (XLNet): "- 1e30" on masked columns,
+    // except the diagonal; in fp32 score - 1e30 == -1e30 exactly for any realistic score.
+    float m = -INFINITY;
+    for (int j = lane; j < Tk; j += 64) {
+      float v = p[j];
+      if (j >= len) v = (mode == 1) ? ((j == i) ? v : v - 1e30f) : -INFINITY;
+      m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < Tk; j += 64) {
+      float v = p[j];
+      if (j >= len) v = (mode == 1) ? ((j == i) ? v : v - 1e30f) : -INFINITY;
+      sum += expf(v - m);
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < Tk; j += 64) {
+      float v = p[j];
+      if (j >= len) v = (mode == 1) ? ((j == i) ? v : v - 1e30f) : -INFINITY;
+      p[j] = expf(v - m) * inv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void softmax_bwd_kernel(float* __restrict__ dp,
+                                                                 const float* __restrict__ p,
+                                                                 long nrows, int Tk) {
+  const int lane = threadIdx.x & 63;
+  const long wid = (long)blockIdx.x * (EW_THREADS / 64) + (threadIdx.x >> 6);
+  const long wstride = (long)gridDim.x * (EW_THREADS / 64);
+  for (long row = wid; row < nrows; row += wstride) {
+    float* g = dp + row * Tk;
+    const float* pr = p + row * Tk;
+    float dot = 0.f;
+    for (int j = lane; j < Tk; j += 64) dot += g[j] * pr[j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < Tk; j += 64) g[j] = pr[j] * (g[j] - dot);
+  }
+}
+
+// s[b][h][i][j] += scale * bd[b][h][i][T - i + j]   (bd rows are 2T long)
+__global__ __launch_bounds__(EW_THREADS) void relshift_add_kernel(float* __restrict__ s,
+                                                                  const float* __restrict__ bd,
+                                                                  float scale, long nrows, int T) {
+  const long total = nrows * T;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % T);
+    const long row = idx / T;
+    const int i = (int)(row % T);
+    s[idx] += scale * bd[row * 2 * T + (T - i + j)];
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void relshift_bwd_kernel(const float* __restrict__ ds,
+                                                                  float* __restrict__ dbd, float scale,
+                                                                  long nrows, int T) {
+  const long total = nrows * 2 * T;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(idx % (2 * T));
+    const long row = idx / (2 * T);
+    const int i = (int)(row % T);
+    const int j = q - T + i;  // q = T - i + j
+    dbd[idx] = (j >= 0 && j < T) ? scale * ds[row * T + j] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------- residual / scale / mask glue
+template <bool VEC>
+__global__ __launch_bounds__(EW_THREADS) void scale_add_fwd_kernel(
+    float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ bval,
+    const float* __restrict__ colscale, const float* __restrict__ rowscale, const int* __restrict__ len,
+    int mask_a, int B, int T, int C) {
+  constexpr int V = VEC ? 4 : 1;
+  const int CV = C / V;
+  const long total = (long)B * T * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CV) * V;
+    const long bt = i / CV;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    const float am = (mask_a && len && t >= len[b]) ? 0.f : 1.f;
+    const float rs = rowscale ? rowscale[b] : 1.f;
+    const long o = bt * C + c;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float cs = colscale ? colscale[c + e] : 1.f;
+      out[o + e] = (a ? a[o + e] * am : 0.f) + cs * rs * bval[o + e];
+    }
+  }
+}
+
+// da = dout*am ; db = dout*cs*rs ; partial dcolscale[c] = sum dout*bval*rs  -> ws[block][C]
+__global__ __launch_bounds__(EW_THREADS) void scale_add_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ bval, const float* __restrict__ colscale,
+    const float* __restrict__ rowscale, const int* __restrict__ len, int mask_a, float* __restrict__ da,
+    float* __restrict__ db, float* __restrict__ ws, int B, int T, int C, int rows_per_block) {
+  const long R = (long)B * T;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > R) r1 = R;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float cs = colscale ? colscale[c] : 1.f;
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const int t = (int)(r % T), b = (int)(r / T);
+      const float am = (mask_a && len && t >= len[b]) ? 0.f : 1.f;
+      const float rs = rowscale ? rowscale[b] : 1.f;
+      const float g = dout[r * C + c];
+      if (da) da[r * C + c] = g * am;
+      if (db) db[r * C + c] = g * cs * rs;
+      if (ws) acc += g * bval[r * C + c] * rs;
+    }
+    if (ws) ws[(long)blockIdx.x * C + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void axpby_kernel(float* __restrict__ out,
+                                                           const float* __restrict__ a,
+                                                           const float* __restrict__ b, float alpha,
+                                                           float beta, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+// dz = dy * act'(aux) * rowmask ; partial dbias -> ws[block][C]
+__global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ dz,
+    float* __restrict__ ws, int act, const int* __restrict__ len, int T, long rows, int C,
+    int rows_per_block) {
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      float g = dy[r * C + c];
+      if (len && (int)(r % T) >= len[r / T]) g = 0.f;
+      if (act == VILCO_ACT_RELU) g = (aux[r * C + c] > 0.f) ? g : 0.f;
+      else if (act == VILCO_ACT_GELU) g *= gelu_grad_f(aux[r * C + c]);
+      dz[r * C + c] = g;
+      acc += g;
+    }
+    if (ws) ws[(long)blockIdx.x * C + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void colsum_partial_kernel(const float* __restrict__ x,
+                                                                    float* __restrict__ ws, long rows,
+                                                                    int C, int rows_per_block) {
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) acc += x[r * C + c];
+    ws[(long)blockIdx.x * C + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void mask_rows_kernel(float* __restrict__ x,
+                                                               const int* __restrict__ len, int B, int T,
+                                                               int C) {
+  const long total = (long)B * T * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long bt = i / C;
+    if ((int)(bt % T) >= len[bt / T]) x[i] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void add_pe_kernel(float* __restrict__ out,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ pe,
+                                                            const int* __restrict__ len, int B, int T,
+                                                            int C) {
+  const long total = (long)B * T * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long bt = i / C;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    out[i] = x[i] + ((t < len[b]) ? pe[(long)t * C + c] : 0.f);
+  }
+}
+
+// in[z][R][S] -> out[z][S][R]; 32x32 tiles through LDS (padded), coalesced on both sides
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ in,
+                                                          float* __restrict__ out, int R, int S) {
+  __shared__ float tile[32][33];
+  const int z = blockIdx.z;
+  const float* src = in + (long)z * R * S;
+  float* dst = out + (long)z * R * S;
+  const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 32; k += 8) {
+    const int r = r0 + ty + k, sc = s0 + tx;
+    if (r < R && sc < S) tile[ty + k][tx] = src[(long)r * S + sc];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 32; k += 8) {
+    const int sc = s0 + ty + k, r = r0 + tx;
+    if (r < R && sc < S) dst[(long)sc * R + r] = tile[tx][ty + k];
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void permute3_kernel(const float* __restrict__ in,
+                                                              float* __restrict__ out, int d0, int d1,
+                                                              int d2, long off, long s0, long s1, long s2) {
+  const long total = (long)d0 * d1 * d2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % d2);
+    const long ij = i / d2;
+    const int j = (int)(ij % d1), ii = (int)(ij / d1);
+    out[i] = in[off + ii * s0 + j * s1 + k * s2];
+  }
+}
+
+int col_blocks(long rows) {
+  long b = (rows + 31) / 32;
+  if (b > 256) b = 256;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int vilco_softmax_fwd(float* s, const int32_t* kv_len, int32_t B, int32_t H, int32_t Tq,
+                                 int32_t Tk, int32_t mode, void* stream) {
+  if (!s || B < 0 || H < 0 || Tq < 0 || Tk < 0 || mode < 0 || mode > 2) return VILCO_ERR_BADARG;
+  if (mode != 2 && !kv_len) return VILCO_ERR_BADARG;
+  const long nrows = (long)B * H * Tq;
+  if (nrows == 0 || Tk == 0) return VILCO_OK;
+  long blocks = (nrows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((int)blocks), dim3(EW_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), s, kv_len, B, H, Tq, Tk, mode);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_softmax_bwd(float* dp, const float* p, int32_t B, int32_t H, int32_t Tq,
+                                 int32_t Tk, void* stream) {
+  if (!dp || !p || B < 0 || H < 0 || Tq < 0 || Tk < 0) return VILCO_ERR_BADARG;
+  const long nrows = (long)B * H * Tq;
+  if (nrows == 0 || Tk == 0) return VILCO_OK;
+  long blocks = (nrows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((int)blocks), dim3(EW_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), dp, p, nrows, Tk);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_relshift_add(float* s, const float* bd, float scale, int32_t B, int32_t H,
+                                  int32_t T, void* stream) {
+  if (!s || !bd || B < 0 || H < 0 || T < 0) return VILCO_ERR_BADARG;
+  const long nrows = (long)B * H * T;
+  if (nrows == 0) return VILCO_OK;
+  hipLaunchKernelGGL(relshift_add_kernel, dim3(ew_grid(nrows * T)), dim3(EW_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), s, bd, scale, nrows, T);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_relshift_bwd(const float* ds, float* dbd, float scale, int32_t B, int32_t H,
+                                  int32_t T, void* stream) {
+  if (!ds || !dbd || B < 0 || H < 0 || T < 0) return VILCO_ERR_BADARG;
+  const long nrows = (long)B * H * T;
+  if (nrows == 0) return VILCO_OK;
+  hipLaunchKernelGGL(relshift_bwd_kernel, dim3(ew_grid(nrows * 2 * T)), dim3(EW_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), ds, dbd, scale, nrows, T);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_scale_add_fwd(float* out, const float* a, const float* bval,
+                                   const float* colscale, const float* rowscale, const int32_t* len,
+                                   int32_t mask_a, int32_t B, int32_t T, int32_t C, void* stream) {
+  if (!out || !bval || B < 0 || T < 0 || C <= 0) return VILCO_ERR_BADARG;
+  if ((long)B * T == 0) return VILCO_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if ((C % 4) == 0)
+    hipLaunchKernelGGL((scale_add_fwd_kernel<true>), dim3(ew_grid((long)B * T * C / 4)), dim3(EW_THREADS), 0,
+                       s, out, a, bval, colscale, rowscale, len, mask_a, B, T, C);
+  else
+    hipLaunchKernelGGL((scale_add_fwd_kernel<false>), dim3(ew_grid((long)B * T * C)), dim3(EW_THREADS), 0, s,
+                       out, a, bval, colscale, rowscale, len, mask_a, B, T, C);
+  return vilco_launch_status();
+}
+
+extern "C" size_t vilco_colsum_workspace(int64_t rows, int32_t C) {
+  return (size_t)col_blocks(rows) * (size_t)C * sizeof(float);
+}
+
+extern "C" int vilco_scale_add_bwd(const float* dout, const float* bval, const float* colscale,
+                                   const float* rowscale, const int32_t* len, int32_t mask_a,
+                                   float* da, float* db, float* dcolscale, int32_t B, int32_t T,
+                                   int32_t C, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dout || B < 0 || T < 0 || C <= 0) return VILCO_ERR_BADARG;
+  if (dcolscale && !bval) return VILCO_ERR_BADARG;
+  const long rows = (long)B * T;
+  if (rows == 0) return VILCO_OK;
+  if (dcolscale && (!workspace || workspace_bytes < vilco_colsum_workspace(rows, C))) return VILCO_ERR_WORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nb = col_blocks(rows);
+  const int rpb = (int)((rows + nb - 1) / nb);
+  float* ws = dcolscale ? reinterpret_cast<float*>(workspace) : nullptr;
+  hipLaunchKernelGGL(scale_add_bwd_kernel, dim3(nb), dim3(EW_THREADS), 0, s, dout, bval, colscale, rowscale,
+                     len, mask_a, da, db, ws, B, T, C, rpb);
+  if (dcolscale) vilco_reduce_rows(ws, dcolscale, nullptr, nb, C, C, s);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_axpby(float* out, const float* a, const float* b, float alpha, float beta,
+                           int64_t n, void* stream) {
+  if (!out || !a || n < 0) return VILCO_ERR_BADARG;
+  if (n == 0) return VILCO_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), out, a, b, alpha, beta, (long)n);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_act_bwd(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
+                             const int32_t* len, int32_t T, int64_t rows, int32_t C, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (!dy || !dz || rows < 0 || C <= 0 || act < 0 || act > 2) return VILCO_ERR_BADARG;
+  if (act != VILCO_ACT_NONE && !aux) return VILCO_ERR_BADARG;
+  if (len && T <= 0) return VILCO_ERR_BADARG;
+  if (rows == 0) return VILCO_OK;
+  if (dbias && (!workspace || workspace_bytes < vilco_colsum_workspace(rows, C))) return VILCO_ERR_WORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nb = col_blocks(rows);
+  const int rpb = (int)((rows + nb - 1) / nb);
+  float* ws = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(nb), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
+                     (long)rows, C, rpb);
+  if (dbias) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_colsum(const float* x, float* out, int64_t rows, int32_t C, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!x || !out || rows < 0 || C <= 0) return VILCO_ERR_BADARG;
+  if (!workspace || workspace_bytes < vilco_colsum_workspace(rows, C)) return VILCO_ERR_WORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nb = col_blocks(rows);
+  const int rpb = (int)((rows + nb - 1) / nb);
+  float* ws = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(EW_THREADS), 0, s, x, ws, (long)rows, C, rpb);
+  vilco_reduce_rows(ws, out, nullptr, nb, C, C, s);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_mask_rows(float* x, const int32_t* len, int32_t B, int32_t T, int32_t C,
+                               void* stream) {
+  if (!x || !len || B < 0 || T < 0 || C <= 0) return VILCO_ERR_BADARG;
+  if ((long)B * T == 0) return VILCO_OK;
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(ew_grid((long)B * T * C)), dim3(EW_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, len, B, T, C);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_add_pe(float* out, const float* x, const float* pe, const int32_t* len, int32_t B,
+                            int32_t T, int32_t C, void* stream) {
+  if (!out || !x || !pe || !len || B < 0 || T < 0 || C <= 0) return VILCO_ERR_BADARG;
+  if ((long)B * T == 0) return VILCO_OK;
+  hipLaunchKernelGGL(add_pe_kernel, dim3(ew_grid((long)B * T * C)), dim3(EW_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), out, x, pe, len, B, T, C);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_transpose2d(const float* in, float* out, int32_t batch, int32_t R, int32_t S,
+                                 void* stream) {
+  if (!in || !out || batch < 0 || R < 0 || S < 0) return VILCO_ERR_BADARG;
+  if ((long)batch * R * S == 0) return VILCO_OK;
+  if (batch > 65535) return VILCO_ERR_UNSUPPORTED;
+  dim3 grid((S + 31) / 32, (R + 31) / 32, batch);
+  hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out,
+                     R, S);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_permute3(const float* in, float* out, int32_t d0, int32_t d1, int32_t d2,
+                              int64_t off, int64_t s0, int64_t s1, int64_t s2, void* stream) {
+  if (!in || !out || d0 < 0 || d1 < 0 || d2 < 0) return VILCO_ERR_BADARG;
+  const long total = (long)d0 * d1 * d2;
+  if (total == 0) return VILCO_OK;
+  hipLaunchKernelGGL(permute3_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), in, out, d0, d1, d2, (long)off, (long)s0, (long)s1,
+                     (long)s2);
+  return vilco_launch_status();
+}

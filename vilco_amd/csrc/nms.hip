@@ -1,0 +1,291 @@
+// 1-D NMS / soft-NMS on the device: one 1024-thread workgroup per class, all classes in one launch.
+// Replaces the CPU extension nms_1d_cpu (MQ/libs/utils/csrc/nms_cpu.cpp) and the per-class python
+// loop around it (MQ/libs/utils/nms.py:124-152).  Index outputs are bit-exact: the kernels keep the
+// reference's array semantics (stable descending order for hard NMS; first-maximum pick, swap and
+// swap-with-last removal for soft-NMS), only the inner O(N) loops run in parallel.
+// Compiled with -ffp-contract=off so the IoU / decay arithmetic rounds like the reference's C++.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr int NW = NT / 64;
+
+struct Ws {
+  float* x1; float* x2; float* sc; float* ar;
+  int* ind; int* tmp; unsigned char* dead;
+};
+
+__device__ __forceinline__ Ws carve(void* ws, long n_total, long off) {
+  float* f = reinterpret_cast<float*>(ws);
+  Ws w;
+  w.x1 = f + 0 * n_total + off;
+  w.x2 = f + 1 * n_total + off;
+  w.sc = f + 2 * n_total + off;
+  w.ar = f + 3 * n_total + off;
+  w.ind = reinterpret_cast<int*>(f + 4 * n_total) + off;
+  w.tmp = reinterpret_cast<int*>(f + 5 * n_total) + off;
+  w.dead = reinterpret_cast<unsigned char*>(f + 6 * n_total) + off;
+  return w;
+}
+
+__device__ __forceinline__ float iou_1d(float ix1, float ix2, float iarea, float jx1, float jx2, float jarea) {
+  const float xx1 = fmaxf(ix1, jx1);
+  const float xx2 = fminf(ix2, jx2);
+  const float inter = fmaxf(0.f, xx2 - xx1);
+  return inter / (iarea + jarea - inter);
+}
+
+// block-wide exclusive scan of one int per thread; returns the exclusive prefix, *total = sum
+__device__ int block_excl_scan(int v, int* total, int* lds /* >= NW+1 ints */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();  // protect lds reuse
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < NW; ++w) { const int t = lds[w]; lds[w] = run; run += t; }
+    lds[NW] = run;
+  }
+  __syncthreads();
+  *total = lds[NW];
+  return lds[wave] + inc - v;
+}
+
+// ------------------------------------------------------------------------------------ hard NMS
+__global__ __launch_bounds__(NT) void nms_kernel(const float* __restrict__ segs,
+                                                 const float* __restrict__ scores,
+                                                 const long* __restrict__ seg_off, float thr,
+                                                 long* __restrict__ out_idx, long* __restrict__ out_cnt,
+                                                 void* ws_raw, long n_total) {
+  __shared__ int s_scan[NW + 1];
+  __shared__ int s_next;
+  const int cls = blockIdx.x;
+  const long off = seg_off[cls];
+  const int n = (int)(seg_off[cls + 1] - off);
+  if (n <= 0) {
+    if (threadIdx.x == 0) out_cnt[cls] = 0;
+    return;
+  }
+  Ws w = carve(ws_raw, n_total, off);
+  const float* sg = segs + off * 2;
+  const float* scr = scores + off;
+
+  // stable descending rank (ties: lower input index first) == aten CPU sort(descending=True)
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const float si = scr[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float sj = scr[j];
+      rank += (sj > si) || (sj == si && j < i);
+    }
+    w.ind[rank] = i;  // order[rank] = i
+    w.x1[rank] = sg[2 * i];
+    w.x2[rank] = sg[2 * i + 1];
+    w.ar[rank] = sg[2 * i + 1] - sg[2 * i] + 1e-6f;
+    w.dead[rank] = 0;
+  }
+  __syncthreads();
+
+  int cur = 0;  // uniform across the block
+  while (cur < n) {
+    const float ix1 = w.x1[cur], ix2 = w.x2[cur], ia = w.ar[cur];
+    for (int j = cur + 1 + threadIdx.x; j < n; j += NT) {
+      if (!w.dead[j]) {
+        const float ovr = iou_1d(ix1, ix2, ia, w.x1[j], w.x2[j], w.ar[j]);
+        if (ovr >= thr) w.dead[j] = 1;
+      }
+    }
+    __syncthreads();
+    // next surviving position after cur: NT candidates per round, minimum through LDS
+    int base = cur + 1;
+    for (;;) {
+      if (threadIdx.x == 0) s_next = n;
+      __syncthreads();
+      const int p = base + (int)threadIdx.x;
+      if (p < n && !w.dead[p]) atomicMin(&s_next, p);
+      __syncthreads();
+      const int found = s_next;
+      __syncthreads();
+      if (found < n || base + NT >= n) { base = found; break; }
+      base += NT;
+    }
+    cur = base;
+  }
+
+  // compact survivors in order
+  const int chunk = (n + NT - 1) / NT;
+  const int lo = min(n, (int)threadIdx.x * chunk), hi = min(n, lo + chunk);
+  int cnt = 0;
+  for (int j = lo; j < hi; ++j) cnt += !w.dead[j];
+  int total;
+  int pos = block_excl_scan(cnt, &total, s_scan);
+  for (int j = lo; j < hi; ++j)
+    if (!w.dead[j]) out_idx[off + pos++] = (long)w.ind[j];
+  if (threadIdx.x == 0) out_cnt[cls] = total;
+}
+
+// ------------------------------------------------------------------------------------ soft NMS
+__global__ __launch_bounds__(NT) void softnms_kernel(const float* __restrict__ segs,
+                                                     const float* __restrict__ scores,
+                                                     const long* __restrict__ seg_off, float thr,
+                                                     float sigma, float min_score, int method,
+                                                     long max_num, float* __restrict__ dets,
+                                                     long* __restrict__ out_idx,
+                                                     long* __restrict__ out_cnt, void* ws_raw,
+                                                     long n_total) {
+  __shared__ int s_scan[NW + 1];
+  __shared__ float s_val[NW];
+  __shared__ int s_pos[NW];
+  const int cls = blockIdx.x;
+  const long off = seg_off[cls];
+  const int n = (int)(seg_off[cls + 1] - off);
+  if (n <= 0) {
+    if (threadIdx.x == 0) out_cnt[cls] = 0;
+    return;
+  }
+  Ws w = carve(ws_raw, n_total, off);
+  const float* sg = segs + off * 2;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    w.x1[i] = sg[2 * i];
+    w.x2[i] = sg[2 * i + 1];
+    w.ar[i] = sg[2 * i + 1] - sg[2 * i] + 1e-6f;
+    w.sc[i] = scores[off + i];
+    w.ind[i] = i;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int nsegs = n;  // uniform
+  int i = 0;
+  for (; i < nsegs; ++i) {
+    if (max_num > 0 && i >= max_num) break;
+    // (a) first maximum of sc[i:nsegs)  (nms_cpu.cpp:91-101: strict '<' keeps the lowest position)
+    float bv = -INFINITY;
+    int bp = 0x7fffffff;
+    for (int p = i + threadIdx.x; p < nsegs; p += NT) {
+      const float v = w.sc[p];
+      if (bp == 0x7fffffff || v > bv) { bv = v; bp = p; }  // ascending p per thread: ties keep lowest
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int op = __shfl_xor(bp, o, 64);
+      if (op != 0x7fffffff && (bp == 0x7fffffff || ov > bv || (ov == bv && op < bp))) { bv = ov; bp = op; }
+    }
+    if (lane == 0) { s_val[wave] = bv; s_pos[wave] = bp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = s_val[0];
+      int p = s_pos[0];
+      for (int k = 1; k < NW; ++k) {
+        const int op = s_pos[k];
+        const float ov = s_val[k];
+        if (op != 0x7fffffff && (p == 0x7fffffff || ov > v || (ov == v && op < p))) { v = ov; p = op; }
+      }
+      // (b) swap slot i <-> p, emit det row i  (nms_cpu.cpp:103-121)
+      const float ax1 = w.x1[p], ax2 = w.x2[p], asc = w.sc[p], aar = w.ar[p];
+      const int aind = w.ind[p];
+      w.x1[p] = w.x1[i]; w.x2[p] = w.x2[i]; w.sc[p] = w.sc[i]; w.ar[p] = w.ar[i]; w.ind[p] = w.ind[i];
+      w.x1[i] = ax1; w.x2[i] = ax2; w.sc[i] = asc; w.ar[i] = aar; w.ind[i] = aind;
+      float* d = dets + (off + i) * 3;
+      d[0] = ax1; d[1] = ax2; d[2] = asc;
+      out_idx[off + i] = (long)aind;
+    }
+    __syncthreads();
+    // (c) decay every remaining score once (nms_cpu.cpp:124-143)
+    const float ix1 = w.x1[i], ix2 = w.x2[i], ia = w.ar[i];
+    const int first = i + 1;
+    const int span = nsegs - first;
+    const int chunk = (span + NT - 1) / NT;
+    const int lo = first + min(span, (int)threadIdx.x * chunk), hi = min(nsegs, lo + chunk);
+    int alive_cnt = 0;
+    for (int p = lo; p < hi; ++p) {
+      const float ovr = iou_1d(ix1, ix2, ia, w.x1[p], w.x2[p], w.ar[p]);
+      float weight = 1.f;
+      if (method == 0) { if (ovr >= thr) weight = 0.f; }
+      else if (method == 1) { if (ovr >= thr) weight = 1.f - ovr; }
+      else if (method == 2) { weight = expf(-(ovr * ovr) / sigma); }
+      const float ns = w.sc[p] * weight;
+      w.sc[p] = ns;
+      const bool dd = ns < min_score;
+      w.dead[p] = dd;
+      alive_cnt += !dd;
+    }
+    // (d) swap-with-last removals (nms_cpu.cpp:146-154), done as: k-th hole (ascending) <- k-th
+    // surviving element counted from the end; identical final array to the sequential loop.
+    int n_alive;
+    int a_before = block_excl_scan(alive_cnt, &n_alive, s_scan);  // alive in [first, lo)
+    const int new_n = first + n_alive;
+    if (n_alive != span) {
+      int a = a_before;
+      for (int p = lo; p < hi; ++p) {
+        if (!w.dead[p]) {
+          if (p >= new_n) w.tmp[n_alive - a - 1] = p;  // rank from the end among sources
+          ++a;
+        }
+      }
+      __syncthreads();
+      a = a_before;
+      for (int p = lo; p < hi; ++p) {
+        if (w.dead[p]) {
+          if (p < new_n) {
+            const int k = (p - first) - a;  // dead positions before p
+            const int src = w.tmp[k];
+            w.x1[p] = w.x1[src]; w.x2[p] = w.x2[src]; w.sc[p] = w.sc[src]; w.ar[p] = w.ar[src];
+            w.ind[p] = w.ind[src];
+          }
+        } else {
+          ++a;
+        }
+      }
+      nsegs = new_n;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_cnt[cls] = i;
+}
+
+}  // namespace
+
+extern "C" size_t vilco_nms_workspace(int64_t n_total, int32_t nseg) {
+  (void)nseg;
+  return (size_t)(n_total > 0 ? n_total : 1) * 7 * sizeof(float);
+}
+
+extern "C" int vilco_nms_1d(const float* segs, const float* scores, const int64_t* seg_off,
+                            int32_t nseg, int64_t n_total, float iou_threshold, int64_t* out_idx,
+                            int64_t* out_cnt, void* workspace, size_t workspace_bytes, void* stream) {
+  if (nseg < 0 || !seg_off || !out_cnt) return VILCO_ERR_BADARG;
+  if (nseg == 0) return VILCO_OK;
+  if (!segs || !scores || !out_idx || !workspace) return VILCO_ERR_BADARG;
+  if (n_total < 0 || workspace_bytes < vilco_nms_workspace(n_total, nseg)) return VILCO_ERR_WORKSPACE;
+  hipLaunchKernelGGL(nms_kernel, dim3(nseg), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), segs,
+                     scores, reinterpret_cast<const long*>(seg_off), iou_threshold,
+                     reinterpret_cast<long*>(out_idx), reinterpret_cast<long*>(out_cnt), workspace, (long)n_total);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_softnms_1d(const float* segs, const float* scores, const int64_t* seg_off,
+                                int32_t nseg, int64_t n_total, float iou_threshold, float sigma,
+                                float min_score, int32_t method, int64_t max_num, float* dets,
+                                int64_t* out_idx,
+                                int64_t* out_cnt, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  if (nseg < 0 || !seg_off || !out_cnt) return VILCO_ERR_BADARG;
+  if (method < 0 || method > 2) return VILCO_ERR_BADARG;
+  if (nseg == 0) return VILCO_OK;
+  if (!segs || !scores || !dets || !out_idx || !workspace) return VILCO_ERR_BADARG;
+  if (n_total < 0 || workspace_bytes < vilco_nms_workspace(n_total, nseg)) return VILCO_ERR_WORKSPACE;
+  hipLaunchKernelGGL(softnms_kernel, dim3(nseg), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), segs,
+                     scores, reinterpret_cast<const long*>(seg_off), iou_threshold, sigma, min_score, method,
+                     (long)max_num, dets, reinterpret_cast<long*>(out_idx), reinterpret_cast<long*>(out_cnt),
+                     workspace, (long)n_total);
+  return vilco_launch_status();
+}

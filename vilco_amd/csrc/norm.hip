@@ -1,0 +1,255 @@
+// LayerNorm over the channel dim of token-major rows (HBM-bound: 8*C bytes per row fwd).
+// One wave per row, the row lives in registers (C <= 4096, C % 4 == 0): one read of x, one write
+// of y; mean / biased variance by wavefront reductions.  Reference: blocks.py:160-175 and the
+// stock nn.LayerNorm uses listed in include/vilco_hip.h.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_WAVES = LN_THREADS / 64;
+
+template <int NV>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long rows, int C,
+    float eps, int relu) {
+  const int lane = threadIdx.x & 63;
+  const long wid = (long)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+  const long wstride = (long)gridDim.x * LN_WAVES;
+  const float invC = 1.0f / (float)C;
+
+  float4 g[NV], b[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      g[i] = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+      b[i] = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+
+  for (long row = wid; row < rows; row += wstride) {
+    const float* xr = x + row * C;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        v[i] = *reinterpret_cast<const float4*>(xr + c);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mu = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+      }
+    }
+    const float var = wave_sum(q) * invC;
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+    float* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        float4 o;
+        o.x = v[i].x * rs * g[i].x + b[i].x;
+        o.y = v[i].y * rs * g[i].y + b[i].y;
+        o.z = v[i].z * rs * g[i].z + b[i].z;
+        o.w = v[i].w * rs * g[i].w + b[i].w;
+        if (relu) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(yr + c) = o;
+      }
+    }
+  }
+}
+
+// dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)),  g = dy (masked by y>0 if relu)
+// per-block partial dgamma/dbeta -> ws[block][2][C]
+template <int NV>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+    float* __restrict__ dx, float* __restrict__ ws, long rows, int C, int relu) {
+  __shared__ float red[LN_WAVES][64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long wid = (long)blockIdx.x * LN_WAVES + wave;
+  const long wstride = (long)gridDim.x * LN_WAVES;
+  const float invC = 1.0f / (float)C;
+
+  float4 gm[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    gm[i] = (c < C && gamma) ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  for (long row = wid; row < rows; row += wstride) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        g[i] = *reinterpret_cast<const float4*>(dy + row * C + c);
+        if (relu) {
+          const float4 yy = *reinterpret_cast<const float4*>(y + row * C + c);
+          if (!(yy.x > 0.f)) g[i].x = 0.f;
+          if (!(yy.y > 0.f)) g[i].y = 0.f;
+          if (!(yy.z > 0.f)) g[i].z = 0.f;
+          if (!(yy.w > 0.f)) g[i].w = 0.f;
+        }
+        const float4 xv = *reinterpret_cast<const float4*>(x + row * C + c);
+        xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs;
+        xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+        dg[i].x += g[i].x * xh[i].x; dg[i].y += g[i].y * xh[i].y;
+        dg[i].z += g[i].z * xh[i].z; dg[i].w += g[i].w * xh[i].w;
+        db[i].x += g[i].x; db[i].y += g[i].y; db[i].z += g[i].z; db[i].w += g[i].w;
+        g[i].x *= gm[i].x; g[i].y *= gm[i].y; g[i].z *= gm[i].z; g[i].w *= gm[i].w;
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+      }
+    }
+    s1 = wave_sum(s1) * invC;
+    s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        float4 o;
+        o.x = rs * (g[i].x - s1 - xh[i].x * s2);
+        o.y = rs * (g[i].y - s1 - xh[i].y * s2);
+        o.z = rs * (g[i].z - s1 - xh[i].z * s2);
+        o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+        *reinterpret_cast<float4*>(dx + row * C + c) = o;
+      }
+    }
+  }
+
+  // block reduction of the per-wave partial sums, one 256-channel slab at a time
+  float* wsb = ws + (long)blockIdx.x * 2 * C;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    for (int which = 0; which < 2; ++which) {
+      const float4 v = which == 0 ? dg[i] : db[i];
+      __syncthreads();
+      *reinterpret_cast<float4*>(&red[wave][lane * 4]) = v;
+      __syncthreads();
+      if (wave == 0 && c < C) {
+        float4 a = *reinterpret_cast<const float4*>(&red[0][lane * 4]);
+#pragma unroll
+        for (int w = 1; w < LN_WAVES; ++w) {
+          const float4 t = *reinterpret_cast<const float4*>(&red[w][lane * 4]);
+          a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        *reinterpret_cast<float4*>(wsb + which * C + c) = a;
+      }
+    }
+  }
+}
+
+// out[j] = sum_r ws[r][j]  (j < ncols); also used by every two-stage column reduction.
+// block = 64 columns x 4 row slices; slices are combined through LDS.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ ws,
+                                                          float* __restrict__ out0,
+                                                          float* __restrict__ out1, int nrows,
+                                                          int ncols, int split) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (j < ncols)
+    for (int r = slice; r < nrows; r += 4) s += ws[(long)r * ncols + j];
+  part[slice][lane] = s;
+  __syncthreads();
+  if (slice == 0 && j < ncols) {
+    s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (out1 && j >= split) out1[j - split] = s;
+    else out0[j] = s;
+  }
+}
+
+int ln_blocks(long rows, long cap = 256) {
+  long b = (rows + LN_WAVES - 1) / LN_WAVES;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+// shared with the other translation units
+void vilco_reduce_rows(const float* ws, float* out0, float* out1, int nrows, int ncols, int split,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, ws, out0, out1,
+                     nrows, ncols, split);
+}
+
+#define LN_DISPATCH(NVV, KERNEL, ...)                                                   \
+  switch (NVV) {                                                                        \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
+    case 5: hipLaunchKernelGGL((KERNEL<5>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
+    case 6: hipLaunchKernelGGL((KERNEL<6>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
+    case 7: case 8: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break; \
+    case 9: hipLaunchKernelGGL((KERNEL<9>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
+    case 10: case 11: case 12: hipLaunchKernelGGL((KERNEL<12>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break; \
+  }
+
+extern "C" int vilco_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                                   float* mean, float* rstd, int64_t rows, int32_t C, float eps,
+                                   int32_t relu, void* stream) {
+  if (!x || !y || rows < 0 || C <= 0) return VILCO_ERR_BADARG;
+  if (rows == 0) return VILCO_OK;
+  if ((C % 4) != 0 || C > 4096) return VILCO_ERR_UNSUPPORTED;
+  if (!vilco_aligned(x, 16) || !vilco_aligned(y, 16)) return VILCO_ERR_BADARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nv = (C + 255) / 256;
+  dim3 grid(ln_blocks(rows, 2048));
+  LN_DISPATCH(nv, ln_fwd_kernel, x, gamma, beta, y, mean, rstd, (long)rows, (int)C, eps, (int)relu)
+  return vilco_launch_status();
+}
+
+extern "C" size_t vilco_layernorm_bwd_workspace(int64_t rows, int32_t C) {
+  return (size_t)ln_blocks(rows) * 2 * (size_t)C * sizeof(float);
+}
+
+extern "C" int vilco_layernorm_bwd(const float* dy, const float* x, const float* y,
+                                   const float* gamma, const float* mean, const float* rstd,
+                                   float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t C,
+                                   int32_t relu, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  if (!dy || !x || !mean || !rstd || !dx || rows < 0 || C <= 0) return VILCO_ERR_BADARG;
+  if (relu && !y) return VILCO_ERR_BADARG;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return VILCO_ERR_BADARG;
+  if (rows == 0) return VILCO_OK;
+  if ((C % 4) != 0 || C > 4096) return VILCO_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < vilco_layernorm_bwd_workspace(rows, C)) return VILCO_ERR_WORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nv = (C + 255) / 256;
+  const int nb = ln_blocks(rows);
+  dim3 grid(nb);
+  float* ws = reinterpret_cast<float*>(workspace);
+  LN_DISPATCH(nv, ln_bwd_kernel, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, (int)relu)
+  if (dgamma && dbeta) vilco_reduce_rows(ws, dgamma, dbeta, nb, 2 * C, C, s);  // ws rows: [dgamma | dbeta]
+  return vilco_launch_status();
+}

@@ -1,0 +1,50 @@
+"""Losses of the MQ heads (reference: MQ/libs/modeling/losses.py:5-168).  Negligible FLOPs
+([#valid, ncls] / [#pos, 2] elementwise); round 1 evaluates them with device tensor ops under
+autograd -- the fused HIP loss kernel is listed as next work in DESIGN.md."""
+import torch
+from torch.nn import functional as F
+
+
+def sigmoid_focal_loss(inputs, targets, alpha: float = 0.25, gamma: float = 2.0, reduction: str = "none"):
+    inputs, targets = inputs.float(), targets.float()
+    p = torch.sigmoid(inputs)
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    if reduction == "mean":
+        loss = loss.mean()
+    elif reduction == "sum":
+        loss = loss.sum()
+    return loss
+
+
+def _iou_terms(inp, tgt, eps):
+    inp, tgt = inp.float(), tgt.float()
+    assert (inp >= 0.0).all(), "predicted offsets must be non-negative"
+    assert (tgt >= 0.0).all(), "GT offsets must be non-negative"
+    lp, rp, lg, rg = inp[:, 0], inp[:, 1], tgt[:, 0], tgt[:, 1]
+    inter = torch.min(rp, rg) + torch.min(lp, lg)
+    union = (lp + rp) + (lg + rg) - inter
+    return lp, rp, lg, rg, inter / union.clamp(min=eps)
+
+
+def _reduce(loss, reduction):
+    if reduction == "mean":
+        return loss.mean() if loss.numel() > 0 else 0.0 * loss.sum()
+    if reduction == "sum":
+        return loss.sum()
+    return loss
+
+
+def ctr_giou_loss_1d(input_offsets, target_offsets, reduction: str = 'none', eps: float = 1e-8):
+    _, _, _, _, iou = _iou_terms(input_offsets, target_offsets, eps)
+    return _reduce(1.0 - iou, reduction)
+
+
+def ctr_diou_loss_1d(input_offsets, target_offsets, reduction: str = 'none', eps: float = 1e-8):
+    lp, rp, lg, rg, iou = _iou_terms(input_offsets, target_offsets, eps)
+    len_c = torch.max(lp, lg) + torch.max(rp, rg)
+    rho = 0.5 * (rp - lp - rg + lg)
+    return _reduce(1.0 - iou + torch.square(rho / len_c.clamp(min=eps)), reduction)

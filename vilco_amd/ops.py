@@ -1,0 +1,660 @@
+"""Torch-facing operators backed by libvilco_hip.so (hand-written HIP for gfx950).
+
+Every operator here is a `torch.autograd.Function` whose forward AND backward launch kernels
+through the C ABI (include/vilco_hip.h) on the current HIP stream.  PyTorch only provides device
+memory, the stream and the autograd tape.  Activations are token-major fp32 `[B, T, C]`.
+
+There is deliberately no CPU / ATen fallback: a non-CUDA tensor raises.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, TAP_A, TAP_B, TAP_NONE, GemmDesc
+
+# 0 = split-bf16 (hi+lo, 3 MFMAs, fp32-parity mode), 1 = single bf16 pass
+_precision = 0
+
+
+def set_precision(p):
+    """'split' / 0: fp32-accurate split-bf16 MFMA;  'bf16' / 1: single bf16 pass."""
+    global _precision
+    _precision = {"split": 0, "fp32": 0, 0: 0, "bf16": 1, 1: 1}[p]
+
+
+def get_precision():
+    return _precision
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("vilco_amd ops run on the HIP device only (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError("expected scalar type Float, got %s" % t.dtype)
+        if not t.is_contiguous():
+            raise RuntimeError("tensor must be contiguous")
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 4), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------------------- GEMM
+def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), sB=(0, 0),
+         sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
+         bias=None, preact=None, act=ACT_NONE, row_len=None, rowT=0, colscale=None, residual=None,
+         res_masked=0, precision=None):
+    """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements."""
+    lib = _lib.load()
+    d = GemmDesc()
+    d.A = A.data_ptr() + 4 * offA
+    d.B = B.data_ptr() + 4 * offB
+    d.C = Cc.data_ptr() + 4 * offC
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.a_kcontig, d.b_kcontig = int(a_kc), int(b_kc)
+    d.lda, d.ldb, d.ldc = int(lda), int(ldb), int(ldc)
+    d.batch_outer, d.batch_inner = int(batch[0]), int(batch[1])
+    d.sAo, d.sAi = int(sA[0]), int(sA[1])
+    d.sBo, d.sBi = int(sB[0]), int(sB[1])
+    d.sCo, d.sCi = int(sC[0]), int(sC[1])
+    d.tap_operand, d.tapC, d.tapT = int(tap), int(tapC), int(tapT)
+    d.precision = _precision if precision is None else int(precision)
+    d.alpha, d.beta = float(alpha), float(beta)
+    d.bias = _p(bias)
+    d.preact = None if preact is None else preact.data_ptr() + 4 * offC
+    d.act = int(act)
+    d.row_len = _p(row_len)
+    d.rowT = int(rowT)
+    d.colscale = _p(colscale)
+    d.residual = None if residual is None else residual.data_ptr() + 4 * offC
+    d.res_masked = int(res_masked)
+    _lib.check(lib.vilco_gemm(C.byref(d), _stream()))
+
+
+def _act_bwd(dy, aux, act, lens, T, want_bias):
+    """dz = dy * act'(aux) * rowmask, optional column sums -> (dz, dbias)."""
+    lib = _lib.load()
+    rows, Cn = dy.numel() // dy.shape[-1], dy.shape[-1]
+    dz = torch.empty_like(dy)
+    db = torch.empty(Cn, dtype=torch.float32, device=dy.device) if want_bias else None
+    ws = _ws(lib.vilco_colsum_workspace(rows, Cn), dy.device) if want_bias else None
+    _lib.check(lib.vilco_act_bwd(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
+                                 int(T or 0), rows, Cn, _p(ws), ws.numel() if ws is not None else 0,
+                                 _stream()))
+    return dz, db
+
+
+def colsum(x2d):
+    lib = _lib.load()
+    rows, Cn = x2d.shape
+    out = torch.empty(Cn, dtype=torch.float32, device=x2d.device)
+    ws = _ws(lib.vilco_colsum_workspace(rows, Cn), x2d.device)
+    _lib.check(lib.vilco_colsum(x2d.data_ptr(), out.data_ptr(), rows, Cn, ws.data_ptr(), ws.numel(),
+                                _stream()))
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) * rowmask.  x [..., K] token-major, W [N, K] (conv1x1 / nn.Linear weight)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, lens, T):
+        _chk(x, w, b)
+        K = x.shape[-1]
+        N = w.shape[0]
+        assert w.numel() == N * K, "weight shape %s does not match input dim %d" % (tuple(w.shape), K)
+        M = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        pre = torch.empty_like(y) if act == ACT_GELU else None
+        gemm(x, w, y, M, N, K, 1, 1, K, K, N, bias=b, preact=pre, act=act, row_len=lens,
+             rowT=T or 0)
+        ctx.act, ctx.T = act, T
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, pre if act == ACT_GELU else (y if act == ACT_RELU else None), lens)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, aux, lens = ctx.saved_tensors
+        dy = dy.contiguous()
+        K, N = x.shape[-1], w.shape[0]
+        M = x.numel() // K
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.act != ACT_NONE or lens is not None:
+            dz, db = _act_bwd(dy, aux, ctx.act, lens, ctx.T, need_db)
+        else:
+            dz, db = dy, (colsum(dy.view(M, N)) if need_db else None)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(dz, w, dx, M, K, N, 1, 0, N, K, K)            # dX = dZ W        (NN)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            gemm(dz, x, dw, N, K, M, 0, 0, N, K, K)            # dW = dZ^T X      (TN)
+        return dx, dw, db, None, None, None
+
+
+def linear(x, w, b=None, act=ACT_NONE, lens=None, T=None):
+    return _Linear.apply(x, w, b, act, lens, T)
+
+
+class _LinearKN(torch.autograd.Function):
+    """y = x W + b with W stored [K, N] (XLNet's einsum("ibh,hnd->ibnd") projections,
+    modeling_xlnet_x.py:437-443, viewed as [D, H*hd])."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _chk(x, w, b)
+        K = x.shape[-1]
+        N = w.numel() // K
+        M = x.numel() // K
+        y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        gemm(x, w, y, M, N, K, 1, 0, K, N, N, bias=b)                 # NN
+        ctx.has_bias = b is not None
+        ctx.bshape = None if b is None else b.shape
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        K = x.shape[-1]
+        N = w.numel() // K
+        M = x.numel() // K
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(dy, w, dx, M, K, N, 1, 1, N, N, K)                   # dX = dY W^T   (NT)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            gemm(x, dy, dw, K, N, M, 0, 0, K, N, N)                   # dW = X^T dY   (TN)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy.view(M, N)).view(ctx.bshape)
+        return dx, dw, db
+
+
+def linear_kn(x, w, b=None):
+    return _LinearKN.apply(x, w, b)
+
+
+def permute3(src, dims, off, strides):
+    lib = _lib.load()
+    out = torch.empty(dims, dtype=torch.float32, device=src.device)
+    _lib.check(lib.vilco_permute3(src.data_ptr(), out.data_ptr(), dims[0], dims[1], dims[2], off,
+                                  strides[0], strides[1], strides[2], _stream()))
+    return out
+
+
+class _Conv3(torch.autograd.Function):
+    """k=3 'same' conv over time + bias, output rows masked (MaskedConv1D, blocks.py:106-130).
+    x [B,T,Cin], w [Cout,Cin,3] (reference layout) -> y [B,T,Cout].  Implicit GEMM over overlapped
+    token rows (K = 3*Cin), no im2col buffer."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, lens):
+        _chk(x, w, b)
+        B, T, Cin = x.shape
+        Cout = w.shape[0]
+        assert w.shape[1] == Cin and w.shape[2] == 3
+        wp = permute3(w, (Cout, 3, Cin), 0, (Cin * 3, 1, 3))          # [Cout][tap][Cin]
+        y = torch.empty(B, T, Cout, dtype=torch.float32, device=x.device)
+        gemm(x, wp, y, B * T, Cout, 3 * Cin, 1, 1, Cin, 3 * Cin, Cout, tap=TAP_A, tapC=Cin, tapT=T,
+             bias=b, row_len=lens, rowT=T)
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, lens)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, lens = ctx.saved_tensors
+        B, T, Cin = x.shape
+        Cout = w.shape[0]
+        dy = dy.contiguous()
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if lens is not None:
+            dz, db = _act_bwd(dy, None, ACT_NONE, lens, T, need_db)
+        else:
+            dz, db = dy, (colsum(dy.view(B * T, Cout)) if need_db else None)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # wt[ci][j'][co] = w[co][ci][2-j']: dX is the k=3 conv of dZ with flipped taps
+            wt = permute3(w, (Cin, 3, Cout), 2, (3, -1, Cin * 3))
+            dx = torch.empty_like(x)
+            gemm(dz, wt, dx, B * T, Cin, 3 * Cout, 1, 1, Cout, 3 * Cout, Cin, tap=TAP_A, tapC=Cout,
+                 tapT=T)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.empty(Cout, 3 * Cin, dtype=torch.float32, device=x.device)
+            gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
+                 tapT=T)
+            dw = permute3(dwp, (Cout, Cin, 3), 0, (3 * Cin, 1, Cin))
+        return dx, dw, db, None
+
+
+def conv3(x, w, b=None, lens=None):
+    return _Conv3.apply(x, w, b, lens)
+
+
+# ---------------------------------------------------------------------------------------- LayerNorm
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        _chk(x, gamma, beta)
+        lib = _lib.load()
+        Cn = x.shape[-1]
+        rows = x.numel() // Cn
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.check(lib.vilco_layernorm_fwd(x.data_ptr(), _p(gamma), _p(beta), y.data_ptr(),
+                                           mean.data_ptr(), rstd.data_ptr(), rows, Cn, eps,
+                                           int(relu), _stream()))
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        lib = _lib.load()
+        dy = dy.contiguous()
+        Cn = x.shape[-1]
+        rows = x.numel() // Cn
+        dx = torch.empty_like(x)
+        dg = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        db = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.vilco_layernorm_bwd_workspace(rows, Cn), x.device)
+        _lib.check(lib.vilco_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _p(y), _p(gamma),
+                                           mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                           dg.data_ptr(), db.data_ptr(), rows, Cn, int(ctx.relu),
+                                           ws.data_ptr(), ws.numel(), _stream()))
+        return dx, dg.view_as(gamma), db.view_as(gamma), None, None
+
+
+def layernorm(x, gamma, beta, eps=1e-5, relu=False):
+    """gamma/beta may have the reference's [1,C,1] shape (blocks.py:152-155) or [C]."""
+    return _LayerNorm.apply(x, gamma, beta, float(eps), bool(relu))
+
+
+# ---------------------------------------------------------------------------------------- dwconv / pool
+class _DwConv3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, lens, stride):
+        _chk(x, w)
+        lib = _lib.load()
+        B, T, Cn = x.shape
+        y = torch.empty(B, T // stride, Cn, dtype=torch.float32, device=x.device)
+        _lib.check(lib.vilco_dwconv3_fwd(x.data_ptr(), w.data_ptr(), lens.data_ptr(), y.data_ptr(), B,
+                                         T, Cn, stride, _stream()))
+        ctx.stride = stride
+        ctx.save_for_backward(x, w, lens)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, lens = ctx.saved_tensors
+        lib = _lib.load()
+        dy = dy.contiguous()
+        B, T, Cn = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        ws = _ws(lib.vilco_dwconv3_bwd_workspace(B, T, Cn, ctx.stride), x.device)
+        _lib.check(lib.vilco_dwconv3_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), lens.data_ptr(),
+                                         _p(dx), _p(dw), B, T, Cn, ctx.stride, ws.data_ptr(),
+                                         ws.numel(), _stream()))
+        return dx, dw, None, None
+
+
+def dwconv3(x, w, lens, stride):
+    """w: [C,1,3] (reference depthwise conv weight, blocks.py:315-318)."""
+    return _DwConv3.apply(x, w, lens, int(stride))
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lens):
+        _chk(x)
+        lib = _lib.load()
+        B, T, Cn = x.shape
+        y = torch.empty(B, T // 2, Cn, dtype=torch.float32, device=x.device)
+        _lib.check(lib.vilco_maxpool3s2_fwd(x.data_ptr(), lens.data_ptr(), y.data_ptr(), B, T, Cn,
+                                            _stream()))
+        ctx.save_for_backward(x, lens)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, lens = ctx.saved_tensors
+        lib = _lib.load()
+        dy = dy.contiguous()
+        B, T, Cn = x.shape
+        dx = torch.empty_like(x)
+        _lib.check(lib.vilco_maxpool3s2_bwd(dy.data_ptr(), x.data_ptr(), lens.data_ptr(),
+                                            dx.data_ptr(), B, T, Cn, _stream()))
+        return dx, None
+
+
+def maxpool3s2(x, lens):
+    return _MaxPool.apply(x, lens)
+
+
+# ---------------------------------------------------------------------------------------- glue
+class _ScaleAdd(torch.autograd.Function):
+    """out = a*(mask_a ? m : 1) + colscale (.) rowscale (.) b   (blocks.py:567,573,576)."""
+
+    @staticmethod
+    def forward(ctx, a, b, colscale, rowscale, lens, mask_a):
+        _chk(a, b, colscale, rowscale)
+        lib = _lib.load()
+        B, T, Cn = b.shape
+        out = torch.empty_like(b)
+        _lib.check(lib.vilco_scale_add_fwd(out.data_ptr(), _p(a), b.data_ptr(), _p(colscale),
+                                           _p(rowscale), _p(lens), int(mask_a), B, T, Cn, _stream()))
+        ctx.mask_a = int(mask_a)
+        ctx.has_a = a is not None
+        ctx.save_for_backward(b, colscale, rowscale, lens)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, colscale, rowscale, lens = ctx.saved_tensors
+        lib = _lib.load()
+        dout = dout.contiguous()
+        B, T, Cn = b.shape
+        need_a = ctx.has_a and ctx.needs_input_grad[0]
+        need_b = ctx.needs_input_grad[1]
+        need_cs = colscale is not None and ctx.needs_input_grad[2]
+        plain_a = need_a and not (ctx.mask_a and lens is not None)
+        da = dout if plain_a else (torch.empty_like(b) if need_a else None)
+        plain_b = need_b and colscale is None and rowscale is None
+        db = dout if plain_b else (torch.empty_like(b) if need_b else None)
+        dcs = torch.empty(Cn, dtype=torch.float32, device=b.device) if need_cs else None
+        if (need_a and not plain_a) or (need_b and not plain_b) or need_cs:
+            ws = _ws(lib.vilco_colsum_workspace(B * T, Cn), b.device) if need_cs else None
+            _lib.check(lib.vilco_scale_add_bwd(
+                dout.data_ptr(), b.data_ptr(), _p(colscale), _p(rowscale), _p(lens), ctx.mask_a,
+                None if plain_a else _p(da), None if plain_b else _p(db), _p(dcs), B, T, Cn, _p(ws),
+                ws.numel() if ws is not None else 0, _stream()))
+        return da, db, (dcs.view_as(colscale) if need_cs else None), None, None, None
+
+
+def scale_add(a, b, colscale=None, rowscale=None, lens=None, mask_a=False):
+    return _ScaleAdd.apply(a, b, colscale, rowscale, lens, bool(mask_a))
+
+
+class _Axpby(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        _chk(a, b)
+        lib = _lib.load()
+        out = torch.empty_like(a)
+        _lib.check(lib.vilco_axpby(out.data_ptr(), a.data_ptr(), _p(b), alpha, beta, a.numel(),
+                                   _stream()))
+        ctx.alpha, ctx.beta = alpha, beta
+        ctx.has_b = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        dout = dout.contiguous()
+
+        def scaled(s):
+            if s == 1.0:
+                return dout
+            o = torch.empty_like(dout)
+            _lib.check(lib.vilco_axpby(o.data_ptr(), dout.data_ptr(), None, s, 0.0, dout.numel(),
+                                       _stream()))
+            return o
+        da = scaled(ctx.alpha) if ctx.needs_input_grad[0] else None
+        db = scaled(ctx.beta) if (ctx.has_b and ctx.needs_input_grad[1]) else None
+        return da, db, None, None
+
+
+def axpby(a, b, alpha, beta):
+    return _Axpby.apply(a, b, float(alpha), float(beta))
+
+
+class _AddPE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pe, lens):
+        _chk(x, pe)
+        lib = _lib.load()
+        B, T, Cn = x.shape
+        out = torch.empty_like(x)
+        _lib.check(lib.vilco_add_pe(out.data_ptr(), x.data_ptr(), pe.data_ptr(), lens.data_ptr(), B, T,
+                                    Cn, _stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, None, None
+
+
+def add_pe(x, pe_tm, lens):
+    """x + pe[t] * mask; pe_tm is the [T, C] token-major slice of the sinusoid table."""
+    return _AddPE.apply(x, pe_tm, lens)
+
+
+class _Transpose(torch.autograd.Function):
+    """[Z, R, S] -> [Z, S, R] (the channel-first <-> token-major boundary)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        lib = _lib.load()
+        Z, R, S = x.shape
+        out = torch.empty(Z, S, R, dtype=torch.float32, device=x.device)
+        _lib.check(lib.vilco_transpose2d(x.data_ptr(), out.data_ptr(), Z, R, S, _stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return _Transpose.apply(dout.contiguous())
+
+
+def transpose(x):
+    return _Transpose.apply(x)
+
+
+def mask_rows_(x, lens):
+    """in place x[b,t,:] = 0 for t >= lens[b] (no autograd; used on inputs)."""
+    lib = _lib.load()
+    B, T, Cn = x.shape
+    _lib.check(lib.vilco_mask_rows(x.data_ptr(), lens.data_ptr(), B, T, Cn, _stream()))
+    return x
+
+
+# ---------------------------------------------------------------------------------------- attention
+MASK_KEYS, MASK_XLNET, MASK_NONE = 0, 1, 2
+
+
+def _softmax_(s, kv_len, B, H, Tq, Tk, mode):
+    lib = _lib.load()
+    _lib.check(lib.vilco_softmax_fwd(s.data_ptr(), _p(kv_len), B, H, Tq, Tk, mode, _stream()))
+
+
+class _Attention(torch.autograd.Function):
+    """softmax(scale * q k^T + mask) v per head; q [B,Tq,C], k/v [B,Tk,C], heads = channel slices
+    (blocks.py:383-400 / 251-265).  Round 1: scores are materialised ([B,H,Tq,Tk] fp32) and the
+    contractions run on the batched MFMA GEMM; P is kept for backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, kv_len, H, scale, mode):
+        _chk(q, k, v)
+        B, Tq, Cn = q.shape
+        Tk = k.shape[1]
+        hd = Cn // H
+        P = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=q.device)
+        gemm(q, k, P, Tq, Tk, hd, 1, 1, Cn, Cn, Tk, batch=(B, H), sA=(Tq * Cn, hd), sB=(Tk * Cn, hd),
+             sC=(H * Tq * Tk, Tq * Tk), alpha=scale)
+        _softmax_(P, kv_len, B, H, Tq, Tk, mode)
+        o = torch.empty_like(q)
+        gemm(P, v, o, Tq, hd, Tk, 1, 0, Tk, Cn, Cn, batch=(B, H), sA=(H * Tq * Tk, Tq * Tk),
+             sB=(Tk * Cn, hd), sC=(Tq * Cn, hd))
+        ctx.H, ctx.scale = H, scale
+        ctx.save_for_backward(q, k, v, P)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, P = ctx.saved_tensors
+        lib = _lib.load()
+        do = do.contiguous()
+        H, scale = ctx.H, ctx.scale
+        B, Tq, Cn = q.shape
+        Tk = k.shape[1]
+        hd = Cn // H
+        sP = (H * Tq * Tk, Tq * Tk)
+        dv = torch.empty_like(v)
+        gemm(P, do, dv, Tk, hd, Tq, 0, 0, Tk, Cn, Cn, batch=(B, H), sA=sP, sB=(Tq * Cn, hd),
+             sC=(Tk * Cn, hd))                                                 # dV = P^T dO
+        dP = torch.empty_like(P)
+        gemm(do, v, dP, Tq, Tk, hd, 1, 1, Cn, Cn, Tk, batch=(B, H), sA=(Tq * Cn, hd),
+             sB=(Tk * Cn, hd), sC=sP)                                          # dP = dO V^T
+        _lib.check(lib.vilco_softmax_bwd(dP.data_ptr(), P.data_ptr(), B, H, Tq, Tk, _stream()))
+        dq = torch.empty_like(q)
+        gemm(dP, k, dq, Tq, hd, Tk, 1, 0, Tk, Cn, Cn, batch=(B, H), sA=sP, sB=(Tk * Cn, hd),
+             sC=(Tq * Cn, hd), alpha=scale)                                    # dQ = dS K
+        dk = torch.empty_like(k)
+        gemm(dP, q, dk, Tk, hd, Tq, 0, 0, Tk, Cn, Cn, batch=(B, H), sA=sP, sB=(Tq * Cn, hd),
+             sC=(Tk * Cn, hd), alpha=scale)                                    # dK = dS^T Q
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q, k, v, kv_len, n_head, scale=None, mode=MASK_KEYS):
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1] // n_head)
+    return _Attention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode))
+
+
+class _RelAttention(torch.autograd.Function):
+    """XLNet relative attention core (modeling_xlnet_x.py:270-320, bi / no mems / no segments):
+    score = scale * ((q + r_w_bias) k^T + rel_shift((q + r_r_bias) k_r^T)) - 1e30 * mask, softmax, @ v.
+    qw = q + r_w_bias and qr = q + r_r_bias are formed by the caller.  kr: [2T, C] (no batch)."""
+
+    @staticmethod
+    def forward(ctx, qw, qr, k, v, kr, kv_len, H, scale):
+        _chk(qw, qr, k, v, kr)
+        lib = _lib.load()
+        B, T, Cn = qw.shape
+        hd = Cn // H
+        sP = (H * T * T, T * T)
+        P = torch.empty(B, H, T, T, dtype=torch.float32, device=qw.device)
+        gemm(qw, k, P, T, T, hd, 1, 1, Cn, Cn, T, batch=(B, H), sA=(T * Cn, hd), sB=(T * Cn, hd), sC=sP,
+             alpha=scale)
+        bd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
+        gemm(qr, kr, bd, T, 2 * T, hd, 1, 1, Cn, Cn, 2 * T, batch=(B, H), sA=(T * Cn, hd), sB=(0, hd),
+             sC=(H * T * 2 * T, T * 2 * T))
+        _lib.check(lib.vilco_relshift_add(P.data_ptr(), bd.data_ptr(), scale, B, H, T, _stream()))
+        del bd
+        _softmax_(P, kv_len, B, H, T, T, MASK_XLNET)
+        o = torch.empty_like(qw)
+        gemm(P, v, o, T, hd, T, 1, 0, T, Cn, Cn, batch=(B, H), sA=sP, sB=(T * Cn, hd), sC=(T * Cn, hd))
+        ctx.H, ctx.scale = H, scale
+        ctx.save_for_backward(qw, qr, k, v, kr, P)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qw, qr, k, v, kr, P = ctx.saved_tensors
+        lib = _lib.load()
+        do = do.contiguous()
+        H, scale = ctx.H, ctx.scale
+        B, T, Cn = qw.shape
+        hd = Cn // H
+        sP = (H * T * T, T * T)
+        sX = (T * Cn, hd)
+        dv = torch.empty_like(v)
+        gemm(P, do, dv, T, hd, T, 0, 0, T, Cn, Cn, batch=(B, H), sA=sP, sB=sX, sC=sX)
+        dS = torch.empty_like(P)
+        gemm(do, v, dS, T, T, hd, 1, 1, Cn, Cn, T, batch=(B, H), sA=sX, sB=sX, sC=sP)
+        _lib.check(lib.vilco_softmax_bwd(dS.data_ptr(), P.data_ptr(), B, H, T, T, _stream()))
+        dqw = torch.empty_like(qw)
+        gemm(dS, k, dqw, T, hd, T, 1, 0, T, Cn, Cn, batch=(B, H), sA=sP, sB=sX, sC=sX, alpha=scale)
+        dk = torch.empty_like(k)
+        gemm(dS, qw, dk, T, hd, T, 0, 0, T, Cn, Cn, batch=(B, H), sA=sP, sB=sX, sC=sX, alpha=scale)
+        # position term: d(bd) = scale * unshift(dS)
+        dbd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
+        _lib.check(lib.vilco_relshift_bwd(dS.data_ptr(), dbd.data_ptr(), scale, B, H, T, _stream()))
+        sB2 = (H * T * 2 * T, T * 2 * T)
+        dqr = torch.empty_like(qr)
+        gemm(dbd, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=(0, hd), sC=sX)
+        # d(kr)[2T, hd] per head = sum_b dbd[b]^T qr[b]: accumulate over the batch with beta = 1
+        dkr = torch.zeros_like(kr)
+        for b in range(B):
+            gemm(dbd, qr, dkr, 2 * T, hd, T, 0, 0, 2 * T, Cn, Cn, batch=(1, H), sA=(0, T * 2 * T),
+                 sB=(0, hd), sC=(0, hd), offA=b * H * T * 2 * T, offB=b * T * Cn, beta=1.0)
+        return dqw, dqr, dk, dv, dkr, None, None, None
+
+
+def rel_attention(qw, qr, k, v, kr, kv_len, n_head, scale):
+    return _RelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale))
+
+
+class _ChannelAttn(torch.autograd.Function):
+    """ChannelAttention core (blocks.py:426-434) on a fused qkv [B,T,3C]:
+    A_h = softmax_rows(scale * k_h^T v_h)  [hd,hd];  out_h[t,:] = q_h[t,:] A_h^T."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, scale):
+        _chk(qkv)
+        B, T, C3 = qkv.shape
+        Cn = C3 // 3
+        hd = Cn // H
+        sQ = (T * C3, hd)
+        A = torch.empty(B, H, hd, hd, dtype=torch.float32, device=qkv.device)
+        gemm(qkv, qkv, A, hd, hd, T, 0, 0, C3, C3, hd, batch=(B, H), sA=sQ, sB=sQ, sC=(H * hd * hd, hd * hd),
+             offA=Cn, offB=2 * Cn, alpha=scale)                                  # (k*scale)^T v
+        _softmax_(A, None, B, H, hd, hd, MASK_NONE)
+        out = torch.empty(B, T, Cn, dtype=torch.float32, device=qkv.device)
+        gemm(qkv, A, out, T, hd, hd, 1, 1, C3, hd, Cn, batch=(B, H), sA=sQ, sB=(H * hd * hd, hd * hd),
+             sC=(T * Cn, hd))                                                    # q A^T
+        ctx.H, ctx.scale = H, scale
+        ctx.save_for_backward(qkv, A)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, A = ctx.saved_tensors
+        lib = _lib.load()
+        dout = dout.contiguous()
+        H, scale = ctx.H, ctx.scale
+        B, T, C3 = qkv.shape
+        Cn = C3 // 3
+        hd = Cn // H
+        sQ = (T * C3, hd)
+        sA_ = (H * hd * hd, hd * hd)
+        sO = (T * Cn, hd)
+        dqkv = torch.empty_like(qkv)
+        # dq[t,e] = sum_d dout[t,d] A[d,e]                                   (NN)
+        gemm(dout, A, dqkv, T, hd, hd, 1, 0, Cn, hd, C3, batch=(B, H), sA=sO, sB=sA_, sC=sQ)
+        # dA[d,e] = sum_t dout[t,d] q[t,e]                                   (TN)
+        dA = torch.empty_like(A)
+        gemm(dout, qkv, dA, hd, hd, T, 0, 0, Cn, C3, hd, batch=(B, H), sA=sO, sB=sQ, sC=sA_)
+        _lib.check(lib.vilco_softmax_bwd(dA.data_ptr(), A.data_ptr(), B, H, hd, hd, _stream()))
+        # S[d,e] = scale * sum_t k[t,d] v[t,e]:  dk[t,d] = scale * sum_e v[t,e] dS[d,e]   (NT)
+        gemm(qkv, dA, dqkv, T, hd, hd, 1, 1, C3, hd, C3, batch=(B, H), sA=sQ, sB=sA_, sC=sQ,
+             offA=2 * Cn, offC=Cn, alpha=scale)
+        # dv[t,e] = scale * sum_d k[t,d] dS[d,e]                                          (NN)
+        gemm(qkv, dA, dqkv, T, hd, hd, 1, 0, C3, hd, C3, batch=(B, H), sA=sQ, sB=sA_, sC=sQ, offA=Cn,
+             offC=2 * Cn, alpha=scale)
+        return dqkv, None, None
+
+
+def channel_attention(qkv, n_head, scale):
+    return _ChannelAttn.apply(qkv, int(n_head), float(scale))
