@@ -1,0 +1,464 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by vilco_amd/ (the product path).
+
+CPU restatement, in plain PyTorch tensor expressions, of the reference's MQ training / inference
+path: MQ/libs/modeling/{blocks,backbones,modeling_xlnet_x,necks,loc_generators,meta_archs,losses}.py.
+It is the checker the HIP path is compared with on the GPU box (where /root/reference does not exist)
+and the `cpu_baseline` ("port") that bench.py times.
+
+Functional style: every function takes the flat parameter dict `p` (a reference-format state_dict,
+any float dtype -- float64 gives a tighter checker) plus a key prefix; activations are channel-first
+[B, C, T] with bool masks [B, 1, T], exactly like the reference.  Each function cites the reference
+lines it follows.
+
+Parity pinned: tests/test_oracle_model.py checks this file (a) against the imported reference itself
+when /root/reference is present and (b) against the committed golden vectors tests/golden/model_*.pt
+that tests/golden/make_golden.py generated from the imported reference (losses, every parameter
+gradient, inference outputs; <= 1e-5 relative in fp32).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------ operators
+def masked_conv1d(x, mask, w, b=None, stride=1, groups=1):
+    """MaskedConv1D.forward, blocks.py:106-130: conv, mask[::stride] (nearest), multiply."""
+    pad = w.shape[-1] // 2
+    y = F.conv1d(x, w, b, stride=stride, padding=pad, groups=groups)
+    if stride > 1:
+        out_mask = F.interpolate(mask.to(x.dtype), size=x.shape[-1] // stride, mode='nearest')
+    else:
+        out_mask = mask.to(x.dtype)
+    return y * out_mask, out_mask.bool()
+
+
+def layer_norm_cf(x, w, b, eps=1e-5):
+    """LayerNorm over dim 1 of [B,C,T], biased variance, eps inside sqrt (blocks.py:160-175)."""
+    r = x - x.mean(dim=1, keepdim=True)
+    y = r / torch.sqrt((r ** 2).mean(dim=1, keepdim=True) + eps)
+    return y * w + b
+
+
+def ln(p, pre, x):
+    return layer_norm_cf(x, p[pre + 'weight'], p[pre + 'bias'])
+
+
+def conv1x1(p, pre, x):
+    return F.conv1d(x, p[pre + 'weight'], p[pre + 'bias'])
+
+
+def _heads(x, n_head):
+    B, C, T = x.shape
+    return x.view(B, n_head, C // n_head, T).transpose(2, 3)
+
+
+def _attend(q, k, v, key_mask, n_head):
+    """softmax((q*scale) k^T masked_fill(-inf)) (v*mask)   (blocks.py:383-400 / 251-265).
+    key_mask: bool [B, Tk]."""
+    B, C, _ = q.shape
+    scale = 1.0 / math.sqrt(C // n_head)
+    q, k, v = _heads(q, n_head), _heads(k, n_head), _heads(v, n_head)
+    att = (q * scale) @ k.transpose(-2, -1)
+    att = att.masked_fill(torch.logical_not(key_mask[:, None, None, :]), float('-inf'))
+    att = F.softmax(att, dim=-1)
+    out = att @ (v * key_mask[:, None, :, None].to(v.dtype))
+    return out.transpose(2, 3).contiguous().view(B, C, -1)
+
+
+def masked_mhca(p, pre, x, mask, n_head, stride):
+    """MaskedMHCA.forward, blocks.py:351-410 (the query conv also uses the kv stride, :313)."""
+    C = x.shape[1]
+    q, qx_mask = masked_conv1d(x, mask, p[pre + 'query_conv.conv.weight'], None, stride, C)
+    q = ln(p, pre + 'query_norm.', q)
+    k, kv_mask = masked_conv1d(x, mask, p[pre + 'key_conv.conv.weight'], None, stride, C)
+    k = ln(p, pre + 'key_norm.', k)
+    v, _ = masked_conv1d(x, mask, p[pre + 'value_conv.conv.weight'], None, stride, C)
+    v = ln(p, pre + 'value_norm.', v)
+    q, k, v = conv1x1(p, pre + 'query.', q), conv1x1(p, pre + 'key.', k), conv1x1(p, pre + 'value.', v)
+    out = _attend(q, k, v, kv_mask[:, 0, :], n_head)
+    return conv1x1(p, pre + 'proj.', out) * qx_mask.to(out.dtype), qx_mask
+
+
+def masked_mha(p, pre, x, mask_float, enc, enc_mask, n_head):
+    """MaskedMHA.forward as cross-attention, blocks.py:228-269.  enc_mask: [B, L] (long/bool)."""
+    q = conv1x1(p, pre + 'query.', x)
+    k = conv1x1(p, pre + 'key.', enc)
+    v = conv1x1(p, pre + 'value.', enc)
+    out = _attend(q, k, v, enc_mask.bool(), n_head)
+    return conv1x1(p, pre + 'proj.', out) * mask_float
+
+
+def channel_attention(p, pre, x, n_head):
+    """ChannelAttention.forward on [B,T,C], blocks.py:423-436."""
+    B, T, C = x.shape
+    qkv = F.linear(x, p[pre + 'qkv.weight'], p.get(pre + 'qkv.bias'))
+    qkv = qkv.reshape(B, T, 3, n_head, C // n_head).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = ((k * (C // n_head) ** -0.5).transpose(-1, -2) @ v).softmax(dim=-1)
+    y = (att @ q.transpose(-1, -2)).transpose(-1, -2)
+    y = y.transpose(1, 2).reshape(B, T, C)
+    return F.linear(y, p[pre + 'proj.weight'], p[pre + 'proj.bias'])
+
+
+def channel_block(p, pre, x, n_head):
+    """ChannelBlock.forward, blocks.py:459-466: norm1 is never applied, no mask, eval-mode drop_path."""
+    x = x.permute(0, 2, 1)
+    x = x + channel_attention(p, pre + 'attn.', x, n_head)
+    h = F.layer_norm(x, (x.shape[-1],), p[pre + 'norm2.weight'], p[pre + 'norm2.bias'], 1e-5)
+    h = F.linear(F.gelu(F.linear(h, p[pre + 'mlp.0.weight'], p[pre + 'mlp.0.bias'])),
+                 p[pre + 'mlp.2.weight'], p[pre + 'mlp.2.bias'])
+    return (x + h).permute(0, 2, 1)
+
+
+def adapter(p, pre, x):
+    """Adapter.layer on the TIME axis of [B,C,T] (meta_archs.py:123-148, 'parallel' mode)."""
+    h = F.gelu(F.linear(x, p[pre + 'layer.0.weight'], p[pre + 'layer.0.bias']))
+    return F.linear(h, p[pre + 'layer.2.weight'], p[pre + 'layer.2.bias'])
+
+
+def transformer_block(p, pre, x, mask, n_head, stride, t_c_alpha, cross_y=None, cross_mask=None,
+                      adapter_pre=None):
+    """TransformerBlock.forward, blocks.py:561-593, deterministic (no stochastic depth / dropout)."""
+    def dp(name, v):          # AffineDropPath scale (blocks.py:669-670) or Identity when droppath == 0
+        key = pre + name + '.scale'
+        return p[key] * v if key in p else v
+
+    h = ln(p, pre + 'ln1.', x)
+    out, out_mask = masked_mhca(p, pre + 'attn.', h, mask, n_head, stride)
+    if adapter_pre is not None:
+        out = out + adapter(p, adapter_pre, h)
+    mf = out_mask.to(out.dtype)
+    skip = F.max_pool1d(x, stride + 1, stride=stride, padding=(stride + 1) // 2) if stride > 1 else x
+    out = skip * mf + dp('drop_path_attn', out)
+    if cross_y is not None and (pre + 'cross_attn.query.weight') in p:
+        c = masked_mha(p, pre + 'cross_attn.', ln(p, pre + 'ln3.', out), mf, ln(p, pre + 'ln3.', cross_y),
+                       cross_mask, n_head)
+        out = out * mf + dp('drop_path_attn', c)
+    m = F.conv1d(F.gelu(conv1x1(p, pre + 'mlp.0.', ln(p, pre + 'ln2.', out))), p[pre + 'mlp.3.weight'],
+                 p[pre + 'mlp.3.bias'])
+    out = out + dp('drop_path_mlp', m * mf)
+    if stride == 1:
+        out = t_c_alpha * out + (1 - t_c_alpha) * channel_block(p, pre + 'channel_attn.', h, n_head)
+    return out, out_mask
+
+
+# ------------------------------------------------------------------------------ XLNet layer
+def xlnet_layer(p, pre, x, mask, n_head):
+    """XLNetModel.forward (bi, no mems / segments / target mapping; eval mode) for one layer:
+    modeling_xlnet_x.py:1075-1308, rel_attn :437-461 -> rel_attn_core :270-320, post_attention :322-332,
+    XLNetFeedForward :482-490.  x [B,T,D], mask [B,T] (1 = valid) -> [B,T,D]."""
+    B, T, D = x.shape
+    h = x.transpose(0, 1)                                           # [T,B,D]
+    att = mask.transpose(0, 1).to(x.dtype)                          # [T,B]
+    data_mask = (1.0 - att)[None]                                   # [1,T,B]
+    attn_mask = (data_mask[:, :, :, None] > 0).to(x.dtype)
+    non_tgt = ((attn_mask + (-torch.eye(T, dtype=x.dtype))[:, :, None, None]) > 0).to(x.dtype)   # [T,T,B,1]
+
+    freq_seq = torch.arange(0, D, 2.0, dtype=torch.float)
+    inv_freq = 1 / torch.pow(10000, (freq_seq / D))
+    pos_seq = torch.arange(T, -T, -1.0, dtype=torch.float)
+    sinus = torch.einsum("i,d->id", pos_seq, inv_freq)
+    pos_emb = torch.cat([torch.sin(sinus), torch.cos(sinus)], dim=-1)[:, None, :].expand(-1, B, -1).to(x.dtype)
+
+    a = pre + 'rel_attn.'
+    q = torch.einsum("ibh,hnd->ibnd", h, p[a + 'q'])
+    k = torch.einsum("ibh,hnd->ibnd", h, p[a + 'k'])
+    v = torch.einsum("ibh,hnd->ibnd", h, p[a + 'v'])
+    kr = torch.einsum("ibh,hnd->ibnd", pos_emb, p[a + 'r'])
+    ac = torch.einsum("ibnd,jbnd->bnij", q + p[a + 'r_w_bias'], k)
+    bd = torch.einsum("ibnd,jbnd->bnij", q + p[a + 'r_r_bias'], kr)
+    s = bd.shape                                                    # rel_shift_bnij, :256-268
+    bd = bd.reshape(s[0], s[1], s[3], s[2])[:, :, 1:, :].reshape(s[0], s[1], s[2], s[3] - 1)
+    bd = torch.index_select(bd, 3, torch.arange(T, dtype=torch.long))
+    d_head = p[a + 'q'].shape[-1]
+    score = (ac + bd) * (1 / (d_head ** 0.5)) - 1e30 * torch.einsum("ijbn->bnij", non_tgt)
+    prob = F.softmax(score, dim=3)
+    vec = torch.einsum("bnij,jbnd->ibnd", prob, v)
+    out = torch.einsum("ibnd,hnd->ibh", vec, p[a + 'o']) + h
+    out = F.layer_norm(out, (D,), p[a + 'layer_norm.weight'], p[a + 'layer_norm.bias'], 1e-12)
+    f = pre + 'ff.'
+    y = F.linear(F.gelu(F.linear(out, p[f + 'layer_1.weight'], p[f + 'layer_1.bias'])),
+                 p[f + 'layer_2.weight'], p[f + 'layer_2.bias'])
+    y = F.layer_norm(y + out, (D,), p[f + 'layer_norm.weight'], p[f + 'layer_norm.bias'], 1e-12)
+    return y.permute(1, 0, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------ model
+def sinusoid_pe(n_position, d_hid, dtype):
+    """get_sinusoid_encoding(max_len, D) / sqrt(D)  (blocks.py:179-190, backbones.py:62) -> [1,D,T]."""
+    pos = torch.arange(n_position, dtype=torch.float64)[:, None]
+    j = torch.arange(d_hid)
+    ang = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2 * torch.div(j, 2, rounding_mode='floor') / d_hid)
+    tab = torch.where(j % 2 == 0, torch.sin(ang), torch.cos(ang)).float()
+    return (tab.unsqueeze(0).transpose(1, 2) / (d_hid ** 0.5)).to(dtype)
+
+
+def backbone(p, cfg, x, mask, text=None, text_mask=None, training=True, adapter_blocks=(), pets_prefix='pets.'):
+    """ConvTransformerBackbone.forward, backbones.py:181-289."""
+    m = cfg
+    pre = 'backbone.'
+    n_head, arch, alpha = m['n_head'], m['backbone_arch'], m['train_cfg']['t_c_alpha']
+    T = x.shape[-1]
+    for i in range(arch[0]):
+        x, mask = masked_conv1d(x, mask, p[pre + 'embd.%d.conv.weight' % i], p.get(pre + 'embd.%d.conv.bias' % i))
+        if m['embd_with_ln']:
+            x = ln(p, pre + 'embd_norm.%d.' % i, x)
+        x = torch.relu(x)
+    if m['use_abs_pe']:
+        pe = sinusoid_pe(m['max_seq_len'], m['embd_dim'], x.dtype)
+        if (not training) and T >= m['max_seq_len']:
+            pe = F.interpolate(pe, T, mode='linear', align_corners=False)
+        x = x + pe[:, :, :T] * mask.to(x.dtype)
+    q = q_mask = None
+    if m['use_cross_modal'] and text is not None:
+        q, qm = text, text_mask
+        for i in range(arch[0]):
+            q, qm = masked_conv1d(q, qm, p[pre + 'txt_embd.%d.conv.weight' % i], p.get(pre + 'txt_embd.%d.conv.bias' % i))
+            if m['embd_with_ln']:
+                q = ln(p, pre + 'txt_embd_norm.%d.' % i, q)
+            q = torch.relu(q)
+        for i in range(arch[1]):
+            q, qm = transformer_block(p, pre + 'txt_stem.%d.' % i, q, qm, n_head, 1, 0.8)
+        q_mask = qm.squeeze(1).long()
+    for i in range(arch[1]):
+        x, mask = transformer_block(p, pre + 'stem.%d.' % i, x, mask, n_head, 1, alpha)
+    feats, masks = [x], [mask]
+    for i in range(arch[2]):
+        if i == 0:
+            if m['use_xl']:
+                x = xlnet_layer(p, pre + 'xlnet.layer.0.', x.permute(0, 2, 1), mask.squeeze(1).long(),
+                                p[pre + 'xlnet.layer.0.rel_attn.q'].shape[1]).permute(0, 2, 1)
+            else:
+                x, mask = transformer_block(p, pre + 'stem.0.', x, mask, n_head, 1, alpha)
+        ad = None
+        if i in adapter_blocks:
+            ad = pets_prefix + '%d.' % list(adapter_blocks).index(i)
+        if i in (1, 2):
+            x, mask = transformer_block(p, pre + 'branch.%d.' % i, x, mask, n_head, m['scale_factor'], alpha,
+                                        adapter_pre=ad)
+        else:
+            x, mask = transformer_block(p, pre + 'branch.%d.' % i, x, mask, n_head, m['scale_factor'], alpha, q,
+                                        q_mask, adapter_pre=ad)
+        feats.append(x)
+        masks.append(mask)
+    return feats, masks
+
+
+def neck(p, cfg, feats, masks):
+    """FPNIdentity.forward, necks.py:173-198."""
+    if cfg['fpn_with_ln']:
+        feats = [ln(p, 'neck.fpn_norms.%d.' % i, f) for i, f in enumerate(feats)]
+    return feats, masks
+
+
+def head_trunk(p, pre, cfg, x, mask):
+    for i in range(cfg['head_num_layers'] - 1):
+        x, _ = masked_conv1d(x, mask, p[pre + 'head.%d.conv.weight' % i], p.get(pre + 'head.%d.conv.bias' % i))
+        if cfg['head_with_ln']:
+            x = ln(p, pre + 'norm.%d.' % i, x)
+        x = torch.relu(x)
+    return x
+
+
+def heads(p, cfg, feats, masks):
+    """PtTransformerClsHead / RegHead forward (meta_archs.py:259-275, 334-349) + the permutes of :848-852."""
+    cls, reg = [], []
+    for l, (f, m) in enumerate(zip(feats, masks)):
+        c, _ = masked_conv1d(head_trunk(p, 'cls_head.', cfg, f, m), m, p['cls_head.cls_head.conv.weight'],
+                             p['cls_head.cls_head.conv.bias'])
+        r, _ = masked_conv1d(head_trunk(p, 'reg_head.', cfg, f, m), m, p['reg_head.offset_head.conv.weight'],
+                             p['reg_head.offset_head.conv.bias'])
+        cls.append(c.permute(0, 2, 1))
+        reg.append(F.relu(r * p['reg_head.scale.%d.scale' % l]).permute(0, 2, 1))
+    return cls, reg
+
+
+def points(cfg, level_lens, dtype=torch.float32):
+    """PointGenerator buffers (loc_generators.py:52-92): [T_l,4] = (t, lo, hi, stride)."""
+    out = []
+    strides = [cfg['scale_factor'] ** i for i in range(cfg['fpn_start_level'], cfg['backbone_arch'][-1] + 1)]
+    max_len = cfg['max_seq_len'] * cfg['max_buffer_len_factor']
+    for n, s, rr in zip(level_lens, strides, cfg['regression_range']):
+        t = torch.arange(0, max_len, s)[:, None].float()
+        k = t.shape[0]
+        pts = torch.cat((t, torch.as_tensor(rr, dtype=torch.float)[None].repeat(k, 1),
+                         torch.as_tensor(s, dtype=torch.float)[None].repeat(k, 1)), dim=1)
+        out.append(pts[:n].to(dtype))
+    return out
+
+
+def label_points_single(p, cfg, pts, seg, lab):
+    """label_points_single_video, meta_archs.py:1253-1344."""
+    tc = cfg['train_cfg']
+    n = pts.shape[0]
+    t, stride = pts[:, 0, None], pts[:, 3, None]
+    lens = (seg[:, 1] - seg[:, 0])[None, :].repeat(n, 1)
+    left, right = t - seg[None, :, 0], seg[None, :, 1] - t
+    rel = ((right - left) / 2.0) / (stride * lens)
+
+    def gauss(mu, sig):
+        mu, sig = p[mu][lab].permute(1, 0), p[sig][lab].permute(1, 0)
+        return (-(rel - mu) ** 2 / (2 * sig ** 2)).exp()
+    g_cls, g_l, g_r = gauss('mu', 'sigma'), gauss('mu_reg_left', 'sigma_reg_left'), gauss('mu_reg_right', 'sigma_reg_right')
+    reg = torch.stack((left, right), dim=-1)
+    if tc['center_sample'] == 'radius':
+        ctr = 0.5 * (seg[None, :, 0] + seg[None, :, 1])
+        lo = t - torch.maximum(ctr - stride * tc['center_sample_radius'], seg[None, :, 0])
+        hi = torch.minimum(ctr + stride * tc['center_sample_radius'], seg[None, :, 1]) - t
+        inside = torch.stack((lo, hi), -1).min(-1)[0] > 0
+    else:
+        inside = reg.min(-1)[0] > 0
+    far = reg.max(-1)[0]
+    in_range = torch.logical_and(far >= pts[:, 1, None], far <= pts[:, 2, None])
+    lens = lens.masked_fill(inside == 0, float('inf')).masked_fill(in_range == 0, float('inf'))
+    min_len, idx = lens.min(dim=1)
+    sel = torch.logical_and(lens <= (min_len[:, None] + 1e-3), lens < float('inf')).to(reg.dtype)
+    ncls = p['mu'].shape[0]
+    cls_t = (sel @ F.one_hot(lab, ncls).to(reg.dtype)).clamp(min=0.0, max=1.0)
+    rows = torch.arange(n)
+    return cls_t.detach(), (reg[rows, idx] / stride).detach(), g_cls[rows, idx], g_l[rows, idx], g_r[rows, idx]
+
+
+def sigmoid_focal(x, t, alpha=0.25, gamma=2.0):
+    """losses.py:5-52."""
+    pr = torch.sigmoid(x)
+    ce = F.binary_cross_entropy_with_logits(x, t, reduction="none")
+    p_t = pr * t + (1 - pr) * (1 - t)
+    return (alpha * t + (1 - alpha) * (1 - t)) * ce * ((1 - p_t) ** gamma)
+
+
+def diou_1d(pred, tgt, eps=1e-8):
+    """ctr_diou_loss_1d, losses.py:109-168."""
+    lp, rp, lg, rg = pred[:, 0], pred[:, 1], tgt[:, 0], tgt[:, 1]
+    inter = torch.min(rp, rg) + torch.min(lp, lg)
+    iou = inter / ((lp + rp) + (lg + rg) - inter).clamp(min=eps)
+    rho = 0.5 * (rp - lp - rg + lg)
+    return 1.0 - iou + torch.square(rho / (torch.max(lp, lg) + torch.max(rp, rg)).clamp(min=eps))
+
+
+def losses(p, cfg, masks, cls_logits, offsets, segments, labels, loss_normalizer, reduce_sim=None, n_known=0):
+    """PtTransformer.losses (meta_archs.py:1374-1524, no CL distillation) -> (dict, new loss_normalizer)."""
+    tc = cfg['train_cfg']
+    level_lens = [c.shape[1] for c in cls_logits]
+    pts = torch.cat(points(cfg, level_lens, cls_logits[0].dtype), dim=0)
+    lab = [label_points_single(p, cfg, pts, s, l) for s, l in zip(segments, labels)]
+    gt_cls = torch.stack([x[0] for x in lab])
+    gt_off = torch.stack([x[1] for x in lab])
+    w_cls, w_l, w_r = (torch.stack([x[i] for x in lab]) for i in (2, 3, 4))
+    valid = torch.cat([m.squeeze(1) for m in masks], dim=1)
+    pos = torch.logical_and(gt_cls.sum(-1) > 0, valid)
+    num_pos = int(pos.sum().item())
+    loss_normalizer = 0.9 * loss_normalizer + 0.1 * max(num_pos, 1)
+    logits = torch.cat(cls_logits, dim=1)
+    ls = tc['label_smoothing']
+    target = gt_cls[valid] * (1 - ls) + ls / (cfg['num_classes'] + 1)
+    w_cls = torch.where(pos, w_cls, torch.ones_like(w_cls))
+    cls_loss = (sigmoid_focal(logits[valid], target).sum(-1) * w_cls[valid]).sum() / loss_normalizer
+    if logits.shape[-1] != 1:
+        sc = logits.masked_fill(valid.unsqueeze(-1) == False, -1e7)     # noqa: E712
+        sc = torch.max(sc.softmax(-1), dim=1)[0]
+        inv = torch.zeros_like(sc)
+        for i, l in enumerate(labels):
+            inv[i, l] = 1
+        al_loss = (-inv * sc.log() - (1 - inv) * (1 - sc).log()).sum() / loss_normalizer
+    else:
+        al_loss = torch.zeros((1,))
+    pred = torch.cat(offsets, dim=1)[pos]
+    if num_pos == 0:
+        reg_loss = 0 * pred.sum()
+    else:
+        reg_loss = (diou_1d(pred, gt_off[pos]) * ((w_l[pos] + w_r[pos]) / 2.0) * w_cls[pos]).sum() / loss_normalizer
+    lw = tc['loss_weight'] if tc['loss_weight'] > 0 else cls_loss.detach() / max(reg_loss.item(), 0.01)
+    final = cls_loss + reg_loss * lw + al_loss * tc['al_loss_weight']
+    if n_known > 0 and cfg['cl_cfg']['name'] == 'l2p':
+        final = final - 0.1 * reduce_sim
+    return {'cls_loss': cls_loss, 'reg_loss': reg_loss, 'al_loss': al_loss, 'final_loss': final}, loss_normalizer
+
+
+def prompt_forward(p, cfg, text_tm, prompt_idx):
+    """Prompt.forward with a given index window (prompt.py:47-116, training path of meta_archs.py:761-767)."""
+    def l2n(v):
+        return v * torch.rsqrt(torch.maximum((v ** 2).sum(1, keepdim=True), torch.tensor(1e-12, dtype=v.dtype)))
+    key_n, x_n = l2n(p['prompt.prompt_key']), l2n(text_tm.mean(dim=1))
+    B = text_tm.shape[0]
+    raw = p['prompt.prompt'][prompt_idx]
+    batched = raw.reshape(B, -1, raw.shape[-1])
+    reduce_sim = torch.sum(key_n[prompt_idx] * x_n.unsqueeze(1)) / B
+    return torch.cat([batched, text_tm], dim=1), reduce_sim
+
+
+def batch_inputs(cfg, video_list, training, dtype=torch.float32):
+    """preprocessing + query_preprocessing, meta_archs.py:1134-1221 (padding to max_seq_len)."""
+    feats = [v['feats'] for v in video_list if len(v['labels']) > 0]
+    lens = torch.as_tensor([f.shape[-1] for f in feats])
+    max_len = int(lens.max())
+    if training or max_len <= cfg['max_seq_len']:
+        max_len = cfg['max_seq_len']
+    else:
+        st = cfg['scale_factor'] ** cfg['backbone_arch'][-1]
+        max_len = (max_len + st - 1) // st * st
+    x = feats[0].new_zeros((len(feats), feats[0].shape[0], max_len))
+    for f, d in zip(feats, x):
+        d[..., :f.shape[-1]].copy_(f)
+    mask = (torch.arange(max_len)[None, :] < lens[:, None]).unsqueeze(1)
+    text = text_mask = None
+    if cfg['use_cross_modal']:
+        tf = [v['prompt_feature'] for v in video_list]
+        tl = torch.as_tensor([f.shape[-1] for f in tf])
+        text = tf[0].new_zeros((len(tf), tf[0].shape[0], int(tl.max())))
+        for f, d in zip(tf, text):
+            d[..., :f.shape[-1]].copy_(f)
+        text_mask = (torch.arange(int(tl.max()))[None, :] < tl[:, None]).unsqueeze(1)
+        text = text.to(dtype)
+    return x.to(dtype), mask, text, text_mask
+
+
+def forward_network(p, cfg, video_list, training=True, task_id=-1):
+    dtype = p['mu'].dtype
+    x, mask, text, text_mask = batch_inputs(cfg, video_list, training, dtype)
+    reduce_sim = None
+    adapter_blocks = tuple(cfg['cl_cfg']['adapt_blocks']) if cfg['cl_cfg'].get('use_adapt') else ()
+    if 'prompt.prompt' in p:
+        k = cfg['cl_cfg']['topk']
+        idx = torch.arange(task_id * k, (task_id + 1) * k).unsqueeze(0).expand(text.shape[0], -1)
+        ttm, reduce_sim = prompt_forward(p, cfg, text.permute(0, 2, 1), idx)
+        text = ttm.permute(0, 2, 1)
+        tl = torch.as_tensor([v['prompt_feature'].shape[-1] for v in video_list])
+        text_mask = (torch.arange(text.shape[-1])[None, :] < tl[:, None]).unsqueeze(1)   # meta_archs.py:775-779
+    feats, masks = backbone(p, cfg, x, mask, text, text_mask, training, adapter_blocks)
+    feats, masks = neck(p, cfg, feats, masks)
+    cls, reg = heads(p, cfg, feats, masks)
+    return feats, masks, cls, reg, reduce_sim
+
+
+def forward_losses(p, cfg, video_list, loss_normalizer=None, task_id=-1, n_known=0):
+    """model(video_list, is_training=True) of the reference in deterministic (eval-dropout) mode."""
+    if loss_normalizer is None:
+        loss_normalizer = cfg['train_cfg']['init_loss_norm']
+    _, masks, cls, reg, reduce_sim = forward_network(p, cfg, video_list, True, task_id)
+    segs = [v['segments'].to(p['mu'].dtype) for v in video_list if len(v['labels']) > 0]
+    labs = [v['labels'] for v in video_list if len(v['labels']) > 0]
+    return losses(p, cfg, masks, cls, reg, segs, labs, loss_normalizer, reduce_sim, n_known)
+
+
+@torch.no_grad()
+def decode_single_video(cfg, pts, masks, cls_logits, offsets):
+    """inference_single_video, meta_archs.py:1594-1692 -> (segs, scores, labels) before NMS."""
+    tc = cfg['test_cfg']
+    segs, scores, labels = [], [], []
+    for cls_i, off_i, pts_i, m_i in zip(cls_logits, offsets, pts, masks):
+        prob = (cls_i.sigmoid() * m_i.unsqueeze(-1)).flatten()
+        keep = prob > tc['pre_nms_thresh']
+        prob, idx = prob[keep], keep.nonzero(as_tuple=True)[0]
+        k = min(tc['pre_nms_topk'], idx.size(0))
+        prob, order = prob.sort(descending=True)
+        prob, idx = prob[:k].clone(), idx[order[:k]].clone()
+        pt = torch.div(idx, cfg['num_classes'], rounding_mode='floor')
+        offs, pp = off_i[pt], pts_i[pt]
+        left, right = pp[:, 0] - offs[:, 0] * pp[:, 3], pp[:, 0] + offs[:, 1] * pp[:, 3]
+        ok = (right - left) > tc['duration_thresh']
+        segs.append(torch.stack((left, right), -1)[ok])
+        scores.append(prob[ok])
+        labels.append(torch.fmod(idx, cfg['num_classes'])[ok])
+    return torch.cat(segs), torch.cat(scores), torch.cat(labels)

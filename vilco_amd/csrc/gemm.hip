@@ -37,7 +37,7 @@ struct Operand {
   const float* p;  // batch-offset base pointer
   long ld;
   int rows;  // extent of the non-k dim (M for A, N for B)
-  int tap;   // 1 when this operand is the tapped (overlapped-row conv) operand
+  int tap;   // 1: tapped (overlapped-row conv) operand, tapC % 8 == 0;  2: tapped, any tapC (A only)
 };
 
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo, bool want_lo) {
@@ -60,15 +60,28 @@ __device__ __forceinline__ void gload_kc(float (&r)[16], const Operand& op, int 
     const int grow = row0 + row, gk = k0 + c * 8;
     bool ok = (grow < op.rows) && (gk < K);
     long off = (long)grow * op.ld + gk;
-    if (op.tap) {
+    if (op.tap == 1) {
       // contiguous dim spans taps {t-1, t, t+1}; zero the taps that fall outside the sequence
       const int tap = gk / tapC;
       const int t = grow % tapT;
       if ((tap == 0 && t == 0) || (tap == 2 && t == tapT - 1)) ok = false;
       off -= tapC;
+    } else if (op.tap == 2) {
+      off -= tapC;
     }
     float* d = &r[h * 8];
-    if (ok && VEC && gk + 8 <= K) {
+    if (op.tap == 2) {
+      // fine-grained taps (tapC not a multiple of 8, e.g. the 2- and 22-channel head outputs in
+      // their dX pass): the 8-wide chunk can straddle taps, so test every element
+      const int t = grow % tapT;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = gk + e;
+        const int tap = k / tapC;
+        const bool oke = (grow < op.rows) && (k < K) && !((tap == 0 && t == 0) || (tap == 2 && t == tapT - 1));
+        d[e] = oke ? op.p[off + e] : 0.f;
+      }
+    } else if (ok && VEC && gk + 8 <= K) {
       const float4 v0 = *reinterpret_cast<const float4*>(op.p + off);
       const float4 v1 = *reinterpret_cast<const float4*>(op.p + off + 4);
       d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w;
@@ -331,7 +344,8 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (d->row_len && d->rowT <= 0) return VILCO_ERR_BADARG;
   if (d->a_kcontig == 0 && d->b_kcontig == 1) return VILCO_ERR_UNSUPPORTED;  // "TT" is never needed
   if (d->tap_operand != VILCO_TAP_NONE) {
-    if (d->tapC <= 0 || d->tapT <= 0 || (d->tapC % 8) != 0) return VILCO_ERR_BADARG;
+    if (d->tapC <= 0 || d->tapT <= 0) return VILCO_ERR_BADARG;
+    if (d->tap_operand == VILCO_TAP_B && (d->tapC % 8) != 0) return VILCO_ERR_UNSUPPORTED;
     // tapped operand: its contiguous dim must be the 3*tapC tap span
     if (d->tap_operand == VILCO_TAP_A && !(d->a_kcontig == 1 && d->K == 3 * d->tapC)) return VILCO_ERR_BADARG;
     if (d->tap_operand == VILCO_TAP_B && !(d->b_kcontig == 0 && d->N == 3 * d->tapC)) return VILCO_ERR_BADARG;
@@ -339,8 +353,8 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   }
 
   Args a;
-  a.a = Operand{d->A, (long)d->lda, d->M, d->tap_operand == VILCO_TAP_A};
-  a.b = Operand{d->B, (long)d->ldb, d->N, d->tap_operand == VILCO_TAP_B};
+  a.a = Operand{d->A, (long)d->lda, d->M, d->tap_operand == VILCO_TAP_A ? ((d->tapC % 8) == 0 ? 1 : 2) : 0};
+  a.b = Operand{d->B, (long)d->ldb, d->N, d->tap_operand == VILCO_TAP_B ? 1 : 0};
   a.c = d->C;
   a.ldc = d->ldc;
   a.M = d->M; a.N = d->N; a.K = d->K;
