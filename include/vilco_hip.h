@@ -43,7 +43,8 @@ const char* vilco_version(void);
 /* Replaces aten::convolution / addmm / bmm / einsum under blocks.py:79,217-226,340-349,420-435, */
 /* 533-539, meta_archs.py:216-235,309-331, modeling_xlnet_x.py:284-325,437-443,474-489.         */
 /* bf16 MFMA (v_mfma_f32_16x16x32_bf16) with fp32 accumulate; precision 0 = split-bf16 (hi+lo, */
-/* 3 MFMAs, ~2^-16 relative: the fp32-parity mode), 1 = single bf16 pass.                       */
+/* 3 MFMAs, ~2^-17 relative), 1 = single bf16 pass, 2 = three-part split (6 MFMAs, ~2^-25:    */
+/* numerically an fp32 GEMM).                                                                  */
 /* ------------------------------------------------------------------------------------------ */
 enum { VILCO_ACT_NONE = 0, VILCO_ACT_RELU = 1, VILCO_ACT_GELU = 2 };
 enum { VILCO_TAP_NONE = 0, VILCO_TAP_A = 1, VILCO_TAP_B = 2 };

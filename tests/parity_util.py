@@ -1,0 +1,88 @@
+"""Helpers shared by the parity tests, smoke() and bench.py (test infrastructure)."""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(HERE, "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import cases  # noqa: E402
+from ref_import import xlnet_json  # noqa: E402  (pure helper; does not touch /root/reference)
+
+
+def load_golden(name):
+    return torch.load(os.path.join(HERE, "golden", "model_%s.pt" % name), weights_only=False)
+
+
+def golden_cfg(gold):
+    """cfg['model'] dict for a golden case (vilco_amd.core.config applies the DEFAULTS)."""
+    from vilco_amd.core.config import make_config
+    return make_config(**gold['overrides'])['model']
+
+
+def golden_inputs(gold):
+    m = golden_cfg(gold)
+    return cases.video_list(m['max_seq_len'], m['input_dim'], m['n_txt_in'], gold['L'])
+
+
+def oracle_run(gold, dtype=torch.float64, with_grads=True):
+    """oracle losses (+ grads wrt every parameter) for a golden case."""
+    from oracle import mq_oracle
+    cfg = golden_cfg(gold)
+    p = {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point() and with_grads)
+         for k, v in gold['state_dict'].items()}
+    vl = golden_inputs(gold)
+    vl = [{k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()} for d in vl]
+    losses, ln = mq_oracle.forward_losses(p, cfg, vl, task_id=gold['task_id'], n_known=gold['n_known'])
+    grads = None
+    if with_grads:
+        losses['final_loss'].backward()
+        grads = {k: v.grad for k, v in p.items()}
+    return losses, grads, ln
+
+
+def rel_err(got, want, floor=1e-12):
+    """max |got - want| / max(max |want|, floor).  `floor` keeps analytically-zero gradients (e.g. the
+    key LayerNorm bias: a constant shift of all keys cancels in softmax) from dividing noise by noise."""
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return ((got - want).abs().max() / max(want.abs().max().item(), floor)).item()
+
+
+GRAD_FLOOR = 1e-7
+
+
+def build_hip_model(gold, device="cuda:0", xl_heads=4):
+    import vilco_amd.modeling as vm
+    m = golden_cfg(gold)
+    kw = dict(m)
+    if m['use_xl']:
+        kw['xlnet_config'] = xlnet_json(m['embd_dim'], xl_heads)
+    model = vm.make_meta_arch('LocPointTransformer', **kw)
+    model.load_state_dict(gold['state_dict'])
+    model.n_known = gold['n_known']
+    return model.to(device).eval()
+
+
+def run_smoke():
+    """one tiny fwd+bwd of the MQ model on cuda:0 through the HIP path, checked against the oracle."""
+    gold = load_golden("xl")
+    model = build_hip_model(gold)
+    model.loss_normalizer = golden_cfg(gold)['train_cfg']['init_loss_norm']
+    losses = model(golden_inputs(gold), task_id=gold['task_id'], is_training=True)
+    losses['final_loss'].backward()
+    torch.cuda.synchronize()
+    want, wgrads, _ = oracle_run(gold, torch.float64)
+    for k in ('cls_loss', 'reg_loss', 'final_loss'):
+        e = rel_err(losses[k], want[k])
+        assert e < 1e-3, "smoke: %s differs from the oracle by %.3e" % (k, e)
+    worst = 0.0
+    for n_, p_ in model.named_parameters():
+        if wgrads[n_] is not None and p_.grad is not None:
+            worst = max(worst, rel_err(p_.grad, wgrads[n_], GRAD_FLOOR))
+    assert worst < 1e-3, "smoke: worst gradient rel err %.3e" % worst
+    print("smoke ok: final_loss %.6f (oracle %.6f), worst grad rel err %.2e" %
+          (float(losses['final_loss']), float(want['final_loss']), worst))

@@ -11,8 +11,9 @@
 // inside the register stage (8(k) x 2(row) patches -> one 16-byte LDS store per row).
 //
 // precision 0 ("split"): x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a*b ~= ah*bh + ah*bl +
-// al*bh (3 MFMAs), relative error ~2^-16: this is the mode that matches the fp32 reference to
-// 1e-3 through the whole network.  precision 1: single bf16 pass.
+// al*bh (3 MFMAs), relative error ~2^-17.  precision 1: single bf16 pass (2^-9).  precision 2
+// ("split3"): three bf16 parts, 6 MFMAs, ~2^-25: numerically an fp32 GEMM at 1/6 of the bf16 MFMA
+// rate (still 2.6x the fp32-MFMA peak of gfx950).
 //
 // Reference arithmetic replaced: see include/vilco_hip.h (vilco_gemm).
 #include "common.h"
@@ -40,12 +41,20 @@ struct Operand {
   int tap;   // 1: tapped (overlapped-row conv) operand, tapC % 8 == 0;  2: tapped, any tapC (A only)
 };
 
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo, bool want_lo) {
+// x = p0 + p1 + p2 (+ ~2^-27 x): p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1); the
+// subtractions are exact in fp32.
+template <int NP>
+__device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    __bf16 h = (__bf16)v[e];
-    hi[e] = h;
-    if (want_lo) lo[e] = (__bf16)(v[e] - (float)h);
+    const __bf16 h = (__bf16)v[e];
+    part[0][e] = h;
+    if (NP >= 2) {
+      const float r1 = v[e] - (float)h;
+      const __bf16 m = (__bf16)r1;
+      part[1][e] = m;
+      if (NP >= 3) part[2][e] = (__bf16)(r1 - (float)m);
+    }
   }
 }
 
@@ -93,8 +102,8 @@ __device__ __forceinline__ void gload_kc(float (&r)[16], const Operand& op, int 
   }
 }
 
-template <bool SPLIT>
-__device__ __forceinline__ void lstore_kc(const float (&r)[16], __bf16* hi, __bf16* lo, int tid) {
+template <int NP>
+__device__ __forceinline__ void lstore_kc(const float (&r)[16], __bf16* tile, int tid) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int id = tid + h * NTHREADS;
@@ -102,11 +111,11 @@ __device__ __forceinline__ void lstore_kc(const float (&r)[16], __bf16* hi, __bf
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = r[h * 8 + e];
-    bf16x8 vh, vl;
-    split8(v, vh, vl, SPLIT);
+    bf16x8 part[3];
+    splitN<NP>(v, part);
     const int o = lds_off(row, c);
-    *reinterpret_cast<bf16x8*>(hi + o) = vh;
-    if (SPLIT) *reinterpret_cast<bf16x8*>(lo + o) = vl;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(tile + q * TILE_ELEMS + o) = part[q];
   }
 }
 
@@ -143,19 +152,19 @@ __device__ __forceinline__ void gload_tr(float (&r)[16], const Operand& op, int 
   }
 }
 
-template <bool SPLIT>
-__device__ __forceinline__ void lstore_tr(const float (&r)[16], __bf16* hi, __bf16* lo, int tid) {
+template <int NP>
+__device__ __forceinline__ void lstore_tr(const float (&r)[16], __bf16* tile, int tid) {
   const int kg = tid >> 6, rg = tid & 63;
 #pragma unroll
   for (int nn = 0; nn < 2; ++nn) {
     float v[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) v[kk] = r[kk * 2 + nn];
-    bf16x8 vh, vl;
-    split8(v, vh, vl, SPLIT);
+    bf16x8 part[3];
+    splitN<NP>(v, part);
     const int o = lds_off(rg * 2 + nn, kg);
-    *reinterpret_cast<bf16x8*>(hi + o) = vh;
-    if (SPLIT) *reinterpret_cast<bf16x8*>(lo + o) = vl;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(tile + q * TILE_ELEMS + o) = part[q];
   }
 }
 
@@ -183,14 +192,13 @@ struct Args {
   Epi e;
 };
 
-template <bool A_KC, bool B_KC, bool SPLIT, bool VEC>
+template <bool A_KC, bool B_KC, int NP, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
-  // layout: [stage 2][operand 2][hi/lo (1|2)][TILE_ELEMS]
-  constexpr int NS = SPLIT ? 2 : 1;
+  // layout: [stage 2][operand 2][part NP][TILE_ELEMS]
   auto tile_ptr = [&](int stage, int opnd, int part) {
-    return smem + ((stage * 2 + opnd) * NS + part) * TILE_ELEMS;
+    return smem + ((stage * 2 + opnd) * NP + part) * TILE_ELEMS;
   };
 
   const int tid = threadIdx.x;
@@ -229,10 +237,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(Args g) {
     else      gload_tr<VEC>(rb, ob, n0, kt * BK, g.K, g.tapC, g.tapT, tid);
   };
   auto lstore = [&](int stage) {
-    if (A_KC) lstore_kc<SPLIT>(ra, tile_ptr(stage, 0, 0), tile_ptr(stage, 0, NS - 1), tid);
-    else      lstore_tr<SPLIT>(ra, tile_ptr(stage, 0, 0), tile_ptr(stage, 0, NS - 1), tid);
-    if (B_KC) lstore_kc<SPLIT>(rb, tile_ptr(stage, 1, 0), tile_ptr(stage, 1, NS - 1), tid);
-    else      lstore_tr<SPLIT>(rb, tile_ptr(stage, 1, 0), tile_ptr(stage, 1, NS - 1), tid);
+    if (A_KC) lstore_kc<NP>(ra, tile_ptr(stage, 0, 0), tid);
+    else      lstore_tr<NP>(ra, tile_ptr(stage, 0, 0), tid);
+    if (B_KC) lstore_kc<NP>(rb, tile_ptr(stage, 1, 0), tid);
+    else      lstore_tr<NP>(rb, tile_ptr(stage, 1, 0), tid);
   };
 
   gload(0);
@@ -244,36 +252,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(Args g) {
     const int st = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
 
-    const __bf16* ah = tile_ptr(st, 0, 0);
-    const __bf16* bh = tile_ptr(st, 1, 0);
-    bf16x8 fa[4], fb[4];
+    // fragments of every part; products kept (smallest first): NP=2: lh hl hh; NP=3: + mm, hl/lh with
+    // the third part.  Dropped terms are <= 2^-17 (NP=2) / 2^-26 (NP=3) relative.
+    bf16x8 fa[NP][4], fb[NP][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i] = *reinterpret_cast<const bf16x8*>(ah + lds_off(wm * 64 + i * 16 + frow, fchunk));
-      fb[i] = *reinterpret_cast<const bf16x8*>(bh + lds_off(wn * 64 + i * 16 + frow, fchunk));
-    }
-    if (SPLIT) {
-      const __bf16* al = tile_ptr(st, 0, NS - 1);
-      const __bf16* bl = tile_ptr(st, 1, NS - 1);
-      bf16x8 fal[4], fbl[4];
+    for (int q = 0; q < NP; ++q) {
+      const __bf16* at = tile_ptr(st, 0, q);
+      const __bf16* bt = tile_ptr(st, 1, q);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fal[i] = *reinterpret_cast<const bf16x8*>(al + lds_off(wm * 64 + i * 16 + frow, fchunk));
-        fbl[i] = *reinterpret_cast<const bf16x8*>(bl + lds_off(wn * 64 + i * 16 + frow, fchunk));
+        fa[q][i] = *reinterpret_cast<const bf16x8*>(at + lds_off(wm * 64 + i * 16 + frow, fchunk));
+        fb[q][i] = *reinterpret_cast<const bf16x8*>(bt + lds_off(wn * 64 + i * 16 + frow, fchunk));
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[i], fb[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fbl[j], acc[i][j], 0, 0, 0);
-        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        f32x4 c = acc[i][j];
+        if (NP == 3) {
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
+        }
+        if (NP >= 2) {
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);
+      }
 
     if (kt + 1 < nk) lstore(st ^ 1);
     __syncthreads();
@@ -309,28 +316,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(Args g) {
   }
 }
 
-template <bool A_KC, bool B_KC>
-int launch(const Args& a, int precision, bool vec, dim3 grid, hipStream_t s) {
-  const size_t lds = (size_t)2 * 2 * (precision == 0 ? 2 : 1) * TILE_ELEMS * sizeof(__bf16);
-  // 64 KiB of dynamic LDS in split mode: raise the per-kernel cap once (no-op if already allowed)
+template <bool A_KC, bool B_KC, int NP>
+int launch_np(const Args& a, bool vec, dim3 grid, hipStream_t s) {
+  const size_t lds = (size_t)2 * 2 * NP * TILE_ELEMS * sizeof(__bf16);   // 32 / 64 / 96 KiB
   static const bool attr_once = [] {
-    const int cap = 2 * 2 * 2 * TILE_ELEMS * (int)sizeof(__bf16);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<A_KC, B_KC, true, true>),
+    const int cap = 2 * 2 * NP * TILE_ELEMS * (int)sizeof(__bf16);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<A_KC, B_KC, NP, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<A_KC, B_KC, true, false>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<A_KC, B_KC, NP, false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     (void)hipGetLastError();
     return true;
   }();
   (void)attr_once;
-  if (precision == 0) {
-    if (vec) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true, true>), grid, dim3(NTHREADS), lds, s, a);
-    else     hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true, false>), grid, dim3(NTHREADS), lds, s, a);
-  } else {
-    if (vec) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, false, true>), grid, dim3(NTHREADS), lds, s, a);
-    else     hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, false, false>), grid, dim3(NTHREADS), lds, s, a);
-  }
+  if (vec) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, NP, true>), grid, dim3(NTHREADS), lds, s, a);
+  else     hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, NP, false>), grid, dim3(NTHREADS), lds, s, a);
   return vilco_launch_status();
+}
+
+template <bool A_KC, bool B_KC>
+int launch(const Args& a, int precision, bool vec, dim3 grid, hipStream_t s) {
+  // precision 0: split-bf16 (2 parts, 3 MFMAs); 1: plain bf16; 2: 3 parts, 6 MFMAs (fp32-equivalent)
+  if (precision == 0) return launch_np<A_KC, B_KC, 2>(a, vec, grid, s);
+  if (precision == 1) return launch_np<A_KC, B_KC, 1>(a, vec, grid, s);
+  return launch_np<A_KC, B_KC, 3>(a, vec, grid, s);
 }
 
 }  // namespace
@@ -339,7 +348,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return VILCO_ERR_BADARG;
   if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch_outer < 1 || d->batch_inner < 1) return VILCO_ERR_BADARG;
   if (d->M == 0 || d->N == 0) return VILCO_OK;
-  if (d->precision != 0 && d->precision != 1) return VILCO_ERR_BADARG;
+  if (d->precision < 0 || d->precision > 2) return VILCO_ERR_BADARG;
   if (d->act < 0 || d->act > 2) return VILCO_ERR_BADARG;
   if (d->row_len && d->rowT <= 0) return VILCO_ERR_BADARG;
   if (d->a_kcontig == 0 && d->b_kcontig == 1) return VILCO_ERR_UNSUPPORTED;  // "TT" is never needed

@@ -14,14 +14,15 @@ import torch
 from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, TAP_A, TAP_B, TAP_NONE, GemmDesc
 
-# 0 = split-bf16 (hi+lo, 3 MFMAs, fp32-parity mode), 1 = single bf16 pass
-_precision = 0
+# 0 = split-bf16 (hi+lo, 3 MFMAs), 1 = single bf16 pass, 2 = three-part split (6 MFMAs, fp32-equivalent)
+_precision = 2
 
 
 def set_precision(p):
-    """'split' / 0: fp32-accurate split-bf16 MFMA;  'bf16' / 1: single bf16 pass."""
+    """'split' / 0: two-part split-bf16 MFMA (~2^-17);  'bf16' / 1: single bf16 pass;
+    'split3' / 'fp32' / 2: three-part split, numerically an fp32 GEMM (~2^-25)."""
     global _precision
-    _precision = {"split": 0, "fp32": 0, 0: 0, "bf16": 1, 1: 1}[p]
+    _precision = {"split": 0, 0: 0, "bf16": 1, 1: 1, "split3": 2, "fp32": 2, 2: 2}[p]
 
 
 def get_precision():
