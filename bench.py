@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric: clips/sec (fwd+bwd) of the MQ video-text transformer at
+T=2304, C=2304 (config "P" of SURVEY.md section 8: D=1024, H=16, arch (2,2,5), XLNet layer on, text
+L=77 x 768, 22 classes, B=2 clips per GPU), synthetic inputs resident in HBM, random-init weights.
+
+  python bench.py --gpus 1 --steps K --warmup W            (single process)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU,
+      data parallel over clips, gradient all-reduce over RCCL inside the timed step)
+
+A "step" = forward + backward of one batch through vilco_amd (HIP kernels via libvilco_hip.so);
+for N > 1 it includes the bucketed gradient all-reduce.  Rank 0 prints ONE JSON line.  Extra objects:
+"roofline" for the dominant kernel (the MFMA GEMM), "cpu_baseline" = the oracle (CPU restatement of
+the reference, kind "port") timed on the host cores on a bounded sample, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+GFLOP_PER_CLIP_FWD_BWD = 1917.0      # BASELINE.md section 2, config P (measured with FlopCounterMode)
+PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+P_XLNET = dict(d_model=1024, n_head=16, d_head=64, d_inner=2048, n_layer=1, dropout=0.0,
+               layer_norm_eps=1e-12, vocab_size=32000, initializer_range=0.02, attn_type="bi",
+               bi_data=False, clamp_len=-1, ff_activation="gelu")
+
+
+def p_config():
+    from vilco_amd.core.config import make_config
+    over = dict(dataset=dict(input_dim=2304, num_classes=22, max_seq_len=2304),
+                model=dict(embd_dim=1024, fpn_dim=1024, head_dim=1024, n_head=16, backbone_arch=(2, 2, 5),
+                           use_abs_pe=True, use_cross_modal=True, n_txt_in=768, max_buffer_len_factor=1.0,
+                           use_xl=True),
+                train_cfg=dict(init_loss_norm=100, dropout=0.0, droppath=0.0))
+    return make_config(**over)['model']
+
+
+def synth_batch(B, device, seed=0, T=2304, Cin=2304, L=77):
+    """SURVEY.md 8d synthetic clips: feats ~ N(0,1) [Cin, t_b], t_0 = T, t_b = T-17; text [768, 77]."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for b in range(B):
+        t = T if b % 2 == 0 else T - 17
+        out.append({'video_id': 'v%d' % b, 'feats': torch.randn(Cin, t, generator=g).to(device),
+                    'segments': torch.tensor([[10.0, 40.0], [60.5, 130.25]]), 'labels': torch.tensor([1, 5]),
+                    'fps': 30.0, 'duration': 100.0, 'feat_stride': 16, 'feat_num_frames': 16,
+                    'segmentation_labels': torch.zeros(t, 22),
+                    'prompt_feature': torch.randn(768, L, generator=g).to(device)})
+    return out
+
+
+def cpu_baseline(cfg, state_dict):
+    """oracle fwd+bwd on the host cores, bounded sample: ONE step on ONE clip (about 10-30 s)."""
+    from oracle import mq_oracle
+    n = os.cpu_count() or 1
+    torch.set_num_threads(n)
+    p = {k: (v.detach().cpu().clone().requires_grad_(True) if v.is_floating_point() else v.cpu())
+         for k, v in state_dict.items()}
+    vl = synth_batch(1, "cpu")
+    t0 = time.time()
+    losses, _ = mq_oracle.forward_losses(p, cfg, vl)
+    losses['final_loss'].backward()
+    dt = time.time() - t0
+    model_name = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model_name = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": 1.0 / dt, "unit": "clips/s", "cores": n, "kind": "port",
+            "sample": "1 fwd+bwd step of 1 clip (T=2304, C=2304, config P), fp32, oracle/mq_oracle.py, "
+                      "%.1f s on %s" % (dt, model_name)}
+
+
+def gemm_profile(step_fn, n=2):
+    """per-launch HIP-event timing of the GEMM kernel on the launch stream, over `n` extra steps.
+    Returns (avg launch us, algorithmic TFLOP/s, launches per step, gemm ms per step)."""
+    from vilco_amd import ops
+    recs = []
+    real = ops.gemm
+
+    def timed(A, B, Cc, M, N, K, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real(A, B, Cc, M, N, K, *a, **k)
+        e1.record()
+        batch = k.get("batch", (1, 1))
+        recs.append((e0, e1, 2.0 * M * N * K * batch[0] * batch[1]))
+    ops.gemm = timed
+    try:
+        for _ in range(n):
+            step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = real
+    t_us = sum(a.elapsed_time(b) for a, b, _ in recs) * 1e3
+    flops = sum(f for _, _, f in recs)
+    return t_us / len(recs), flops / (t_us * 1e-6) / 1e12, len(recs) // n, t_us / n / 1e3, flops / n / len(recs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=2, help="clips per GPU (mq_vilco.yaml: 2)")
+    ap.add_argument("--precision", default="split3", choices=["split3", "split", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")            # "nccl" IS RCCL on ROCm
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+
+    import vilco_amd
+    import vilco_amd.modeling as vm
+    from vilco_amd import ops
+    vilco_amd._lib.load()                                  # no fallback: fail here if the .so is missing
+    ops.set_precision(args.precision)
+
+    cfg = p_config()
+    torch.manual_seed(0)
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=P_XLNET))
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1) else None
+    model = model.to(dev).train()
+    batch = synth_batch(args.batch, dev, seed=rank)
+
+    reducer = None
+    if distributed:
+        from vilco_amd.dist import GradReducer
+        reducer = GradReducer(model)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        if reducer is not None:
+            reducer.begin()
+        losses = model(batch, is_training=True)
+        losses['final_loss'].backward()
+        if reducer is not None:
+            reducer.finish()
+        return losses
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms = dt / args.steps * 1e3
+    clips_per_s = world * args.batch * args.steps / dt
+
+    if rank == 0:
+        out = {"metric": "clips/sec (fwd+bwd) MQ transformer T=2304 C=2304", "value": clips_per_s,
+               "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": {"split3": "bf16 MFMA x3-part split, fp32 accumulate (fp32-equivalent)",
+                         "split": "bf16 MFMA x2-part split, fp32 accumulate", "bf16": "bf16"}[args.precision],
+               "data": "synthetic",
+               "config": {"workload": "MQ ViLCo backbone config P: T=2304 Cin=2304 D=1024 H=16 arch(2,2,5) XLNet layer "
+                                      "(dropout 0) text L=77x768 22 classes, train mode dropout/droppath 0",
+                          "clips_per_gpu": args.batch, "global_batch": world * args.batch,
+                          "parallelism": "dp%d" % world},
+               "clips_per_s_per_gpu": clips_per_s / world,
+               "model_mfma_frac": clips_per_s / world * GFLOP_PER_CLIP_FWD_BWD / 1e3 / PEAK_BF16_TFLOPS}
+        avg_us, tflops, n_launch, gemm_ms, flop_per_launch = gemm_profile(step)
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (all instantiations)", "achieved": tflops,
+                           "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_BF16_TFLOPS,
+                           "traffic": None, "avg_launch_us": avg_us, "launches_per_step": n_launch,
+                           "gemm_ms_per_step": gemm_ms, "algorithmic_gflop_per_launch": flop_per_launch / 1e9}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, cpu_state)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

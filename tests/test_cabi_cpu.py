@@ -1,0 +1,81 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vilco_hip.h declares; argument
+validation paths that need no GPU; the config surface equals the reference DEFAULTS."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vilco_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vilco_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from vilco_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 25
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "missing export " + n
+
+
+def test_status_strings_and_version():
+    from vilco_amd import _lib
+    lib = _lib.load()
+    assert b"gfx950" in lib.vilco_version()
+    assert lib.vilco_status_str(0) == b"ok"
+    for code in (-1, -2, -3, -4):
+        assert lib.vilco_status_str(code).startswith(b"vilco_hip")
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    from vilco_amd import _lib
+    lib = _lib.load()
+    d = _lib.GemmDesc()
+    assert lib.vilco_gemm(ctypes.byref(d), None) == -1              # null operands
+    assert lib.vilco_layernorm_fwd(None, None, None, None, None, None, 4, 64, 1e-5, 0, None) == -1
+    assert lib.vilco_nms_1d(None, None, None, -1, 0, 0.5, None, None, None, 0, None) == -1
+    with pytest.raises(RuntimeError, match="bad argument"):
+        _lib.check(-1)
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from vilco_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.zeros(4, 8), torch.zeros(3, 8))
+
+
+def test_config_defaults_match_reference():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import ref_import
+    from vilco_amd.core import config as c
+    cfg = c.make_config(dataset=dict(input_dim=96))
+    assert cfg["model"]["input_dim"] == 96 and cfg["model"]["train_cfg"] is cfg["train_cfg"]
+    if not ref_import.available():
+        pytest.skip("reference not present")
+    libs = ref_import.setup()
+    assert c.DEFAULTS == libs.core.config.DEFAULTS
+
+
+def test_state_dict_is_drop_in():
+    """same keys and shapes as the golden reference state_dict; loads strictly"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity_util import golden_cfg, load_golden, xlnet_json
+    import vilco_amd.modeling as vm
+    for name in ("xl", "prompt"):
+        gold = load_golden(name)
+        m = golden_cfg(gold)
+        kw = dict(m, xlnet_config=xlnet_json(m['embd_dim'], 4)) if m['use_xl'] else m
+        model = vm.make_meta_arch('LocPointTransformer', **kw)
+        assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == \
+               {k: tuple(v.shape) for k, v in gold['state_dict'].items()}
+        model.load_state_dict(gold['state_dict'], strict=True)
