@@ -42,6 +42,8 @@ const char* vilco_version(void);
 /* attention contractions.  C[m][n] = epilogue(alpha * sum_k A(m,k) B(k,n)).                    */
 /* Replaces aten::convolution / addmm / bmm / einsum under blocks.py:79,217-226,340-349,420-435, */
 /* 533-539, meta_archs.py:216-235,309-331, modeling_xlnet_x.py:284-325,437-443,474-489.         */
+/* Operands are first split into bf16 planes (pack kernels, transposing where needed), then one */
+/* NT MFMA kernel (256x128 / 128x128 tiles, optional split-K) runs on the planes.                */
 /* bf16 MFMA (v_mfma_f32_16x16x32_bf16) with fp32 accumulate; precision 0 = split-bf16 (hi+lo, */
 /* 3 MFMAs, ~2^-17 relative), 1 = single bf16 pass, 2 = three-part split (6 MFMAs, ~2^-25:    */
 /* numerically an fp32 GEMM).                                                                  */
@@ -75,8 +77,12 @@ typedef struct vilco_gemm_desc {
   const float* colscale;  /* [N]  (AffineDropPath.scale, blocks.py:663-670) */
   const float* residual;  /* same layout as C; added after scaling */
   int32_t res_masked;     /* 1: residual is also zeroed on masked rows */
+  /* device scratch for the bf16 operand planes and split-K partials; size from vilco_gemm_workspace() */
+  void* workspace;
+  size_t workspace_bytes;
 } vilco_gemm_desc;
 
+size_t vilco_gemm_workspace(const vilco_gemm_desc* d);
 int vilco_gemm(const vilco_gemm_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("bias", c_fp), ("preact", c_fp), ("act", i32),
         ("row_len", c_fp), ("rowT", i32),
         ("colscale", c_fp), ("residual", c_fp), ("res_masked", i32),
+        ("workspace", c_fp), ("workspace_bytes", sz),
     ]
 
 
@@ -39,6 +40,7 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     "vilco_status_str": (C.c_char_p, [C.c_int]),
     "vilco_version": (C.c_char_p, []),
+    "vilco_gemm_workspace": (sz, [C.POINTER(GemmDesc)]),
     "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "vilco_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp]),
     "vilco_layernorm_bwd_workspace": (sz, [i64, i32]),

@@ -1,20 +1,21 @@
-// MFMA GEMM for gfx950: fp32 operands in HBM, bf16 MFMA (16x16x32) with fp32 accumulate.
+// MFMA GEMM for gfx950 (v2):  C[m][n] = epilogue(alpha * sum_k A(m,k) * B(k,n)),  fp32 in / fp32 out.
 //
-//   C[m][n] = epilogue(alpha * sum_k A(m,k) * B(k,n))
+// Two stages per call, both on the caller's stream:
+//   1. pack: each fp32 operand is split ONCE into NP bf16 "planes" (x = p0 + p1 + p2, p0 = bf16(x),
+//      p1 = bf16(x - p0), ...) laid out [part][row][Kp], k contiguous, zero padded to Kp = 32*ceil(K/32).
+//      Operands whose contiguous dim is not k (activations in dW = dY^T X, weights in dX = dY W) are transposed
+//      here through an LDS tile, so the MFMA kernel only ever sees the "NT" form.  k=3 convs keep their
+//      overlapped-row trick: the plane gets one zero row before and after every sequence, and row (b,t) of the
+//      A operand is the contiguous span of rows t-1,t,t+1 (K = 3*Cin, row stride Cin): no im2col.
+//   2. gemm_planes_kernel<BM,NP>: tile BM x 128 x 32 (BM = 256 with 8 waves, or 128 with 4), each wave a 64x64
+//      sub-tile = 4x4 v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Planes stream global -> registers -> LDS
+//      (16-byte chunks, no conversion work in the loop), double buffered, one barrier per K-step.  LDS rows are
+//      64 B with a chunk XOR swizzle that makes every ds_read_b128 fragment read conflict free (swz()).
+//      NP=1: 1, NP=2: 3, NP=3: 6 MFMAs per fragment pair (dropped cross terms <= 2^-9, 2^-17, 2^-26).
+//      Optional split-K (grid.y) writes fp32 partials that a reduce kernel sums and finishes (used when the
+//      tile count cannot fill 256 CUs: dW problems, pyramid levels with <= 288 tokens, the 77-token text side).
 //
-// Tile 128x128x32, 256 threads = 4 waves (2x2), each wave owns a 64x64 sub-tile = 4x4 MFMA tiles.
-// Operands are staged global -> registers -> (fp32 -> bf16 hi[/lo]) -> LDS, double buffered, one
-// barrier per K-step: the global loads of step k+1 are in flight while step k's MFMAs run.
-// LDS tiles are always [128 rows][32 k] bf16 with a 16-byte-chunk XOR swizzle that makes the
-// ds_read_b128 fragment reads bank-conflict free (see swz()).  Operands whose contiguous dim is
-// NOT k ("transposed" operands: activations in dW = dY^T X, weights in dX = dY W) are transposed
-// inside the register stage (8(k) x 2(row) patches -> one 16-byte LDS store per row).
-//
-// precision 0 ("split"): x = hi + lo with hi = bf16(x), lo = bf16(x - hi); a*b ~= ah*bh + ah*bl +
-// al*bh (3 MFMAs), relative error ~2^-17.  precision 1: single bf16 pass (2^-9).  precision 2
-// ("split3"): three bf16 parts, 6 MFMAs, ~2^-25: numerically an fp32 GEMM at 1/6 of the bf16 MFMA
-// rate (still 2.6x the fp32-MFMA peak of gfx950).
-//
+// precision 0 = NP 2 ("split"), 1 = NP 1 (plain bf16), 2 = NP 3 ("split3": numerically an fp32 GEMM).
 // Reference arithmetic replaced: see include/vilco_hip.h (vilco_gemm).
 #include "common.h"
 
@@ -23,26 +24,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
-constexpr int TILE_ELEMS = 128 * 32;  // bf16 elements per operand tile
+constexpr int BN = 128, BK = 32;
 
-// Swizzle: rows are 64 B (4 chunks of 16 B); chunk' = chunk ^ f(row>>2).  With f = {0,3,2,1}
-// every ds_read_b128 lane group ({0-3,12-15,20-27}, ...) touches 16 distinct 16-B slots of the
-// 256-B bank row (derivation in DESIGN.md "GEMM LDS layout").
+// rows are 64 B (4 chunks of 16 B); chunk' = chunk ^ f(row>>2), f = {0,3,2,1}: every ds_read_b128 lane group
+// ({0-3,12-15,20-27}, ...) then touches 16 distinct 16-B slots of the 256-B bank row
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * 32 + ((chunk ^ swz(row)) << 3);
-}
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ swz(row)) << 3); }
 
-struct Operand {
-  const float* p;  // batch-offset base pointer
-  long ld;
-  int rows;  // extent of the non-k dim (M for A, N for B)
-  int tap;   // 1: tapped (overlapped-row conv) operand, tapC % 8 == 0;  2: tapped, any tapC (A only)
-};
-
-// x = p0 + p1 + p2 (+ ~2^-27 x): p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1); the
-// subtractions are exact in fp32.
 template <int NP>
 __device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3]) {
 #pragma unroll
@@ -50,7 +38,7 @@ __device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3]) {
     const __bf16 h = (__bf16)v[e];
     part[0][e] = h;
     if (NP >= 2) {
-      const float r1 = v[e] - (float)h;
+      const float r1 = v[e] - (float)h;      // exact in fp32
       const __bf16 m = (__bf16)r1;
       part[1][e] = m;
       if (NP >= 3) part[2][e] = (__bf16)(r1 - (float)m);
@@ -58,116 +46,131 @@ __device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3]) {
   }
 }
 
-// ---- operand whose contiguous dim is k: element (r,k) at p[r*ld + k] --------------------------
-template <bool VEC>
-__device__ __forceinline__ void gload_kc(float (&r)[16], const Operand& op, int row0, int k0, int K,
-                                         int tapC, int tapT, int tid) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int id = tid + h * NTHREADS;
-    const int row = id >> 2, c = id & 3;
-    const int grow = row0 + row, gk = k0 + c * 8;
-    bool ok = (grow < op.rows) && (gk < K);
-    long off = (long)grow * op.ld + gk;
-    if (op.tap == 1) {
-      // contiguous dim spans taps {t-1, t, t+1}; zero the taps that fall outside the sequence
-      const int tap = gk / tapC;
-      const int t = grow % tapT;
-      if ((tap == 0 && t == 0) || (tap == 2 && t == tapT - 1)) ok = false;
-      off -= tapC;
-    } else if (op.tap == 2) {
-      off -= tapC;
+// ------------------------------------------------------------------------------------------ pack
+// "kc" source: element (r,k) at src[r*ld + k];  "tr" source: element (r,k) at src[k*ld + r].
+struct PackArgs {
+  const float* src;
+  __bf16* dst;         // part 0, batch 0
+  long ld;
+  int rows, K, Kp;
+  long plane_stride;   // elements between parts
+  long batch_stride;   // elements between batches inside one part
+  int nbi;             // packed inner batch count
+  long so, si;         // source batch strides
+  // tap modes (k=3 conv):  0 none
+  //  1 (kc, seqpad): rows = B*T source rows of width tapC; output has T+2 rows per sequence (first and last
+  //                  zero) plus zero slack rows; the GEMM reads 3*tapC-wide overlapped spans from it
+  //  2 (kc, expand): output row r = [x[t-1] | x[t] | x[t+1]] explicitly (K = 3*tapC), for tapC % 8 != 0
+  //  3 (tr, taps):   output row (j*tapC + c), column tok = x[tok + j - 1][c], zero across sequence ends
+  int tap, tapC, tapT;
+  int out_rows;        // rows written by the kc kernel
+  int vec;             // 16-byte aligned source rows
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
+  const int z = blockIdx.z, zo = z / a.nbi, zi = z % a.nbi;
+  const float* src = a.src + zo * a.so + zi * a.si;
+  __bf16* dst = a.dst + (long)z * a.batch_stride;
+  const int width = (a.tap == 1) ? a.tapC : a.Kp;       // elements per output row
+  const int kmax = (a.tap == 1) ? a.tapC : a.K;         // valid source columns
+  const int chunks = width >> 3;
+  const long total = (long)a.out_rows * chunks;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % chunks);
+    const long orow = i / chunks;
+    const int k0 = c * 8;
+    float v[8];
+    long srow = orow;
+    bool row_ok = orow < a.rows;
+    if (a.tap == 1) {
+      const long seq = orow / (a.tapT + 2);
+      const int tt = (int)(orow % (a.tapT + 2)) - 1;
+      srow = seq * a.tapT + tt;
+      row_ok = tt >= 0 && tt < a.tapT && srow < a.rows;
     }
-    float* d = &r[h * 8];
-    if (op.tap == 2) {
-      // fine-grained taps (tapC not a multiple of 8, e.g. the 2- and 22-channel head outputs in
-      // their dX pass): the 8-wide chunk can straddle taps, so test every element
-      const int t = grow % tapT;
+    if (a.tap == 2) {
+      const int t = (int)(orow % a.tapT);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int k = gk + e;
-        const int tap = k / tapC;
-        const bool oke = (grow < op.rows) && (k < K) && !((tap == 0 && t == 0) || (tap == 2 && t == tapT - 1));
-        d[e] = oke ? op.p[off + e] : 0.f;
+        const int k = k0 + e;
+        const int j = k / a.tapC, cc = k % a.tapC;
+        const bool ok = row_ok && k < a.K && !((j == 0 && t == 0) || (j == 2 && t == a.tapT - 1));
+        v[e] = ok ? src[(orow + j - 1) * a.ld + cc] : 0.f;
       }
-    } else if (ok && VEC && gk + 8 <= K) {
-      const float4 v0 = *reinterpret_cast<const float4*>(op.p + off);
-      const float4 v1 = *reinterpret_cast<const float4*>(op.p + off + 4);
-      d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w;
-      d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+    } else if (row_ok && a.vec && k0 + 8 <= kmax) {
+      const float4 v0 = *reinterpret_cast<const float4*>(src + srow * a.ld + k0);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + srow * a.ld + k0 + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d[e] = (ok && gk + e < K) ? op.p[off + e] : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = (row_ok && k0 + e < kmax) ? src[srow * a.ld + k0 + e] : 0.f;
     }
-  }
-}
-
-template <int NP>
-__device__ __forceinline__ void lstore_kc(const float (&r)[16], __bf16* tile, int tid) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int id = tid + h * NTHREADS;
-    const int row = id >> 2, c = id & 3;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = r[h * 8 + e];
     bf16x8 part[3];
     splitN<NP>(v, part);
-    const int o = lds_off(row, c);
+    const long o = orow * (long)width + k0;
 #pragma unroll
-    for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(tile + q * TILE_ELEMS + o) = part[q];
+    for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(dst + q * a.plane_stride + o) = part[q];
   }
 }
 
-// ---- operand whose contiguous dim is its row index: element (r,k) at p[k*ld + r] --------------
-// thread -> patch of 8 k x 2 rows: kg = tid>>6 (k chunk), rg = tid&63 (row pair)
-template <bool VEC>
-__device__ __forceinline__ void gload_tr(float (&r)[16], const Operand& op, int row0, int k0, int K,
-                                         int tapC, int tapT, int tid) {
-  const int kg = tid >> 6, rg = tid & 63;
-  const int gr = row0 + rg * 2;
-  int tap = 0;
-  long coff = gr;
-  if (op.tap) {
-    tap = gr / tapC;  // both rows of the pair are in one tap (tapC even)
-    coff -= tapC;
-  }
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const int gk = k0 + kg * 8 + kk;
-    bool ok = gk < K;
-    if (op.tap) {
-      const int t = gk % tapT;
-      if ((tap == 0 && t == 0) || (tap == 2 && t == tapT - 1)) ok = false;
-    }
-    const long off = (long)gk * op.ld + coff;
-    if (ok && VEC && gr + 2 <= op.rows) {
-      const float2 v = *reinterpret_cast<const float2*>(op.p + off);
-      r[kk * 2] = v.x;
-      r[kk * 2 + 1] = v.y;
-    } else {
-      r[kk * 2] = (ok && gr < op.rows) ? op.p[off] : 0.f;
-      r[kk * 2 + 1] = (ok && gr + 1 < op.rows) ? op.p[off + 1] : 0.f;
-    }
-  }
-}
-
+// transposing pack: 64(r) x 64(k) tile through LDS.  grid = (ceil(nrows/64), ceil(Kp/64), batch * ntap)
 template <int NP>
-__device__ __forceinline__ void lstore_tr(const float (&r)[16], __bf16* tile, int tid) {
-  const int kg = tid >> 6, rg = tid & 63;
+__global__ __launch_bounds__(256) void pack_tr_kernel(PackArgs a) {
+  __shared__ float tile[64][65];
+  const int ntap = (a.tap == 3) ? 3 : 1;
+  const int nrows = (a.tap == 3) ? a.tapC : a.rows;
+  const int z = blockIdx.z / ntap, j = blockIdx.z % ntap;
+  const int zo = z / a.nbi, zi = z % a.nbi;
+  const float* src = a.src + zo * a.so + zi * a.si;
+  __bf16* dst = a.dst + (long)z * a.batch_stride;
+  const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
 #pragma unroll
-  for (int nn = 0; nn < 2; ++nn) {
-    float v[8];
+  for (int it = 0; it < 4; ++it) {        // load 64 k-rows x 64 r, float4 along r
+    const int id = tid + it * 256;
+    const int kk = id >> 4, r4 = (id & 15) * 4;
+    const int k = k0 + kk, r = r0 + r4;
+    bool ok = k < a.K;
+    long ksrc = k;
+    if (a.tap == 3) {
+      const int t = k % a.tapT;
+      if ((j == 0 && t == 0) || (j == 2 && t == a.tapT - 1)) ok = false;
+      ksrc = (long)k + j - 1;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && r < nrows) {
+      const float* p = src + ksrc * a.ld + r;
+      if (a.vec && r + 4 <= nrows) v = *reinterpret_cast<const float4*>(p);
+      else {
+        v.x = p[0];
+        if (r + 1 < nrows) v.y = p[1];
+        if (r + 2 < nrows) v.z = p[2];
+        if (r + 3 < nrows) v.w = p[3];
+      }
+    }
+    tile[kk][r4] = v.x; tile[kk][r4 + 1] = v.y; tile[kk][r4 + 2] = v.z; tile[kk][r4 + 3] = v.w;
+  }
+  __syncthreads();
+  const int r = tid & 63;                 // store: thread -> (row r, two 8-k chunks)
+  if (r0 + r < nrows) {
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) v[kk] = r[kk * 2 + nn];
-    bf16x8 part[3];
-    splitN<NP>(v, part);
-    const int o = lds_off(rg * 2 + nn, kg);
+    for (int h = 0; h < 2; ++h) {
+      const int kc = (tid >> 6) + h * 4;
+      if (k0 + kc * 8 >= a.Kp) continue;
+      float v[8];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(tile + q * TILE_ELEMS + o) = part[q];
+      for (int e = 0; e < 8; ++e) v[e] = tile[kc * 8 + e][r];
+      bf16x8 part[3];
+      splitN<NP>(v, part);
+      const long o = ((long)j * a.tapC * (a.tap == 3) + r0 + r) * a.Kp + k0 + kc * 8;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(dst + q * a.plane_stride + o) = part[q];
+    }
   }
 }
 
+// ------------------------------------------------------------------------------------------ GEMM on planes
 struct Epi {
   float alpha, beta;
   const float* bias;
@@ -180,46 +183,91 @@ struct Epi {
   int res_masked;
 };
 
-struct Args {
-  Operand a, b;
-  float* c;
+struct PlaneOp {
+  const __bf16* p;      // part 0, batch 0
+  long plane_stride;    // between parts
+  long batch_stride;    // between packed batches
+  int nbi;              // packed inner batch count
+  int has_o, has_i;     // whether the planes vary with the outer / inner batch index
+  int rows;             // valid rows (M or N); tile rows beyond are clamped (their outputs are never stored)
+  int seqT;             // rows per sequence for the overlapped-row layout (INT_MAX otherwise)
+  long seq_stride;      // elements between sequences
+  long row_stride;      // elements between rows
+};
+
+struct GArgs {
+  PlaneOp a, b;
+  float* c;             // output, or the split-K partial slabs
+  float* cfinal;        // the real output (beta / reduce)
   long ldc;
-  int M, N, K;
+  int M, N, Kp;
   int batch_inner;
-  long sAo, sAi, sBo, sBi, sCo, sCi;
-  int tapC, tapT;
+  long sCo, sCi;
   int tiles_n, ntiles;
+  int ksplit, kchunk;   // kchunk = K-steps per split
+  long split_stride;    // elements between split slabs
   Epi e;
 };
 
-template <bool A_KC, bool B_KC, int NP, bool VEC>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(Args g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);
-  // layout: [stage 2][operand 2][part NP][TILE_ELEMS]
-  auto tile_ptr = [&](int stage, int opnd, int part) {
-    return smem + ((stage * 2 + opnd) * NP + part) * TILE_ELEMS;
-  };
+__device__ __forceinline__ long row_off(const PlaneOp& o, int r) {
+  if (r >= o.rows) r = o.rows - 1;
+  return (long)(r / o.seqT) * o.seq_stride + (long)(r % o.seqT) * o.row_stride;
+}
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void store_out(const GArgs& g, long idx, int n, float acc, bool valid) {
+  const Epi& e = g.e;
+  float v = e.alpha * acc;
+  if (e.bias) v += e.bias[n];
+  if (e.preact) e.preact[idx] = v;
+  if (e.act == VILCO_ACT_RELU) v = fmaxf(v, 0.f);
+  else if (e.act == VILCO_ACT_GELU) v = gelu_f(v);
+  if (!valid) v = 0.f;
+  if (e.colscale) v *= e.colscale[n];
+  if (e.residual && (valid || !e.res_masked)) v += e.residual[idx];
+  if (e.beta != 0.f) v += e.beta * g.cfinal[idx];
+  g.cfinal[idx] = v;
+}
+
+template <int BM, int NP>
+__global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
+  constexpr int NT = BM * 2;                     // threads
+  constexpr int ROWS = BM + BN;                  // staged rows per part (A rows then B rows)
+  constexpr int TILE = ROWS * 32;                // bf16 elements per part per stage
+  constexpr int CH = ROWS * 4 * NP / NT;         // 16-byte chunks per thread per stage
+  static_assert((ROWS * 4 * NP) % NT == 0, "chunk split");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);   // [stage 2][part NP][ROWS][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
-  // contiguous run of tiles (neighbours share the A row panel in its L2).  Bijective for any count.
   int bid = blockIdx.x;
-  {
+  {  // XCD-aware tile order (bijective): blocks b, b+8 share an XCD -> give each XCD a contiguous tile run
     const int nwg = g.ntiles, q = nwg >> 3, r = nwg & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
   const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-
   const int z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
-  Operand oa = g.a, ob = g.b;
-  oa.p += zo * g.sAo + zi * g.sAi;
-  ob.p += zo * g.sBo + zi * g.sBi;
-  const long coff = zo * g.sCo + zi * g.sCi;
+  const int ks = blockIdx.y;
+
+  const __bf16* pa = g.a.p + ((long)(g.a.has_o ? zo : 0) * g.a.nbi + (g.a.has_i ? zi : 0)) * g.a.batch_stride;
+  const __bf16* pb = g.b.p + ((long)(g.b.has_o ? zo : 0) * g.b.nbi + (g.b.has_i ? zi : 0)) * g.b.batch_stride;
+
+  const __bf16* gsrc[CH];   // per-thread chunk sources / LDS destinations, fixed over the K loop
+  int ldst[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int id = tid + i * NT;
+    const int part = id / (ROWS * 4);
+    const int rem = id % (ROWS * 4);
+    const int row = rem >> 2, c = rem & 3;
+    const __bf16* base;
+    if (row < BM) base = pa + part * g.a.plane_stride + row_off(g.a, m0 + row);
+    else          base = pb + part * g.b.plane_stride + row_off(g.b, n0 + row - BM);
+    gsrc[i] = base + c * 8;
+    ldst[i] = part * TILE + lds_off(row, c);
+  }
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -227,49 +275,47 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(Args g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float ra[16], rb[16];
-  const int nk = (g.K + BK - 1) / BK;
+  const int kt0 = ks * g.kchunk;
+  int kt1 = kt0 + g.kchunk;
+  const int nk_all = g.Kp / BK;
+  if (kt1 > nk_all) kt1 = nk_all;
 
+  bf16x8 stage[CH];
   auto gload = [&](int kt) {
-    if (A_KC) gload_kc<VEC>(ra, oa, m0, kt * BK, g.K, g.tapC, g.tapT, tid);
-    else      gload_tr<VEC>(ra, oa, m0, kt * BK, g.K, g.tapC, g.tapT, tid);
-    if (B_KC) gload_kc<VEC>(rb, ob, n0, kt * BK, g.K, g.tapC, g.tapT, tid);
-    else      gload_tr<VEC>(rb, ob, n0, kt * BK, g.K, g.tapC, g.tapT, tid);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) stage[i] = *reinterpret_cast<const bf16x8*>(gsrc[i] + (long)kt * BK);
   };
-  auto lstore = [&](int stage) {
-    if (A_KC) lstore_kc<NP>(ra, tile_ptr(stage, 0, 0), tid);
-    else      lstore_tr<NP>(ra, tile_ptr(stage, 0, 0), tid);
-    if (B_KC) lstore_kc<NP>(rb, tile_ptr(stage, 1, 0), tid);
-    else      lstore_tr<NP>(rb, tile_ptr(stage, 1, 0), tid);
+  auto lstore = [&](int st) {
+    __bf16* s = smem + st * NP * TILE;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) *reinterpret_cast<bf16x8*>(s + ldst[i]) = stage[i];
   };
 
-  gload(0);
-  lstore(0);
+  if (kt0 < kt1) {
+    gload(kt0);
+    lstore(0);
+  }
   __syncthreads();
 
   const int frow = lane & 15, fchunk = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int st = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-
-    // fragments of every part; products kept (smallest first): NP=2: lh hl hh; NP=3: + mm, hl/lh with
-    // the third part.  Dropped terms are <= 2^-17 (NP=2) / 2^-26 (NP=3) relative.
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int st = (kt - kt0) & 1;
+    if (kt + 1 < kt1) gload(kt + 1);
+    const __bf16* s = smem + st * NP * TILE;
     bf16x8 fa[NP][4], fb[NP][4];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const __bf16* at = tile_ptr(st, 0, q);
-      const __bf16* bt = tile_ptr(st, 1, q);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[q][i] = *reinterpret_cast<const bf16x8*>(at + lds_off(wm * 64 + i * 16 + frow, fchunk));
-        fb[q][i] = *reinterpret_cast<const bf16x8*>(bt + lds_off(wn * 64 + i * 16 + frow, fchunk));
+        fa[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + lds_off(wm * 64 + i * 16 + frow, fchunk));
+        fb[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + lds_off(BM + wn * 64 + i * 16 + frow, fchunk));
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        f32x4 c = acc[i][j];
+        f32x4 c = acc[i][j];     // smallest terms first
         if (NP == 3) {
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);
@@ -281,13 +327,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(Args g) {
         }
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);
       }
-
-    if (kt + 1 < nk) lstore(st ^ 1);
+    if (kt + 1 < kt1) lstore(st ^ 1);
     __syncthreads();
   }
 
-  // epilogue: C/D layout of mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg
-  const Epi& e = g.e;
+  // epilogue.  C/D layout of mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg
+  const long coff = zo * g.sCo + zi * g.sCi;
+  const bool partial = g.ksplit > 1;
+  float* cp = g.c + (partial ? (long)ks * g.split_stride : 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -295,54 +342,153 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(Args g) {
       const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
       if (m >= g.M) continue;
       bool valid = true;
-      if (e.row_len) valid = (m % e.rowT) < e.row_len[m / e.rowT];
+      if (!partial && g.e.row_len) valid = (m % g.e.rowT) < g.e.row_len[m / g.e.rowT];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + (lane & 15);
         if (n >= g.N) continue;
         const long idx = coff + (long)m * g.ldc + n;
-        float v = e.alpha * acc[i][j][rr];
-        if (e.bias) v += e.bias[n];
-        if (e.preact) e.preact[idx] = v;
-        if (e.act == VILCO_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (e.act == VILCO_ACT_GELU) v = gelu_f(v);
-        if (!valid) v = 0.f;
-        if (e.colscale) v *= e.colscale[n];
-        if (e.residual && (valid || !e.res_masked)) v += e.residual[idx];
-        if (e.beta != 0.f) v += e.beta * g.c[idx];
-        g.c[idx] = v;
+        if (partial) cp[idx] = acc[i][j][rr];
+        else store_out(g, idx, n, acc[i][j][rr], valid);
       }
     }
   }
 }
 
-template <bool A_KC, bool B_KC, int NP>
-int launch_np(const Args& a, bool vec, dim3 grid, hipStream_t s) {
-  const size_t lds = (size_t)2 * 2 * NP * TILE_ELEMS * sizeof(__bf16);   // 32 / 64 / 96 KiB
-  static const bool attr_once = [] {
-    const int cap = 2 * 2 * NP * TILE_ELEMS * (int)sizeof(__bf16);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<A_KC, B_KC, NP, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<A_KC, B_KC, NP, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+// out = epilogue(alpha * sum_s part[s])
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
+  const long per = (long)g.M * g.N;
+  const long total = per * nz;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int z = (int)(i / per);
+    const long mn = i % per;
+    const int m = (int)(mn / g.N), n = (int)(mn % g.N);
+    const int zo = z / g.batch_inner, zi = z % g.batch_inner;
+    const long idx = zo * g.sCo + zi * g.sCi + (long)m * g.ldc + n;
+    float s = 0.f;
+    for (int k = 0; k < g.ksplit; ++k) s += g.c[(long)k * g.split_stride + idx];
+    bool valid = true;
+    if (g.e.row_len) valid = (m % g.e.rowT) < g.e.row_len[m / g.e.rowT];
+    store_out(g, idx, n, s, valid);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+inline long align_up(long x, long a) { return (x + a - 1) / a * a; }
+
+struct Plan {
+  int NP, Kp, BM, ksplit, kchunk;
+  bool a_tr, b_tr;
+  int a_tap, b_tap;               // pack tap mode
+  int a_out_rows, b_out_rows;     // plane rows written by the kc pack
+  long a_plane, b_plane;          // elements per part (all batches)
+  long a_batch, b_batch;          // elements per batch inside a part
+  int a_nbo, a_nbi, b_nbo, b_nbi;
+  long a_bytes, b_bytes, part_bytes;
+  long split_stride;
+};
+
+void make_plan(const vilco_gemm_desc* d, Plan& p) {
+  p.NP = d->precision == 1 ? 1 : (d->precision == 0 ? 2 : 3);
+  p.Kp = (int)align_up(d->K > 0 ? d->K : 1, 32);
+  p.a_tr = !d->a_kcontig;
+  p.b_tr = !d->b_kcontig;
+  p.a_tap = p.b_tap = 0;
+  p.a_out_rows = d->M;
+  p.b_out_rows = d->N;
+  long a_batch = (long)d->M * p.Kp, b_batch = (long)d->N * p.Kp;
+  if (d->tap_operand == VILCO_TAP_A) {
+    if ((d->tapC % 8) == 0) {
+      p.a_tap = 1;
+      const long nseq = d->M / d->tapT;
+      const long slack = (p.Kp + d->tapC - 1) / d->tapC;       // zero rows covering the last spans' over-read
+      p.a_out_rows = (int)(nseq * (d->tapT + 2) + slack);
+      a_batch = (long)p.a_out_rows * d->tapC;
+    } else {
+      p.a_tap = 2;
+    }
+  } else if (d->tap_operand == VILCO_TAP_B) {
+    p.b_tap = 3;
+  }
+  p.a_nbo = (d->sAo && d->batch_outer > 1) ? d->batch_outer : 1;
+  p.a_nbi = (d->sAi && d->batch_inner > 1) ? d->batch_inner : 1;
+  p.b_nbo = (d->sBo && d->batch_outer > 1) ? d->batch_outer : 1;
+  p.b_nbi = (d->sBi && d->batch_inner > 1) ? d->batch_inner : 1;
+  p.a_batch = align_up(a_batch, 8);
+  p.b_batch = align_up(b_batch, 8);
+  p.a_plane = p.a_batch * p.a_nbo * p.a_nbi;
+  p.b_plane = p.b_batch * p.b_nbo * p.b_nbi;
+  p.a_bytes = align_up(p.a_plane * p.NP * 2, 256);
+  p.b_bytes = align_up(p.b_plane * p.NP * 2, 256);
+
+  const long nbatch = (long)d->batch_outer * d->batch_inner;
+  const long tn = (d->N + BN - 1) / BN;
+  const long tiles128 = ((d->M + 127) / 128) * tn * nbatch;
+  const long tiles256 = ((d->M + 255) / 256) * tn * nbatch;
+  p.BM = (d->M >= 512 && tiles256 >= 200) ? 256 : 128;
+  const long tiles = p.BM == 256 ? tiles256 : tiles128;
+  const int nk = p.Kp / BK;
+  int ks = 1;
+  if (tiles < 192 && nk >= 8) {
+    ks = (int)((384 + tiles - 1) / tiles);
+    if (ks > nk / 4) ks = nk / 4;        // at least 4 K-steps (128 k) per split
+    if (ks > 32) ks = 32;
+    if (ks < 1) ks = 1;
+  }
+  p.kchunk = (nk + ks - 1) / ks;
+  p.ksplit = (nk + p.kchunk - 1) / p.kchunk;
+  long out_span = 0;
+  if (p.ksplit > 1) {   // a split slab covers the whole (strided) output footprint
+    out_span = (long)(d->batch_outer - 1) * d->sCo + (long)(d->batch_inner - 1) * d->sCi + (long)(d->M - 1) * d->ldc + d->N;
+    out_span = align_up(out_span, 64);
+  }
+  p.split_stride = out_span;
+  p.part_bytes = p.ksplit > 1 ? align_up(out_span * p.ksplit * 4, 256) : 0;
+}
+
+template <int NP>
+void launch_pack(const PackArgs& a, bool tr, int nbatch, hipStream_t s) {
+  if (!tr) {
+    const int width = (a.tap == 1) ? a.tapC : a.Kp;
+    long blocks = ((long)a.out_rows * (width / 8) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((pack_kc_kernel<NP>), dim3((int)blocks, 1, nbatch), dim3(256), 0, s, a);
+  } else {
+    const int ntap = a.tap == 3 ? 3 : 1;
+    const int nrows = a.tap == 3 ? a.tapC : a.rows;
+    dim3 grid((nrows + 63) / 64, (a.Kp + 63) / 64, nbatch * ntap);
+    hipLaunchKernelGGL((pack_tr_kernel<NP>), grid, dim3(256), 0, s, a);
+  }
+}
+
+void dispatch_pack(int NP, const PackArgs& a, bool tr, int nbatch, hipStream_t s) {
+  if (NP == 1) launch_pack<1>(a, tr, nbatch, s);
+  else if (NP == 2) launch_pack<2>(a, tr, nbatch, s);
+  else launch_pack<3>(a, tr, nbatch, s);
+}
+
+template <int BM, int NP>
+void launch_gemm(const GArgs& g, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * NP * (BM + BN) * 32 * sizeof(__bf16);   // up to 144 KiB
+  static const bool once = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_kernel<BM, NP>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     return true;
   }();
-  (void)attr_once;
-  if (vec) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, NP, true>), grid, dim3(NTHREADS), lds, s, a);
-  else     hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, NP, false>), grid, dim3(NTHREADS), lds, s, a);
-  return vilco_launch_status();
-}
-
-template <bool A_KC, bool B_KC>
-int launch(const Args& a, int precision, bool vec, dim3 grid, hipStream_t s) {
-  // precision 0: split-bf16 (2 parts, 3 MFMAs); 1: plain bf16; 2: 3 parts, 6 MFMAs (fp32-equivalent)
-  if (precision == 0) return launch_np<A_KC, B_KC, 2>(a, vec, grid, s);
-  if (precision == 1) return launch_np<A_KC, B_KC, 1>(a, vec, grid, s);
-  return launch_np<A_KC, B_KC, 3>(a, vec, grid, s);
+  (void)once;
+  hipLaunchKernelGGL((gemm_planes_kernel<BM, NP>), grid, dim3(BM * 2), lds, s, g);
 }
 
 }  // namespace
+
+extern "C" size_t vilco_gemm_workspace(const vilco_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K < 0) return 512;
+  Plan p;
+  make_plan(d, p);
+  return (size_t)(p.a_bytes + p.b_bytes + p.part_bytes + 512);
+}
 
 extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return VILCO_ERR_BADARG;
@@ -354,41 +500,78 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (d->a_kcontig == 0 && d->b_kcontig == 1) return VILCO_ERR_UNSUPPORTED;  // "TT" is never needed
   if (d->tap_operand != VILCO_TAP_NONE) {
     if (d->tapC <= 0 || d->tapT <= 0) return VILCO_ERR_BADARG;
-    if (d->tap_operand == VILCO_TAP_B && (d->tapC % 8) != 0) return VILCO_ERR_UNSUPPORTED;
-    // tapped operand: its contiguous dim must be the 3*tapC tap span
-    if (d->tap_operand == VILCO_TAP_A && !(d->a_kcontig == 1 && d->K == 3 * d->tapC)) return VILCO_ERR_BADARG;
-    if (d->tap_operand == VILCO_TAP_B && !(d->b_kcontig == 0 && d->N == 3 * d->tapC)) return VILCO_ERR_BADARG;
-    if (d->tap_operand != VILCO_TAP_A && d->tap_operand != VILCO_TAP_B) return VILCO_ERR_BADARG;
+    if (d->batch_outer != 1 || d->batch_inner != 1) return VILCO_ERR_UNSUPPORTED;
+    if (d->tap_operand == VILCO_TAP_A) {
+      if (!(d->a_kcontig == 1 && d->K == 3 * d->tapC && d->lda == d->tapC && (d->M % d->tapT) == 0)) return VILCO_ERR_BADARG;
+    } else if (d->tap_operand == VILCO_TAP_B) {
+      if (!(d->b_kcontig == 0 && d->N == 3 * d->tapC && d->ldb == d->tapC && (d->K % d->tapT) == 0)) return VILCO_ERR_BADARG;
+    } else {
+      return VILCO_ERR_BADARG;
+    }
   }
-
-  Args a;
-  a.a = Operand{d->A, (long)d->lda, d->M, d->tap_operand == VILCO_TAP_A ? ((d->tapC % 8) == 0 ? 1 : 2) : 0};
-  a.b = Operand{d->B, (long)d->ldb, d->N, d->tap_operand == VILCO_TAP_B ? 1 : 0};
-  a.c = d->C;
-  a.ldc = d->ldc;
-  a.M = d->M; a.N = d->N; a.K = d->K;
-  a.batch_inner = d->batch_inner;
-  a.sAo = d->sAo; a.sAi = d->sAi; a.sBo = d->sBo; a.sBi = d->sBi; a.sCo = d->sCo; a.sCi = d->sCi;
-  a.tapC = d->tapC > 0 ? d->tapC : 1;
-  a.tapT = d->tapT > 0 ? d->tapT : 1;
-  a.tiles_n = (d->N + BN - 1) / BN;
-  a.ntiles = a.tiles_n * ((d->M + BM - 1) / BM);
-  a.e = Epi{d->alpha, d->beta, d->bias, d->preact, d->act, d->row_len, d->rowT, d->colscale,
-            d->residual, d->res_masked};
-
-  // vector path: k-contiguous operands need 16-B aligned rows, transposed ones 8-B aligned pairs
-  auto vec_ok = [&](const float* p, long ld, bool kc, long so, long si) {
-    const long q = kc ? 4 : 2;
-    return vilco_aligned(p, kc ? 16 : 8) && (ld % q == 0) && (so % q == 0) && (si % q == 0);
-  };
-  bool vec = vec_ok(d->A, d->lda, d->a_kcontig, d->sAo, d->sAi) &&
-             vec_ok(d->B, d->ldb, d->b_kcontig, d->sBo, d->sBi);
-  if (d->a_kcontig && (d->K % 4) != 0) vec = false;   // row tails are handled scalar, starts must align
-  if (d->tap_operand != VILCO_TAP_NONE && (d->tapC % 4) != 0) vec = false;
-
-  dim3 grid(a.ntiles, 1, d->batch_outer * d->batch_inner);
+  Plan p;
+  make_plan(d, p);
+  const size_t need = (size_t)(p.a_bytes + p.b_bytes + p.part_bytes + 512);
+  if (!d->workspace || d->workspace_bytes < need) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d->a_kcontig && d->b_kcontig) return launch<true, true>(a, d->precision, vec, grid, s);
-  if (d->a_kcontig && !d->b_kcontig) return launch<true, false>(a, d->precision, vec, grid, s);
-  return launch<false, false>(a, d->precision, vec, grid, s);
+
+  unsigned char* ws = reinterpret_cast<unsigned char*>(align_up((long)reinterpret_cast<uintptr_t>(d->workspace), 256));
+  __bf16* planesA = reinterpret_cast<__bf16*>(ws);
+  __bf16* planesB = reinterpret_cast<__bf16*>(ws + p.a_bytes);
+  float* parts = reinterpret_cast<float*>(ws + p.a_bytes + p.b_bytes);
+
+  // ---- pack A and B into bf16 planes
+  PackArgs pa;
+  pa.src = d->A; pa.dst = planesA; pa.ld = d->lda; pa.rows = d->M; pa.K = d->K; pa.Kp = p.Kp;
+  pa.plane_stride = p.a_plane; pa.batch_stride = p.a_batch; pa.nbi = p.a_nbi;
+  pa.so = p.a_nbo > 1 ? d->sAo : 0; pa.si = p.a_nbi > 1 ? d->sAi : 0;
+  pa.tap = p.a_tap; pa.tapC = d->tapC > 0 ? d->tapC : 1; pa.tapT = d->tapT > 0 ? d->tapT : 1;
+  pa.out_rows = p.a_out_rows;
+  pa.vec = vilco_aligned(d->A, 16) && (d->lda % 4) == 0 && (d->sAo % 4) == 0 && (d->sAi % 4) == 0;
+  dispatch_pack(p.NP, pa, p.a_tr, p.a_nbo * p.a_nbi, s);
+
+  PackArgs pb;
+  pb.src = d->B; pb.dst = planesB; pb.ld = d->ldb; pb.rows = d->N; pb.K = d->K; pb.Kp = p.Kp;
+  pb.plane_stride = p.b_plane; pb.batch_stride = p.b_batch; pb.nbi = p.b_nbi;
+  pb.so = p.b_nbo > 1 ? d->sBo : 0; pb.si = p.b_nbi > 1 ? d->sBi : 0;
+  pb.tap = p.b_tap; pb.tapC = d->tapC > 0 ? d->tapC : 1; pb.tapT = d->tapT > 0 ? d->tapT : 1;
+  pb.out_rows = p.b_out_rows;
+  pb.vec = vilco_aligned(d->B, 16) && (d->ldb % 4) == 0 && (d->sBo % 4) == 0 && (d->sBi % 4) == 0;
+  dispatch_pack(p.NP, pb, p.b_tr, p.b_nbo * p.b_nbi, s);
+
+  // ---- MFMA kernel
+  GArgs g;
+  g.a.p = planesA; g.a.plane_stride = p.a_plane; g.a.batch_stride = p.a_batch; g.a.nbi = p.a_nbi;
+  g.a.has_o = p.a_nbo > 1; g.a.has_i = p.a_nbi > 1; g.a.rows = d->M;
+  if (p.a_tap == 1) { g.a.seqT = d->tapT; g.a.seq_stride = (long)(d->tapT + 2) * d->tapC; g.a.row_stride = d->tapC; }
+  else { g.a.seqT = 0x7fffffff; g.a.seq_stride = 0; g.a.row_stride = p.Kp; }
+  g.b.p = planesB; g.b.plane_stride = p.b_plane; g.b.batch_stride = p.b_batch; g.b.nbi = p.b_nbi;
+  g.b.has_o = p.b_nbo > 1; g.b.has_i = p.b_nbi > 1; g.b.rows = d->N;
+  g.b.seqT = 0x7fffffff; g.b.seq_stride = 0; g.b.row_stride = p.Kp;
+  g.ldc = d->ldc; g.M = d->M; g.N = d->N; g.Kp = p.Kp;
+  g.batch_inner = d->batch_inner; g.sCo = d->sCo; g.sCi = d->sCi;
+  g.tiles_n = (d->N + BN - 1) / BN;
+  g.ntiles = g.tiles_n * ((d->M + p.BM - 1) / p.BM);
+  g.ksplit = p.ksplit; g.kchunk = p.kchunk; g.split_stride = p.split_stride;
+  g.c = p.ksplit > 1 ? parts : d->C;
+  g.cfinal = d->C;
+  g.e = Epi{d->alpha, d->beta, d->bias, d->preact, d->act, d->row_len, d->rowT, d->colscale, d->residual,
+            d->res_masked};
+  const int nz = d->batch_outer * d->batch_inner;
+  dim3 grid(g.ntiles, p.ksplit, nz);
+  if (p.BM == 256) {
+    if (p.NP == 1) launch_gemm<256, 1>(g, grid, s);
+    else if (p.NP == 2) launch_gemm<256, 2>(g, grid, s);
+    else launch_gemm<256, 3>(g, grid, s);
+  } else {
+    if (p.NP == 1) launch_gemm<128, 1>(g, grid, s);
+    else if (p.NP == 2) launch_gemm<128, 2>(g, grid, s);
+    else launch_gemm<128, 3>(g, grid, s);
+  }
+  if (p.ksplit > 1) {
+    long blocks = ((long)d->M * d->N * nz + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, g, nz);
+  }
+  return vilco_launch_status();
 }

@@ -83,6 +83,9 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     d.colscale = _p(colscale)
     d.residual = None if residual is None else residual.data_ptr() + 4 * offC
     d.res_masked = int(res_masked)
+    nbytes = lib.vilco_gemm_workspace(C.byref(d))      # bf16 operand planes + split-K partials
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=Cc.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     _lib.check(lib.vilco_gemm(C.byref(d), _stream()))
 
 
