@@ -185,23 +185,32 @@ def _attn_ref(q, k, v, lens, H, scale, xl=False):
     return (p @ vh).transpose(1, 2).reshape(B, Tq, C)
 
 
-@pytest.mark.parametrize("B,Tq,Tk,H,hd", [(2, 64, 64, 4, 16), (2, 40, 77, 4, 16), (1, 130, 130, 2, 64), (2, 32, 5, 4, 8)])
-def test_attention(dev, B, Tq, Tk, H, hd):
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("B,Tq,Tk,H,hd", [(2, 64, 64, 4, 16), (2, 40, 77, 4, 16), (1, 130, 130, 2, 64), (2, 32, 5, 4, 8),
+                                          (2, 200, 157, 3, 32), (1, 96, 300, 2, 64), (1, 64, 64, 2, 128)])
+def test_attention(dev, B, Tq, Tk, H, hd, flash):
     from vilco_amd import ops
+    ops.use_flash = flash
     torch.manual_seed(7)
     C = H * hd
     q, k, v = torch.randn(B, Tq, C), torch.randn(B, Tk, C), torch.randn(B, Tk, C)
     lens = torch.tensor([Tk, max(1, Tk - 9)][:B], dtype=torch.int32)
     scale = 1 / math.sqrt(hd)
-    run_pair(lambda q, k, v: ops.attention(q, k, v, lens.to(dev), H, scale),
-             lambda q, k, v: _attn_ref(q, k, v, lens, H, scale), dict(q=q, k=k, v=v), dev, TOL_GEMM)
+    try:
+        run_pair(lambda q, k, v: ops.attention(q, k, v, lens.to(dev), H, scale),
+                 lambda q, k, v: _attn_ref(q, k, v, lens, H, scale), dict(q=q, k=k, v=v), dev, TOL_GEMM)
+    finally:
+        ops.use_flash = True
 
 
-def test_rel_attention(dev):
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("T,hd", [(48, 16), (100, 64)])
+def test_rel_attention(dev, flash, T, hd):
     """XLNet core vs the published formula incl. rel_shift_bnij (modeling_xlnet_x.py:256-320)."""
     from vilco_amd import ops
+    ops.use_flash = flash
     torch.manual_seed(8)
-    B, T, H, hd = 2, 48, 4, 16
+    B, H = 2, 4
     C = H * hd
     qw, qr, k, v = [torch.randn(B, T, C) for _ in range(4)]
     kr = torch.randn(2 * T, C)
@@ -222,8 +231,11 @@ def test_rel_attention(dev):
         p = torch.softmax(score, dim=3)
         o = torch.einsum("bnij,jbnd->ibnd", p, f(v))
         return o.permute(1, 0, 2, 3).reshape(B, T, C)
-    run_pair(lambda qw, qr, k, v, kr: ops.rel_attention(qw, qr, k, v, kr, lens.to(dev), H, scale), ref,
-             dict(qw=qw, qr=qr, k=k, v=v, kr=kr), dev, TOL_GEMM)
+    try:
+        run_pair(lambda qw, qr, k, v, kr: ops.rel_attention(qw, qr, k, v, kr, lens.to(dev), H, scale), ref,
+                 dict(qw=qw, qr=qr, k=k, v=v, kr=kr), dev, TOL_GEMM)
+    finally:
+        ops.use_flash = True
 
 
 def test_channel_attention(dev):

@@ -122,7 +122,9 @@ __global__ __launch_bounds__(EW_THREADS) void scale_add_fwd_kernel(
   }
 }
 
-// da = dout*am ; db = dout*cs*rs ; partial dcolscale[c] = sum dout*bval*rs  -> ws[block][C]
+// da = dout*am ; db = dout*cs*rs ; partial dcolscale[c] = sum dout*bval*rs  -> ws[row chunk][C]
+// grid = (row chunks, column chunks of 256): every thread owns one column of one row chunk, so loads are
+// coalesced across the block and there are rows/32 * C/256 blocks to fill the chip.
 __global__ __launch_bounds__(EW_THREADS) void scale_add_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ bval, const float* __restrict__ colscale,
     const float* __restrict__ rowscale, const int* __restrict__ len, int mask_a, float* __restrict__ da,
@@ -131,20 +133,20 @@ __global__ __launch_bounds__(EW_THREADS) void scale_add_bwd_kernel(
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > R) r1 = R;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float cs = colscale ? colscale[c] : 1.f;
-    float acc = 0.f;
-    for (long r = r0; r < r1; ++r) {
-      const int t = (int)(r % T), b = (int)(r / T);
-      const float am = (mask_a && len && t >= len[b]) ? 0.f : 1.f;
-      const float rs = rowscale ? rowscale[b] : 1.f;
-      const float g = dout[r * C + c];
-      if (da) da[r * C + c] = g * am;
-      if (db) db[r * C + c] = g * cs * rs;
-      if (ws) acc += g * bval[r * C + c] * rs;
-    }
-    if (ws) ws[(long)blockIdx.x * C + c] = acc;
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float cs = colscale ? colscale[c] : 1.f;
+  float acc = 0.f;
+  for (long r = r0; r < r1; ++r) {
+    const int t = (int)(r % T), b = (int)(r / T);
+    const float am = (mask_a && len && t >= len[b]) ? 0.f : 1.f;
+    const float rs = rowscale ? rowscale[b] : 1.f;
+    const float g = dout[r * C + c];
+    if (da) da[r * C + c] = g * am;
+    if (db) db[r * C + c] = g * cs * rs;
+    if (ws) acc += g * bval[r * C + c] * rs;
   }
+  if (ws) ws[(long)blockIdx.x * C + c] = acc;
 }
 
 __global__ __launch_bounds__(EW_THREADS) void axpby_kernel(float* __restrict__ out,
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(EW_THREADS) void axpby_kernel(float* __restrict__ o
     out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
 
-// dz = dy * act'(aux) * rowmask ; partial dbias -> ws[block][C]
+// dz = dy * act'(aux) * rowmask ; partial dbias -> ws[row chunk][C]   (same 2-D decomposition)
 __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ dz,
     float* __restrict__ ws, int act, const int* __restrict__ len, int T, long rows, int C,
@@ -163,18 +165,18 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float acc = 0.f;
-    for (long r = r0; r < r1; ++r) {
-      float g = dy[r * C + c];
-      if (len && (int)(r % T) >= len[r / T]) g = 0.f;
-      if (act == VILCO_ACT_RELU) g = (aux[r * C + c] > 0.f) ? g : 0.f;
-      else if (act == VILCO_ACT_GELU) g *= gelu_grad_f(aux[r * C + c]);
-      dz[r * C + c] = g;
-      acc += g;
-    }
-    if (ws) ws[(long)blockIdx.x * C + c] = acc;
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (long r = r0; r < r1; ++r) {
+    float g = dy[r * C + c];
+    if (len && (int)(r % T) >= len[r / T]) g = 0.f;
+    if (act == VILCO_ACT_RELU) g = (aux[r * C + c] > 0.f) ? g : 0.f;
+    else if (act == VILCO_ACT_GELU) g *= gelu_grad_f(aux[r * C + c]);
+    dz[r * C + c] = g;
+    acc += g;
   }
+  if (ws) ws[(long)blockIdx.x * C + c] = acc;
 }
 
 __global__ __launch_bounds__(EW_THREADS) void colsum_partial_kernel(const float* __restrict__ x,
@@ -183,11 +185,11 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_partial_kernel(const float*
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float acc = 0.f;
-    for (long r = r0; r < r1; ++r) acc += x[r * C + c];
-    ws[(long)blockIdx.x * C + c] = acc;
-  }
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (long r = r0; r < r1; ++r) acc += x[r * C + c];
+  ws[(long)blockIdx.x * C + c] = acc;
 }
 
 __global__ __launch_bounds__(EW_THREADS) void mask_rows_kernel(float* __restrict__ x,
@@ -249,8 +251,8 @@ __global__ __launch_bounds__(EW_THREADS) void permute3_kernel(const float* __res
 }
 
 int col_blocks(long rows) {
-  long b = (rows + 31) / 32;
-  if (b > 256) b = 256;
+  long b = (rows + 15) / 16;
+  if (b > 128) b = 128;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -334,7 +336,7 @@ extern "C" int vilco_scale_add_bwd(const float* dout, const float* bval, const f
   const int nb = col_blocks(rows);
   const int rpb = (int)((rows + nb - 1) / nb);
   float* ws = dcolscale ? reinterpret_cast<float*>(workspace) : nullptr;
-  hipLaunchKernelGGL(scale_add_bwd_kernel, dim3(nb), dim3(EW_THREADS), 0, s, dout, bval, colscale, rowscale,
+  hipLaunchKernelGGL(scale_add_bwd_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dout, bval, colscale, rowscale,
                      len, mask_a, da, db, ws, B, T, C, rpb);
   if (dcolscale) vilco_reduce_rows(ws, dcolscale, nullptr, nb, C, C, s);
   return vilco_launch_status();
@@ -361,7 +363,7 @@ extern "C" int vilco_act_bwd(const float* dy, const float* aux, float* dz, float
   const int nb = col_blocks(rows);
   const int rpb = (int)((rows + nb - 1) / nb);
   float* ws = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(nb), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
                      (long)rows, C, rpb);
   if (dbias) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
   return vilco_launch_status();
@@ -375,7 +377,7 @@ extern "C" int vilco_colsum(const float* x, float* out, int64_t rows, int32_t C,
   const int nb = col_blocks(rows);
   const int rpb = (int)((rows + nb - 1) / nb);
   float* ws = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(EW_THREADS), 0, s, x, ws, (long)rows, C, rpb);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, x, ws, (long)rows, C, rpb);
   vilco_reduce_rows(ws, out, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }

@@ -485,6 +485,7 @@ def mask_rows_(x, lens):
 
 # ---------------------------------------------------------------------------------------- attention
 MASK_KEYS, MASK_XLNET, MASK_NONE = 0, 1, 2
+use_flash = True     # fused attention kernels when the head dim is supported; False = materialised scores
 
 
 def _softmax_(s, kv_len, B, H, Tq, Tk, mode):
@@ -540,10 +541,60 @@ class _Attention(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None
 
 
+def flash_supported(hd):
+    return bool(_lib.load().vilco_attn_supported(int(hd)))
+
+
+def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode):
+    lib = _lib.load()
+    B, Tq, Cn = q.shape
+    Tk = k.shape[1]
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
+    _lib.check(lib.vilco_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
+                                  lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, _precision, _stream()))
+    return o, lse
+
+
+def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias):
+    lib = _lib.load()
+    B, Tq, Cn = q.shape
+    Tk = k.shape[1]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dbias = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=q.device) if want_dbias else None
+    nws = lib.vilco_attn_bwd_workspace(B, H, Tq)
+    ws = _ws(nws, q.device)
+    _lib.check(lib.vilco_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
+                                  lse.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                  _p(dbias), B, H, Tq, Tk, Cn // H, scale, mode, _precision, ws.data_ptr(), nws,
+                                  _stream()))
+    return dq, dk, dv, dbias
+
+
+class _FlashAttention(torch.autograd.Function):
+    """fused attention (vilco_attn_fwd / vilco_attn_bwd): scores never reach HBM; backward recomputes P
+    from (q, k, lse)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, kv_len, H, scale, mode):
+        _chk(q, k, v)
+        o, lse = _flash_fwd(q, k, v, None, kv_len, H, scale, mode)
+        ctx.H, ctx.scale, ctx.mode = H, scale, mode
+        ctx.save_for_backward(q, k, v, kv_len, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, kv_len, o, lse = ctx.saved_tensors
+        dq, dk, dv, _ = _flash_bwd(q, k, v, None, kv_len, o, lse, do.contiguous(), ctx.H, ctx.scale, ctx.mode, False)
+        return dq, dk, dv, None, None, None, None
+
+
 def attention(q, k, v, kv_len, n_head, scale=None, mode=MASK_KEYS):
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1] // n_head)
-    return _Attention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode))
+    fn = _FlashAttention if (use_flash and flash_supported(q.shape[-1] // n_head)) else _Attention
+    return fn.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode))
 
 
 class _RelAttention(torch.autograd.Function):
@@ -606,8 +657,52 @@ class _RelAttention(torch.autograd.Function):
         return dqw, dqr, dk, dv, dkr, None, None, None
 
 
+class _FlashRelAttention(torch.autograd.Function):
+    """XLNet relative attention with the content term fused: the position term bd = qr kr^T is a batched
+    GEMM, shifted (rel_shift_bnij) into an additive bias that the flash kernel consumes; backward returns
+    dS as d(bias)."""
+
+    @staticmethod
+    def forward(ctx, qw, qr, k, v, kr, kv_len, H, scale):
+        _chk(qw, qr, k, v, kr)
+        lib = _lib.load()
+        B, T, Cn = qw.shape
+        hd = Cn // H
+        bd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
+        gemm(qr, kr, bd, T, 2 * T, hd, 1, 1, Cn, Cn, 2 * T, batch=(B, H), sA=(T * Cn, hd), sB=(0, hd),
+             sC=(H * T * 2 * T, T * 2 * T))
+        bias = torch.zeros(B, H, T, T, dtype=torch.float32, device=qw.device)
+        _lib.check(lib.vilco_relshift_add(bias.data_ptr(), bd.data_ptr(), scale, B, H, T, _stream()))
+        del bd
+        o, lse = _flash_fwd(qw, k, v, bias, kv_len, H, scale, MASK_XLNET)
+        ctx.H, ctx.scale = H, scale
+        ctx.save_for_backward(qw, qr, k, v, kr, kv_len, bias, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qw, qr, k, v, kr, kv_len, bias, o, lse = ctx.saved_tensors
+        lib = _lib.load()
+        H, scale = ctx.H, ctx.scale
+        B, T, Cn = qw.shape
+        hd = Cn // H
+        dqw, dk, dv, dS = _flash_bwd(qw, k, v, bias, kv_len, o, lse, do.contiguous(), H, scale, MASK_XLNET, True)
+        dbd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
+        _lib.check(lib.vilco_relshift_bwd(dS.data_ptr(), dbd.data_ptr(), scale, B, H, T, _stream()))
+        del dS
+        sX, sB2 = (T * Cn, hd), (H * T * 2 * T, T * 2 * T)
+        dqr = torch.empty_like(qr)
+        gemm(dbd, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=(0, hd), sC=sX)
+        dkr = torch.zeros_like(kr)
+        for b in range(B):
+            gemm(dbd, qr, dkr, 2 * T, hd, T, 0, 0, 2 * T, Cn, Cn, batch=(1, H), sA=(0, T * 2 * T),
+                 sB=(0, hd), sC=(0, hd), offA=b * H * T * 2 * T, offB=b * T * Cn, beta=1.0)
+        return dqw, dqr, dk, dv, dkr, None, None, None
+
+
 def rel_attention(qw, qr, k, v, kr, kv_len, n_head, scale):
-    return _RelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale))
+    fn = _FlashRelAttention if (use_flash and flash_supported(qw.shape[-1] // n_head)) else _RelAttention
+    return fn.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale))
 
 
 class _ChannelAttn(torch.autograd.Function):
