@@ -11,6 +11,45 @@ import numpy as np
 
 f32 = np.float32
 
+# std::exp(float) of the reference == glibc expf (2.35 in this image): the table-driven fp64 algorithm of the ARM
+# optimized routines (32-entry 2^(i/32) table, cubic polynomial, one rounding to float).  numpy's own SIMD exp
+# can differ from it by 1 ulp, which is enough to flip a soft-NMS pick among 30 000 candidates, so the algorithm
+# is restated here (test_expf_matches_libm pins it against libm itself).
+_N = 32
+_TAB = None
+
+
+def _tab():
+    global _TAB
+    if _TAB is None:
+        from decimal import Decimal, getcontext
+        import struct
+        getcontext().prec = 80
+        t = []
+        for i in range(_N):
+            v = float(Decimal(2) ** (Decimal(i) / Decimal(_N)))
+            t.append((struct.unpack('<Q', struct.pack('<d', v))[0] - (i << 47)) & 0xFFFFFFFFFFFFFFFF)
+        _TAB = np.array(t, dtype=np.uint64)
+    return _TAB
+
+
+def expf_libm(x):
+    """float32 -> float32, bit-identical to glibc expf for |x| < 80 (vectorised)."""
+    xd = np.asarray(x, dtype=np.float32).astype(np.float64)
+    z = (float.fromhex('0x1.71547652b82fep+0') * _N) * xd
+    shift = float.fromhex('0x1.8p+52')
+    kd = z + shift
+    ki = kd.view(np.uint64) if isinstance(kd, np.ndarray) else np.float64(kd).view(np.uint64)
+    kd = kd - shift
+    r = z - kd
+    t = _tab()[(ki % np.uint64(_N)).astype(np.int64)] + (ki << np.uint64(47))
+    s = t.view(np.float64) if isinstance(t, np.ndarray) else np.uint64(t).view(np.float64)
+    c0 = float.fromhex('0x1.c6af84b912394p-5') / _N / _N / _N
+    c1 = float.fromhex('0x1.ebfce50fac4f3p-3') / _N / _N
+    c2 = float.fromhex('0x1.62e42ff0c52d6p-1') / _N
+    y = (c0 * r + c1) * (r * r) + (c2 * r + 1.0)
+    return (y * s).astype(np.float32)
+
 
 def nms(segs, scores, iou_threshold):
     segs = np.asarray(segs, dtype=f32).reshape(-1, 2)
@@ -71,7 +110,7 @@ def softnms(segs, scores, iou_threshold, sigma, min_score, method, max_num=0):
                 if ovr >= thr:
                     w = f32(1) - ovr
             elif method == 2:
-                w = f32(np.exp(f32(-(ovr * ovr) / sigma)))
+                w = f32(expf_libm(np.array([f32(-(ovr * ovr) / sigma)], dtype=f32))[0])
             sc[pos] = f32(sc[pos] * w)
             if sc[pos] < min_score:
                 last = nsegs - 1

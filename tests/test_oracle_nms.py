@@ -62,3 +62,14 @@ def test_against_goldens():
             assert np.array_equal(c, z["out_cls"]), f
             np.testing.assert_allclose(s, z["out_segs"], rtol=1e-6)
             np.testing.assert_allclose(sc, z["out_scores"], rtol=1e-5, atol=1e-8)
+
+
+def test_expf_matches_libm():
+    """the restated glibc expf (oracle + HIP kernel use the same algorithm) is bit-identical to libm"""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.expf.restype, libm.expf.argtypes = ctypes.c_float, [ctypes.c_float]
+    rng = np.random.RandomState(0)
+    xs = np.concatenate([-rng.uniform(0, 2.5, 40000), -rng.uniform(0, 1e-3, 5000), -rng.uniform(0, 70, 5000)]).astype(np.float32)
+    want = np.array([libm.expf(float(x)) for x in xs], dtype=np.float32)
+    assert np.array_equal(nms_oracle.expf_libm(xs), want)

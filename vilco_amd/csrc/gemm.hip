@@ -17,6 +17,7 @@
 //
 // precision 0 = NP 2 ("split"), 1 = NP 1 (plain bf16), 2 = NP 3 ("split3": numerically an fp32 GEMM).
 // Reference arithmetic replaced: see include/vilco_hip.h (vilco_gemm).
+#include <cstdlib>
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -425,16 +426,27 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   const long tn = (d->N + BN - 1) / BN;
   const long tiles128 = ((d->M + 127) / 128) * tn * nbatch;
   const long tiles256 = ((d->M + 255) / 256) * tn * nbatch;
-  p.BM = (d->M >= 512 && tiles256 >= 200) ? 256 : 128;
+  // tile / split-K choice, tuned on MI355X with tools/gemm_tune.py (profiles/r01_gemm_tune.txt):
+  // the 8-wave 256-row tile wins whenever M >= 2048; with >= 128 tiles only long K is worth splitting
+  // (>= 32 K-steps per split), with fewer tiles filling the 256 CUs comes first.
+  p.BM = d->M >= 2048 ? 256 : 128;
   const long tiles = p.BM == 256 ? tiles256 : tiles128;
   const int nk = p.Kp / BK;
   int ks = 1;
-  if (tiles < 192 && nk >= 8) {
-    ks = (int)((384 + tiles - 1) / tiles);
-    if (ks > nk / 4) ks = nk / 4;        // at least 4 K-steps (128 k) per split
-    if (ks > 32) ks = 32;
+  if (tiles < 256) {
+    if (tiles >= 128) {
+      ks = nk / 32;
+      if (ks > 3) ks = 3;
+    } else {
+      ks = (int)((288 + tiles - 1) / tiles);
+      if (ks > nk / 4) ks = nk / 4;
+      if (ks > 16) ks = 16;
+    }
     if (ks < 1) ks = 1;
   }
+  // tuning overrides (tools/gemm_tune.py): VILCO_GEMM_BM = 128|256, VILCO_GEMM_KS = forced split count
+  if (const char* e = getenv("VILCO_GEMM_BM")) { const int v = atoi(e); if (v == 128 || v == 256) p.BM = v; }
+  if (const char* e = getenv("VILCO_GEMM_KS")) { const int v = atoi(e); if (v >= 1 && v <= nk) ks = v; }
   p.kchunk = (nk + ks - 1) / ks;
   p.ksplit = (nk + p.kchunk - 1) / p.kchunk;
   long out_span = 0;
