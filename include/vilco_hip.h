@@ -193,6 +193,24 @@ int vilco_permute3(const float* in, float* out, int32_t d0, int32_t d1, int32_t 
                    int64_t s0, int64_t s1, int64_t s2, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Step glue of train_one_epoch (MQ/libs/utils/train_utils.py:343-351): clip_grad_norm_ + optimizer.step()  */
+/* as multi-tensor kernels.  ptrs = device int64 [4][n] (param, grad, state1, state2 pointers of the n      */
+/* gradient-bearing fp32 tensors), numel [n]; the work is cut into nchunks chunks of `chunk` elements        */
+/* (chunk_tensor / chunk_off).  norm_coef (device float[2]) = {total L2 norm, min(1, max_norm/(norm+1e-6))}; */
+/* pass it to vilco_optim_step to scale gradients without a host sync, or null.                              */
+/* kind 0 = torch.optim.AdamW (decoupled decay; tensor_step = device float[n], each tensor's step count      */
+/* after this update, for the bias corrections), 1 = SGD with momentum.                                      */
+/* lr / wd are HOST arrays indexed by parameter group (group[n] on the device).                              */
+/* ------------------------------------------------------------------------------------------ */
+int vilco_grad_norm(const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                    const int64_t* chunk_off, int32_t n, int32_t nchunks, int32_t chunk, float max_norm,
+                    float* partial, float* norm_coef, void* stream);
+int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                     const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks, int32_t chunk,
+                     const float* lr, const float* wd, int32_t ngroups, float beta1, float beta2, float eps,
+                     float momentum, const float* tensor_step, const float* norm_coef, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* 1-D NMS on the device, replacing nms_1d_cpu (MQ/libs/utils/csrc/nms_cpu.cpp).                 */
 /* Segments of all classes are passed concatenated; seg_off[nseg+1] gives each class's range      */
 /* (batched_nms's per-class loop, nms.py:124-152, becomes one launch: one workgroup per class).   */

@@ -1,0 +1,100 @@
+"""Step glue.  CPU: parameter grouping and LR sequences vs goldens produced by the
+reference's make_optimizer / make_scheduler.  GPU: the fused multi-tensor clip + AdamW / SGD kernels vs torch.optim."""
+import json
+import os
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "train_glue.json")))
+
+
+def _model(name):
+    from parity_util import xlnet_json
+    import vilco_amd.modeling as vm
+    from vilco_amd.core.config import make_config
+    over = GOLD[name]["overrides"]
+    over['model']['backbone_arch'] = tuple(over['model']['backbone_arch'])
+    m = make_config(**over)['model']
+    kw = dict(m, xlnet_config=xlnet_json(m['embd_dim'], 4)) if m['use_xl'] else m
+    return vm.make_meta_arch('LocPointTransformer', **kw)
+
+
+@pytest.mark.parametrize("name", ["xl", "prompt"])
+def test_param_groups_match_reference(name):
+    from vilco_amd.utils.train_utils import make_optimizer
+    model = _model(name)
+    opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-4))
+    by_id = {}
+    for n, p in model.named_parameters(remove_duplicate=False):
+        by_id.setdefault(id(p), []).append(n)
+    groups = [[sorted(by_id[id(p)])[0] for p in g['params']] for g in opt.param_groups]
+    assert [len(g) for g in groups] == [len(g) for g in GOLD[name]["groups"]]
+    assert groups == GOLD[name]["groups"]
+    assert [g['weight_decay'] for g in opt.param_groups] == GOLD[name]["weight_decay"]
+
+
+@pytest.mark.parametrize("tag", ["cosine", "multistep"])
+def test_lr_sequences_match_reference(tag):
+    from vilco_amd.utils.train_utils import make_scheduler
+    g = GOLD["lr"][tag]
+    lin = torch.nn.Linear(2, 2)
+    opt = torch.optim.AdamW(lin.parameters(), lr=g["base_lr"])
+    sch = make_scheduler(opt, g["cfg"], g["iters_per_epoch"])
+    for want in g["lrs"]:
+        got = opt.param_groups[0]['lr']
+        assert abs(got - want) <= 1e-12 + 1e-9 * abs(want), (got, want)
+        opt.step()
+        sch.step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["AdamW", "SGD"])
+@pytest.mark.parametrize("clip", [-1.0, 0.5])
+def test_fused_optimizer_vs_torch(dev, kind, clip):
+    from vilco_amd.utils.train_utils import FusedOptimizer
+    torch.manual_seed(0)
+    shapes = [(300, 17), (5,), (70000,), (1, 64, 1), (33, 3, 3)]
+    ref_p = [torch.randn(s, dtype=torch.float64, requires_grad=True) for s in shapes]
+    hip_p = [p.detach().float().to(dev).requires_grad_(True) for p in ref_p]
+    mk = lambda ps: [{"params": ps[:2], "weight_decay": 0.05}, {"params": ps[2:4], "weight_decay": 0.0},
+                     {"params": ps[4:], "weight_decay": 0.05}]
+    if kind == "AdamW":
+        ref = torch.optim.AdamW(mk(ref_p), lr=1e-2)
+    else:
+        ref = torch.optim.SGD(mk(ref_p), lr=1e-2, momentum=0.9)
+    hip = FusedOptimizer(mk(hip_p), lr=1e-2, kind=kind, momentum=0.9)
+    for step in range(4):
+        for a, b in zip(ref_p, hip_p):
+            g = torch.randn(a.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(10 * step + a.numel()))
+            a.grad, b.grad = g.clone(), g.float().to(dev)
+        hip_p[1].grad = None if step == 2 else hip_p[1].grad          # a parameter without a gradient is skipped
+        ref_p[1].grad = None if step == 2 else ref_p[1].grad
+        if clip > 0:
+            want_norm = torch.nn.utils.clip_grad_norm_([p for p in ref_p if p.grad is not None], clip)
+        for g in hip.param_groups + ref.param_groups:
+            g['lr'] = 1e-2 * (1 + step)
+        ref.step()
+        hip.step(clip_grad_l2norm=clip)
+        if clip > 0:
+            assert abs(float(hip.last_grad_norm[0]) - float(want_norm)) < 1e-4 * float(want_norm)
+        for a, b in zip(ref_p, hip_p):
+            err = (b.detach().cpu().double() - a.detach()).abs().max() / a.detach().abs().max()
+            assert err < 2e-6, (step, tuple(a.shape), float(err))
+
+
+@pytest.mark.gpu
+def test_train_step_runs_and_descends(dev):
+    """three iterations of the glue on a golden-size model: loss decreases with a plain AdamW schedule"""
+    from parity_util import golden_inputs, load_golden, build_hip_model, golden_cfg
+    from vilco_amd.utils.train_utils import make_optimizer, make_scheduler, train_step
+    gold = load_golden("noxl")
+    model = build_hip_model(gold).train()
+    model.loss_normalizer = golden_cfg(gold)['train_cfg']['init_loss_norm']
+    opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=2e-3))
+    sch = make_scheduler(opt, dict(warmup=False, epochs=2, schedule_type="cosine", schedule_steps=[], schedule_gamma=0.1), 10)
+    vl = golden_inputs(gold)
+    losses = [float(train_step(model, opt, sch, vl, clip_grad_l2norm=1.0)['final_loss']) for _ in range(6)]
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0], losses

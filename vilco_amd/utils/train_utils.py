@@ -1,0 +1,217 @@
+"""Step glue of the MQ training loop on the HIP path (reference:
+MQ/libs/utils/train_utils.py -- make_optimizer :68-144, make_scheduler :147-211, train_one_epoch :318-357,
+save_checkpoint :54-59, fix_random_seed :33-51).
+
+`make_optimizer` reproduces the reference's parameter grouping (decay / no-decay / "remain") and returns a
+`FusedOptimizer`: an ordinary torch.optim.Optimizer (param_groups, state_dict with torch.optim.AdamW's layout,
+LR schedulers attach to it) whose `step()` is three multi-tensor HIP launches -- global-norm clip coefficient
+(kept on the device) + AdamW/SGD update -- instead of ~1500 small kernels."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import torch
+from torch import optim
+
+from .. import _lib
+from ..modeling.blocks import AffineDropPath, LayerNorm, MaskedConv1D, Scale
+from .lr_schedulers import LinearWarmupCosineAnnealingLR, LinearWarmupMultiStepLR
+
+CHUNK = 16384
+
+
+def fix_random_seed(seed, include_cuda=True):
+    rng = torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    if include_cuda and torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    return rng
+
+
+def save_checkpoint(state, file_folder, file_name='checkpoint.pth.tar'):
+    os.makedirs(file_folder, exist_ok=True)
+    torch.save(state, os.path.join(file_folder, file_name))
+
+
+def param_groups(model):
+    """(decay, no_decay, remain) sorted name lists, following the rule chain of train_utils.py:74-103.
+    `m.named_parameters()` is recursive there, so a parameter is classified by every (ancestor module,
+    relative name) pair that matches a rule; what matches nothing ends up in `remain` (weight-decayed)."""
+    decay, no_decay = set(), set()
+    white = (torch.nn.Linear, torch.nn.Conv1d, MaskedConv1D)
+    black = (LayerNorm, torch.nn.GroupNorm)
+    for mn, m in model.named_modules():
+        for pn, _ in m.named_parameters():
+            full = '%s.%s' % (mn, pn) if mn else pn
+            if pn.endswith('bias'):
+                no_decay.add(full)
+            elif 'xlnet' in pn:
+                (no_decay if 'norm' in pn else decay).add(full)
+            elif pn.endswith('weight') and isinstance(m, white):
+                decay.add(full)
+            elif pn.endswith('weight') and isinstance(m, black):
+                no_decay.add(full)
+            elif pn.endswith('scale') and isinstance(m, (Scale, AffineDropPath)):
+                no_decay.add(full)
+            elif pn.endswith('rel_pe'):
+                no_decay.add(full)
+    names = {pn for pn, _ in model.named_parameters()}
+    remain = names - (decay | no_decay)
+    return sorted(decay), sorted(no_decay), sorted(remain)
+
+
+class FusedOptimizer(optim.Optimizer):
+    """AdamW (torch.optim.AdamW defaults: betas (0.9, 0.999), eps 1e-8) or SGD+momentum over fp32 CUDA
+    parameters, executed by vilco_grad_norm / vilco_optim_step."""
+
+    def __init__(self, params, lr, kind="AdamW", momentum=0.9, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        assert kind in ("AdamW", "SGD")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, momentum=momentum))
+        self.kind = kind
+        self._plan_key, self._plan = None, None
+        self.last_grad_norm = None      # device tensor [norm, clip coef] of the last step
+
+    def _passes(self):
+        """[(param, group index)] lists; a parameter listed k times (the adapter aliases of train_utils.py:108-113)
+        is stepped k times per iteration like torch.optim would: k-th occurrences go to pass k."""
+        seen, passes = {}, []
+        for gi, g in enumerate(self.param_groups):
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                k = seen.get(id(p), 0)
+                seen[id(p)] = k + 1
+                while len(passes) <= k:
+                    passes.append([])
+                passes[k].append((p, gi))
+        return passes
+
+    def _build_plan(self, items):
+        numel = [p.numel() for p, _ in items]
+        ct, co = [], []
+        for i, n in enumerate(numel):
+            for off in range(0, n, CHUNK):
+                ct.append(i)
+                co.append(off)
+        dev = items[0][0].device
+        return dict(numel=torch.tensor(numel, dtype=torch.int64, device=dev),
+                    chunk_tensor=torch.tensor(ct, dtype=torch.int32, device=dev),
+                    chunk_off=torch.tensor(co, dtype=torch.int64, device=dev),
+                    group=torch.tensor([gi for _, gi in items], dtype=torch.int32, device=dev),
+                    partial=torch.empty(max(len(ct), 1), dtype=torch.float32, device=dev), nchunks=len(ct))
+
+    @torch.no_grad()
+    def step(self, closure=None, clip_grad_l2norm=-1.0):
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        passes = self._passes()
+        ng = len(self.param_groups)
+        lr = (C.c_float * ng)(*[float(g['lr']) for g in self.param_groups])
+        wd = (C.c_float * ng)(*[float(g['weight_decay']) for g in self.param_groups])
+        g0 = self.param_groups[0]
+        for k, items in enumerate(passes):
+            for p, _ in items:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                    raise RuntimeError("FusedOptimizer needs contiguous fp32 parameters on the HIP device")
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.tensor(0.0)
+                    if self.kind == "AdamW":
+                        st['exp_avg'] = torch.zeros_like(p)
+                        st['exp_avg_sq'] = torch.zeros_like(p)
+                    else:
+                        st['momentum_buffer'] = torch.zeros_like(p)
+            key = (k, tuple(id(p) for p, _ in items))
+            if k == 0 and key != self._plan_key:
+                self._plan_key, self._plan = key, self._build_plan(items)
+            plan = self._plan if k == 0 else self._build_plan(items)
+            s1 = 'exp_avg' if self.kind == "AdamW" else 'momentum_buffer'
+            ptrs = torch.tensor([[p.data_ptr() for p, _ in items], [p.grad.data_ptr() for p, _ in items],
+                                 [self.state[p][s1].data_ptr() for p, _ in items],
+                                 [self.state[p]['exp_avg_sq'].data_ptr() if self.kind == "AdamW" else 0 for p, _ in items]],
+                                dtype=torch.int64).to(items[0][0].device, non_blocking=True)
+            n = len(items)
+            coef = None
+            if k == 0:
+                coef = torch.empty(2, dtype=torch.float32, device=items[0][0].device)
+                _lib.check(lib.vilco_grad_norm(ptrs.data_ptr(), plan['numel'].data_ptr(), plan['chunk_tensor'].data_ptr(),
+                                               plan['chunk_off'].data_ptr(), n, plan['nchunks'], CHUNK,
+                                               float(clip_grad_l2norm), plan['partial'].data_ptr(), coef.data_ptr(), stream))
+                self.last_grad_norm = coef
+            for p, _ in items:
+                self.state[p]['step'] += 1          # torch.optim keeps the step per parameter
+            tstep = torch.tensor([float(self.state[p]['step']) for p, _ in items], dtype=torch.float32).to(
+                items[0][0].device, non_blocking=True)
+            _lib.check(lib.vilco_optim_step(0 if self.kind == "AdamW" else 1, ptrs.data_ptr(), plan['numel'].data_ptr(),
+                                            plan['chunk_tensor'].data_ptr(), plan['chunk_off'].data_ptr(),
+                                            plan['group'].data_ptr(), n, plan['nchunks'], CHUNK, lr, wd, ng,
+                                            g0['betas'][0], g0['betas'][1], g0['eps'], g0['momentum'], tstep.data_ptr(),
+                                            None if coef is None or clip_grad_l2norm <= 0 else coef.data_ptr(), stream))
+        return None
+
+
+def make_optimizer(model, optimizer_config):
+    """same groups as the reference; the duplicated adapter aliases (`pets.*`) are listed again when
+    model.use_adapt, as train_utils.py:108-113 does."""
+    decay, no_decay, remain = param_groups(model)
+    pd = dict(model.named_parameters())
+    if getattr(model, "use_adapt", False):
+        for mn, m in model.named_modules():
+            for pn, p in m.named_parameters():
+                full = '%s.%s' % (mn, pn) if mn else pn
+                if 'pets' in full:
+                    pd[full] = p
+    groups = [{"params": [pd[n] for n in decay], "weight_decay": optimizer_config['weight_decay']},
+              {"params": [pd[n] for n in no_decay], "weight_decay": 0.0},
+              {"params": [pd[n] for n in remain], "weight_decay": optimizer_config['weight_decay']}]
+    if optimizer_config["type"] not in ("SGD", "AdamW"):
+        raise TypeError("Unsupported optimizer!")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")      # duplicate-parameter warning: intended, see _passes()
+        return FusedOptimizer(groups, lr=optimizer_config["learning_rate"], kind=optimizer_config["type"],
+                              momentum=optimizer_config["momentum"],
+                              weight_decay=0.01 if optimizer_config["type"] == "AdamW" else 0.0)
+
+
+def make_scheduler(optimizer, optimizer_config, num_iters_per_epoch, last_epoch=-1):
+    """per-iteration schedulers, as train_utils.py:147-211"""
+    c = optimizer_config
+    if c["warmup"]:
+        max_steps = (c["epochs"] + c["warmup_epochs"]) * num_iters_per_epoch
+        warmup_steps = c["warmup_epochs"] * num_iters_per_epoch
+        if c["schedule_type"] == "cosine":
+            return LinearWarmupCosineAnnealingLR(optimizer, warmup_steps, max_steps, last_epoch=last_epoch)
+        if c["schedule_type"] == "multistep":
+            steps = [num_iters_per_epoch * s for s in c["schedule_steps"]]
+            return LinearWarmupMultiStepLR(optimizer, warmup_steps, steps, gamma=c["schedule_gamma"], last_epoch=last_epoch)
+        raise TypeError("Unsupported scheduler!")
+    max_steps = c["epochs"] * num_iters_per_epoch
+    if c["schedule_type"] == "cosine":
+        return optim.lr_scheduler.CosineAnnealingLR(optimizer, max_steps, last_epoch=last_epoch)
+    if c["schedule_type"] == "multistep":
+        steps = [num_iters_per_epoch * s for s in c["schedule_steps"]]
+        return optim.lr_scheduler.MultiStepLR(optimizer, steps, gamma=c["schedule_gamma"], last_epoch=last_epoch)
+    raise TypeError("Unsupported scheduler!")
+
+
+def train_step(model, optimizer, scheduler, video_list, task_id=0, prev_out_cls_logits=None,
+               clip_grad_l2norm=-1.0, reducer=None):
+    """one iteration of train_one_epoch (train_utils.py:322-357): zero_grad, forward, backward,
+    (gradient all-reduce), clip, optimizer / scheduler step, adapter EMA."""
+    optimizer.zero_grad(set_to_none=True)
+    if reducer is not None:
+        reducer.begin()
+    losses = model(video_list, task_id=task_id, prev_out_cls_logits=prev_out_cls_logits)
+    losses['final_loss'].backward()
+    if reducer is not None:
+        reducer.finish()
+    optimizer.step(clip_grad_l2norm=clip_grad_l2norm)
+    if scheduler is not None:
+        scheduler.step()
+    if getattr(model, "use_adapt", False):
+        model.post_train_step()
+    return losses
