@@ -142,13 +142,16 @@ int vilco_relshift_bwd(const float* ds, float* dbd, float scale, int32_t B, int3
 /* MaskedMHCA / MaskedMHA cores (blocks.py:383-400, 251-265) and, with `bias`, XLNet's             */
 /* rel_attn_core (modeling_xlnet_x.py:270-320; bias = scale * rel_shift(bd)).  Scores stay on chip. */
 /* q [B,Tq,H*hd], k/v [B,Tk,H*hd], bias [B,H,Tq,Tk] or null, lse [B,H,Tq] (saved for backward).     */
-/* mask modes as vilco_softmax_fwd; precision as vilco_gemm.  hd <= 64 (vilco_attn_supported).      */
+/* mask modes as vilco_softmax_fwd; precision as vilco_gemm.  hd <= 64, hd % 4 == 0.                */
 /* ------------------------------------------------------------------------------------------ */
 int vilco_attn_supported(int32_t hd);
+/* workspace = bf16 operand planes (q, k natural; v transposed), built inside the call by the pack kernels */
+size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
-                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, void* stream);
-size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq);
+                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, void* workspace,
+                   size_t workspace_bytes, void* stream);
+size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 /* dq/dk/dv are overwritten; dbias (optional, [B,H,Tq,Tk]) receives dS.  Deterministic (no atomics). */
 int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, const float* o, const float* lse, const float* dout,

@@ -13,18 +13,19 @@
 // work in the "transposed" orientation S^T = K Q^T, O^T = V^T P^T: the MFMA C layout then puts ONE query on a
 // lane (col = lane & 15) and 4 consecutive keys / channels in its registers, so the softmax statistics are
 // lane-local (two shuffles per reduction), P goes to LDS as packed 8-byte stores, and O leaves as float4.
-// K / V tiles are staged global -> registers -> (split) -> LDS; V is transposed in the register stage
-// ([d][key] image) because the PV product contracts over keys.  LDS rows are XOR-swizzled per row width so
-// every ds_read_b128 fragment read is bank-conflict free.
+// q/k/v (and dO in backward) are first split ONCE into bf16 planes by the pack kernels of pack.h -- natural
+// [token][d] images and transposed [d][token] images (the PV / dQ / dK / dV products contract over tokens) --
+// so the tile loops only copy 16-byte chunks global -> registers -> LDS (next tile prefetched under the current
+// tile's MFMAs).  LDS rows are XOR-swizzled per row width so every ds_read_b128 fragment read is conflict free,
+// and every fragment address is one per-lane base plus compile-time constants.
 //
 // Backward = two kernels that recompute P from (q, k, lse): attn_bwd_dq (same orientation, one workgroup per
 // query tile: dS -> dQ, optional dBias) and attn_bwd_dkdv (one workgroup per key tile, S = Q K^T orientation so
 // P^T / dS^T are packed stores: dV^T = dO^T P, dK^T = Q^T dS).  No atomics: results are bitwise reproducible.
 #include "common.h"
+#include "pack.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
 
@@ -70,67 +71,60 @@ __device__ __forceinline__ void split4(const float (&v)[4], bf16x4 (&part)[3]) {
   }
 }
 
-// natural tile: R rows x W (>= hd, zero padded) from fp32 rows g[(row0+r)*ld + d]; rows >= rows_valid are zero
-template <int W, int NP>
-__device__ __forceinline__ void load_tile_nat(__bf16* lds, int R, const float* __restrict__ g, long ld, int row0,
-                                              int rows_valid, int hd, int tid) {
-  constexpr int CPR = W / 8;
-  const int chunks = R * CPR;
-  for (int id = tid; id < chunks; id += ATT_THREADS) {
-    const int row = id / CPR, c = id % CPR;
-    const int d0 = c * 8;
-    const int grow = row0 + row;
-    float v[8];
-    if (grow < rows_valid && d0 + 8 <= hd) {
-      const float4 a = *reinterpret_cast<const float4*>(g + (long)grow * ld + d0);
-      const float4 b = *reinterpret_cast<const float4*>(g + (long)grow * ld + d0 + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (grow < rows_valid && d0 + e < hd) ? g[(long)grow * ld + d0 + e] : 0.f;
-    }
-    bf16x8 part[3];
-    split8<NP>(v, part);
-#pragma unroll
-    for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(lds + q * R * W + toff<W>(row, c)) = part[q];
-  }
-}
+// ---- operand planes (built by pack.h): part q of batch z starts at p + q*part_stride + z*batch_stride
+struct Planes {
+  const __bf16* p;
+  long part_stride, batch_stride;
+  int row_stride;      // elements between rows
+  int rows;            // valid rows (tokens for natural planes, hd for transposed planes)
+  int cols;            // valid columns (padded: HDP for natural planes, Tp for transposed planes)
+};
 
-// transposed tile: HDP rows (d) x WK (keys) from fp32 rows g[(key0+k)*ld + d]; patches of 8 keys x 2 d
-template <int WK, int NP>
-__device__ __forceinline__ void load_tile_tr(__bf16* lds, int HDP, const float* __restrict__ g, long ld, int key0,
-                                             int keys_valid, int hd, int tid) {
-  const int DP = HDP / 2;
-  const int patches = (WK / 8) * DP;
-  for (int id = tid; id < patches; id += ATT_THREADS) {
-    const int dp = id % DP, kc = id / DP;
-    const int d = dp * 2;
-    float v0[8], v1[8];
+// staged copy of an R x W tile (all NP parts): gload -> registers, lstore -> swizzled LDS image [part][R][W].
+// rows >= pl.rows or columns >= pl.cols read as zero.
+template <int W, int R, int NP>
+struct TileStage {
+  static constexpr int N = (R * (W / 8) + ATT_THREADS - 1) / ATT_THREADS;
+  bf16x8 v[NP][N];
+};
+
+template <int W, int R, int NP>
+__device__ __forceinline__ void gload_tile(TileStage<W, R, NP>& st, const Planes& pl, const __bf16* base, int row0,
+                                           int col0, int tid) {
+  constexpr int CPR = W / 8;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const int key = key0 + kc * 8 + kk;
-      float2 t = make_float2(0.f, 0.f);
-      if (key < keys_valid) {
-        if (d + 2 <= hd) t = *reinterpret_cast<const float2*>(g + (long)key * ld + d);
-        else if (d < hd) t.x = g[(long)key * ld + d];
-      }
-      v0[kk] = t.x;
-      v1[kk] = t.y;
-    }
-    bf16x8 p0[3], p1[3];
-    split8<NP>(v0, p0);
-    split8<NP>(v1, p1);
+  for (int i = 0; i < TileStage<W, R, NP>::N; ++i) {
+    const int id = tid + i * ATT_THREADS;
+    const int row = id / CPR, c = id % CPR;
+    const bool ok = id < R * CPR && row0 + row < pl.rows && col0 + c * 8 < pl.cols;
+    const long off = (long)(row0 + row) * pl.row_stride + col0 + c * 8;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      *reinterpret_cast<bf16x8*>(lds + q * HDP * WK + toff<WK>(d, kc)) = p0[q];
-      *reinterpret_cast<bf16x8*>(lds + q * HDP * WK + toff<WK>(d + 1, kc)) = p1[q];
+      bf16x8 z = {};
+      st.v[q][i] = ok ? *reinterpret_cast<const bf16x8*>(base + q * pl.part_stride + off) : z;
     }
   }
 }
 
+template <int W, int R, int NP>
+__device__ __forceinline__ void lstore_tile(const TileStage<W, R, NP>& st, __bf16* lds, int tid) {
+  constexpr int CPR = W / 8;
+#pragma unroll
+  for (int i = 0; i < TileStage<W, R, NP>::N; ++i) {
+    const int id = tid + i * ATT_THREADS;
+    if (id >= R * CPR) continue;
+    const int o = toff<W>(id / CPR, id % CPR);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(lds + q * R * W + o) = st.v[q][i];
+  }
+}
+
+// fragment read.  fb = toff<W>(lane & 15, lane >> 4) is computed once per lane; rows are only ever added in
+// multiples of 16 (the swizzle is invariant under row += 16) and the second 32-wide k-step of a 64-wide row is
+// the XOR of 4 chunks (32 elements), so every address is fb plus compile-time constants.
 template <int W>
-__device__ __forceinline__ bf16x8 frag(const __bf16* tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(tile + toff<W>(row, chunk));
+__device__ __forceinline__ bf16x8 frag(const __bf16* tile, int fb, int row_add, int ks) {
+  return *reinterpret_cast<const bf16x8*>(tile + ((fb + row_add * W) ^ (ks << 5)));
 }
 
 // acc += sum over part pairs of A_parts x B_parts (smallest terms first)
@@ -158,31 +152,34 @@ struct AttnArgs {
   // backward
   const float* dout; const float* delta;
   float* dq; float* dk; float* dv; float* dbias;
+  // bf16 planes (natural [tok][HDP] and transposed [d][Tp]) of k, v, q, dout
+  Planes kn, vn, kt, vt, qn, don, qt, dot;
 };
 
 // registers holding the B-operand fragments of this wave's 16 query rows (all k-steps, all parts)
 template <int HDP, int NP>
 struct QFrag { bf16x8 f[HDP / 32][3]; };
 
+// B fragments straight from a natural plane: lane supplies row (lane & 15), k = ks*32 + 8*(lane >> 4) + j
 template <int HDP, int NP>
-__device__ __forceinline__ void load_qfrag(QFrag<HDP, NP>& qf, const float* __restrict__ g, long ld, int qrow,
-                                           int Tq, int hd, int lane) {
-  // lane supplies row (lane & 15), k = 8*(lane >> 4) + j of each 32-wide k-step
+__device__ __forceinline__ void load_qfrag(QFrag<HDP, NP>& qf, const Planes& pl, const __bf16* base, int qrow, int lane) {
   const int r = qrow + (lane & 15);
 #pragma unroll
   for (int ks = 0; ks < HDP / 32; ++ks) {
-    const int d0 = ks * 32 + (lane >> 4) * 8;
-    float v[8];
+    const long off = (long)r * pl.row_stride + ks * 32 + (lane >> 4) * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (r < Tq && d0 + e < hd) ? g[(long)r * ld + d0 + e] : 0.f;
-    bf16x8 part[3];
-    split8<NP>(v, part);
-#pragma unroll
-    for (int q = 0; q < NP; ++q) qf.f[ks][q] = part[q];
+    for (int q = 0; q < NP; ++q) {
+      bf16x8 z = {};
+      qf.f[ks][q] = r < pl.rows ? *reinterpret_cast<const bf16x8*>(base + q * pl.part_stride + off) : z;
+    }
   }
 }
 
-// score of (query i, key j) after scale: add bias, apply mask
+// exp(x) on the hardware exp2 unit (v_exp_f32): one multiply + one transcendental instead of the ~15-instruction
+// expf; |relative error| <= ~2^-21 for the |x| <= 40 range of softmax arguments, far inside the 1e-3 budget.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+// score of (query i, key j) after scale + bias: apply the mask
 __device__ __forceinline__ float mask_score(float s, int i, int j, int len, int Tk, int mode) {
   if (j >= Tk) return -INFINITY;
   if (mode == 0) return j < len ? s : -INFINITY;
@@ -201,17 +198,19 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int bh = b * a.H + h;
   const long ld = a.C;
-  const float* qg = a.q + (long)b * a.Tq * ld + h * a.hd;
-  const float* kg = a.k + (long)b * a.Tk * ld + h * a.hd;
-  const float* vg = a.v + (long)b * a.Tk * ld + h * a.hd;
   const int q0 = qt * 64 + wave * 16;
   const int qi = q0 + (lane & 15);                 // this lane's query
   const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
-  const float* bias = a.bias ? a.bias + ((long)(b * a.H + h) * a.Tq) * a.Tk : nullptr;
+  const float* bias = a.bias ? a.bias + ((long)bh * a.Tq) * a.Tk : nullptr;
+  const __bf16* kbase = a.kn.p + (long)bh * a.kn.batch_stride;
+  const __bf16* vbase = a.vt.p + (long)bh * a.vt.batch_stride;
+  const int fbH = toff<HDP>(lane & 15, lane >> 4);        // fragment bases (see frag())
+  const int fb64 = toff<64>(lane & 15, lane >> 4);
 
   QFrag<HDP, NP> qf;
-  load_qfrag<HDP, NP>(qf, qg, ld, q0, a.Tq, a.hd, lane);
+  load_qfrag<HDP, NP>(qf, a.qn, a.qn.p + (long)bh * a.qn.batch_stride, q0, lane);
 
   f32x4 oacc[HDP / 16];
 #pragma unroll
@@ -221,14 +220,25 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   int kend = a.Tk;
   if (a.mode == 0 && len < kend) kend = len;      // tiles entirely beyond kv_len contribute nothing
   const int ntiles = (kend + BKV - 1) / BKV;
+  const int kfull = len < a.Tk ? len : a.Tk;      // keys below this index need no masking in any mode
   __bf16* myP = sP + wave * NP * 16 * BKV;
 
+  TileStage<HDP, BKV, NP> stK;
+  TileStage<BKV, HDP, NP> stV;
+  if (ntiles > 0) {
+    gload_tile<HDP, BKV, NP>(stK, a.kn, kbase, 0, 0, tid);
+    gload_tile<BKV, HDP, NP>(stV, a.vt, vbase, 0, 0, tid);
+  }
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * BKV;
     __syncthreads();                                // previous tile fully consumed
-    load_tile_nat<HDP, NP>(sK, BKV, kg, ld, k0, a.Tk, a.hd, tid);
-    load_tile_tr<BKV, NP>(sVt, HDP, vg, ld, k0, a.Tk, a.hd, tid);
+    lstore_tile<HDP, BKV, NP>(stK, sK, tid);
+    lstore_tile<BKV, HDP, NP>(stV, sVt, tid);
     __syncthreads();
+    if (t + 1 < ntiles) {                           // next tile's loads fly under this tile's MFMAs
+      gload_tile<HDP, BKV, NP>(stK, a.kn, kbase, k0 + BKV, 0, tid);
+      gload_tile<BKV, HDP, NP>(stV, a.vt, vbase, 0, k0 + BKV, tid);
+    }
 
     // S^T[key][q] = K Q^T : 4 m-tiles of 16 keys, this wave's 16 queries
     f32x4 s[4];
@@ -239,39 +249,46 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
       for (int ks = 0; ks < HDP / 32; ++ks) {
         bf16x8 ka[3];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) ka[q] = frag<HDP>(sK + q * BKV * HDP, mi * 16 + (lane & 15), ks * 4 + (lane >> 4));
+        for (int q = 0; q < NP; ++q) ka[q] = frag<HDP>(sK + q * BKV * HDP, fbH, mi * 16, ks);
         c = mfma_parts<NP>(ka, qf.f[ks], c);
       }
       s[mi] = c;
     }
     // lane holds query qi, keys k0 + mi*16 + 4*(lane>>4) + r
+    const bool plain = (bias == nullptr) && (k0 + BKV <= kfull);      // wave-uniform: no bias, nothing masked
     float tmax = -INFINITY;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int jb = k0 + mi * 16 + (lane >> 4) * 4;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias && qi < a.Tq) {
+      if (plain) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (jb + r < a.Tk) bv[r] = bias[(long)qi * a.Tk + jb + r];
-      }
+        for (int r = 0; r < 4; ++r) { s[mi][r] *= a.scale; tmax = fmaxf(tmax, s[mi][r]); }
+      } else {
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias && qi < a.Tq) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float x = mask_score(s[mi][r] * a.scale + bv[r], qi, jb + r, len, a.Tk, a.mode);
-        s[mi][r] = x;
-        tmax = fmaxf(tmax, x);
+          for (int r = 0; r < 4; ++r) if (jb + r < a.Tk) bv[r] = bias[(long)qi * a.Tk + jb + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = mask_score(s[mi][r] * a.scale + bv[r], qi, jb + r, len, a.Tk, a.mode);
+          s[mi][r] = x;
+          tmax = fmaxf(tmax, x);
+        }
       }
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);
+    const bool dead = m_new == -INFINITY;
+    const float alpha = dead ? 1.f : fast_exp(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       float p[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p[r] = (m_new == -INFINITY) ? 0.f : expf(s[mi][r] - m_new);
+        p[r] = dead ? 0.f : fast_exp(s[mi][r] - m_new);
         psum += p[r];
       }
       bf16x4 pp[3];
@@ -296,12 +313,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     for (int ks = 0; ks < BKV / 32; ++ks) {
       bf16x8 pb[3];
 #pragma unroll
-      for (int q = 0; q < NP; ++q) pb[q] = frag<BKV>(myP + q * 16 * BKV, lane & 15, ks * 4 + (lane >> 4));
+      for (int q = 0; q < NP; ++q) pb[q] = frag<BKV>(myP + q * 16 * BKV, fb64, 0, ks);
 #pragma unroll
       for (int di = 0; di < HDP / 16; ++di) {
         bf16x8 va[3];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) va[q] = frag<BKV>(sVt + q * HDP * BKV, di * 16 + (lane & 15), ks * 4 + (lane >> 4));
+        for (int q = 0; q < NP; ++q) va[q] = frag<BKV>(sVt + q * HDP * BKV, fb64, di * 16, ks);
         oacc[di] = mfma_parts<NP>(va, pb, oacc[di]);
       }
     }
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 4; ++r) if (d + r < a.hd) og[d + r] = oacc[di][r] * inv;
       }
     }
-    if (a.lse && (lane >> 4) == 0) a.lse[((long)b * a.H + h) * a.Tq + qi] = m_run + logf(l_run);
+    if (a.lse && (lane >> 4) == 0) a.lse[(long)bh * a.Tq + qi] = m_run + logf(l_run);
   }
 }
 
@@ -353,21 +370,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int bh = b * a.H + h;
   const long ld = a.C;
-  const float* qg = a.q + (long)b * a.Tq * ld + h * a.hd;
-  const float* kg = a.k + (long)b * a.Tk * ld + h * a.hd;
-  const float* vg = a.v + (long)b * a.Tk * ld + h * a.hd;
-  const float* dog = a.dout + (long)b * a.Tq * ld + h * a.hd;
   const int q0 = qt * 64 + wave * 16;
   const int qi = q0 + (lane & 15);
   const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
-  const long row_bh = ((long)b * a.H + h) * a.Tq;
+  const long row_bh = (long)bh * a.Tq;
   const float* bias = a.bias ? a.bias + row_bh * a.Tk : nullptr;
   float* dbias = a.dbias ? a.dbias + row_bh * a.Tk : nullptr;
+  const __bf16* knb = a.kn.p + (long)bh * a.kn.batch_stride;
+  const __bf16* vnb = a.vn.p + (long)bh * a.vn.batch_stride;
+  const __bf16* ktb = a.kt.p + (long)bh * a.kt.batch_stride;
+  const int fbH = toff<HDP>(lane & 15, lane >> 4);
+  const int fb64 = toff<64>(lane & 15, lane >> 4);
 
   QFrag<HDP, NP> qf, dof;
-  load_qfrag<HDP, NP>(qf, qg, ld, q0, a.Tq, a.hd, lane);
-  load_qfrag<HDP, NP>(dof, dog, ld, q0, a.Tq, a.hd, lane);
+  load_qfrag<HDP, NP>(qf, a.qn, a.qn.p + (long)bh * a.qn.batch_stride, q0, lane);
+  load_qfrag<HDP, NP>(dof, a.don, a.don.p + (long)bh * a.don.batch_stride, q0, lane);
   const float lse = qi < a.Tq ? a.lse[row_bh + qi] : 0.f;
   const float dlt = qi < a.Tq ? a.delta[row_bh + qi] : 0.f;
 
@@ -378,15 +397,29 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   int kend = a.Tk;
   if (a.mode == 0 && len < kend) kend = len;
   const int ntiles = (kend + BKV - 1) / BKV;
+  const int kfull = len < a.Tk ? len : a.Tk;
   __bf16* myS = sS + wave * NP * 16 * BKV;
 
+  TileStage<HDP, BKV, NP> stK, stV;
+  TileStage<BKV, HDP, NP> stKt;
+  if (ntiles > 0) {
+    gload_tile<HDP, BKV, NP>(stK, a.kn, knb, 0, 0, tid);
+    gload_tile<HDP, BKV, NP>(stV, a.vn, vnb, 0, 0, tid);
+    gload_tile<BKV, HDP, NP>(stKt, a.kt, ktb, 0, 0, tid);
+  }
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * BKV;
     __syncthreads();
-    load_tile_nat<HDP, NP>(sK, BKV, kg, ld, k0, a.Tk, a.hd, tid);
-    load_tile_nat<HDP, NP>(sV, BKV, vg, ld, k0, a.Tk, a.hd, tid);
-    load_tile_tr<BKV, NP>(sKt, HDP, kg, ld, k0, a.Tk, a.hd, tid);
+    lstore_tile<HDP, BKV, NP>(stK, sK, tid);
+    lstore_tile<HDP, BKV, NP>(stV, sV, tid);
+    lstore_tile<BKV, HDP, NP>(stKt, sKt, tid);
     __syncthreads();
+    if (t + 1 < ntiles) {
+      gload_tile<HDP, BKV, NP>(stK, a.kn, knb, k0 + BKV, 0, tid);
+      gload_tile<HDP, BKV, NP>(stV, a.vn, vnb, k0 + BKV, 0, tid);
+      gload_tile<BKV, HDP, NP>(stKt, a.kt, ktb, 0, k0 + BKV, tid);
+    }
+    const bool plain = (bias == nullptr) && (k0 + BKV <= kfull);
 
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -396,8 +429,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
         bf16x8 ka[3], va[3];
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-          ka[q] = frag<HDP>(sK + q * BKV * HDP, mi * 16 + (lane & 15), ks * 4 + (lane >> 4));
-          va[q] = frag<HDP>(sV + q * BKV * HDP, mi * 16 + (lane & 15), ks * 4 + (lane >> 4));
+          ka[q] = frag<HDP>(sK + q * BKV * HDP, fbH, mi * 16, ks);
+          va[q] = frag<HDP>(sV + q * BKV * HDP, fbH, mi * 16, ks);
         }
         s = mfma_parts<NP>(ka, qf.f[ks], s);       // S^T  = K Q^T
         dp = mfma_parts<NP>(va, dof.f[ks], dp);    // dP^T = V dO^T
@@ -406,10 +439,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float bv = 0.f;
-        if (bias && qi < a.Tq && jb + r < a.Tk) bv = bias[(long)qi * a.Tk + jb + r];
-        const float x = mask_score(s[r] * a.scale + bv, qi, jb + r, len, a.Tk, a.mode);
-        const float p = (x == -INFINITY) ? 0.f : expf(x - lse);
+        float x = s[r] * a.scale;
+        if (!plain) {
+          float bv = 0.f;
+          if (bias && qi < a.Tq && jb + r < a.Tk) bv = bias[(long)qi * a.Tk + jb + r];
+          x = mask_score(x + bv, qi, jb + r, len, a.Tk, a.mode);
+        }
+        const float p = (x == -INFINITY) ? 0.f : fast_exp(x - lse);
         ds[r] = p * (dp[r] - dlt);
       }
       if (dbias && qi < a.Tq) {
@@ -429,17 +465,17 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int ks = 0; ks < BKV / 32; ++ks) {
       bf16x8 sb[3];
 #pragma unroll
-      for (int q = 0; q < NP; ++q) sb[q] = frag<BKV>(myS + q * 16 * BKV, lane & 15, ks * 4 + (lane >> 4));
+      for (int q = 0; q < NP; ++q) sb[q] = frag<BKV>(myS + q * 16 * BKV, fb64, 0, ks);
 #pragma unroll
       for (int di = 0; di < HDP / 16; ++di) {
         bf16x8 ka[3];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) ka[q] = frag<BKV>(sKt + q * HDP * BKV, di * 16 + (lane & 15), ks * 4 + (lane >> 4));
+        for (int q = 0; q < NP; ++q) ka[q] = frag<BKV>(sKt + q * HDP * BKV, fb64, di * 16, ks);
         dqacc[di] = mfma_parts<NP>(ka, sb, dqacc[di]);
       }
     }
   }
-  // rows of dbias beyond the visited key tiles (mode 0, keys >= kv_len) are zero
+  // columns of dbias beyond the visited key tiles (mode 0, keys >= kv_len) are zero
   if (dbias && qi < a.Tq) {
     for (int j = ntiles * BKV + (lane >> 4); j < a.Tk; j += 4) dbias[(long)qi * a.Tk + j] = 0.f;
   }
@@ -472,18 +508,26 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int bh = b * a.H + h;
   const long ld = a.C;
-  const float* qg = a.q + (long)b * a.Tq * ld + h * a.hd;
-  const float* kg = a.k + (long)b * a.Tk * ld + h * a.hd;
-  const float* vg = a.v + (long)b * a.Tk * ld + h * a.hd;
-  const float* dog = a.dout + (long)b * a.Tq * ld + h * a.hd;
   const int k0 = kt * BKV;
   const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
-  const long row_bh = ((long)b * a.H + h) * a.Tq;
+  const long row_bh = (long)bh * a.Tq;
   const float* bias = a.bias ? a.bias + row_bh * a.Tk : nullptr;
+  const __bf16* qnb = a.qn.p + (long)bh * a.qn.batch_stride;
+  const __bf16* donb = a.don.p + (long)bh * a.don.batch_stride;
+  const __bf16* qtb = a.qt.p + (long)bh * a.qt.batch_stride;
+  const __bf16* dotb = a.dot.p + (long)bh * a.dot.batch_stride;
+  const int fbH = toff<HDP>(lane & 15, lane >> 4);
+  const int fb32 = toff<32>(lane & 15, lane >> 4);
 
-  load_tile_nat<HDP, NP>(sK, BKV, kg, ld, k0, a.Tk, a.hd, tid);
-  load_tile_nat<HDP, NP>(sV, BKV, vg, ld, k0, a.Tk, a.hd, tid);
+  {
+    TileStage<HDP, BKV, NP> st;
+    gload_tile<HDP, BKV, NP>(st, a.kn, a.kn.p + (long)bh * a.kn.batch_stride, k0, 0, tid);
+    lstore_tile<HDP, BKV, NP>(st, sK, tid);
+    gload_tile<HDP, BKV, NP>(st, a.vn, a.vn.p + (long)bh * a.vn.batch_stride, k0, 0, tid);
+    lstore_tile<HDP, BKV, NP>(st, sV, tid);
+  }
 
   // S / dP tiles: wave -> (m-tile of 16 queries = wave & 1, key half = wave >> 1 : 2 n-tiles of 16 keys)
   const int mq = wave & 1, kh = wave >> 1;
@@ -493,15 +537,31 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
   for (int i = 0; i < HDP / 16; ++i) { dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const bool tile_dead = (a.mode == 0 && k0 >= len);      // every key of this tile is masked: grads are zero
+  const int kfull = len < a.Tk ? len : a.Tk;
+  const bool plain = (bias == nullptr) && (k0 + BKV <= kfull);
   const int nq = tile_dead ? 0 : (a.Tq + BQ - 1) / BQ;
+  TileStage<HDP, BQ, NP> stQ, stdO;
+  TileStage<BQ, HDP, NP> stQt, stdOt;
+  if (nq > 0) {
+    gload_tile<HDP, BQ, NP>(stQ, a.qn, qnb, 0, 0, tid);
+    gload_tile<HDP, BQ, NP>(stdO, a.don, donb, 0, 0, tid);
+    gload_tile<BQ, HDP, NP>(stQt, a.qt, qtb, 0, 0, tid);
+    gload_tile<BQ, HDP, NP>(stdOt, a.dot, dotb, 0, 0, tid);
+  }
   for (int t = 0; t < nq; ++t) {
     const int q0 = t * BQ;
     __syncthreads();
-    load_tile_nat<HDP, NP>(sQ, BQ, qg, ld, q0, a.Tq, a.hd, tid);
-    load_tile_nat<HDP, NP>(sdO, BQ, dog, ld, q0, a.Tq, a.hd, tid);
-    load_tile_tr<BQ, NP>(sQt, HDP, qg, ld, q0, a.Tq, a.hd, tid);
-    load_tile_tr<BQ, NP>(sdOt, HDP, dog, ld, q0, a.Tq, a.hd, tid);
+    lstore_tile<HDP, BQ, NP>(stQ, sQ, tid);
+    lstore_tile<HDP, BQ, NP>(stdO, sdO, tid);
+    lstore_tile<BQ, HDP, NP>(stQt, sQt, tid);
+    lstore_tile<BQ, HDP, NP>(stdOt, sdOt, tid);
     __syncthreads();
+    if (t + 1 < nq) {
+      gload_tile<HDP, BQ, NP>(stQ, a.qn, qnb, q0 + BQ, 0, tid);
+      gload_tile<HDP, BQ, NP>(stdO, a.don, donb, q0 + BQ, 0, tid);
+      gload_tile<BQ, HDP, NP>(stQt, a.qt, qtb, 0, q0 + BQ, tid);
+      gload_tile<BQ, HDP, NP>(stdOt, a.dot, dotb, 0, q0 + BQ, tid);
+    }
 
     // lane: key col = lane & 15 (per n-tile), query rows 4*(lane>>4) + r of m-tile mq
     float lse4[4], dl4[4];
@@ -520,10 +580,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
         bf16x8 qa[3], kb[3], da[3], vb[3];
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-          qa[q] = frag<HDP>(sQ + q * BQ * HDP, mq * 16 + (lane & 15), ks * 4 + (lane >> 4));
-          da[q] = frag<HDP>(sdO + q * BQ * HDP, mq * 16 + (lane & 15), ks * 4 + (lane >> 4));
-          kb[q] = frag<HDP>(sK + q * BKV * HDP, ncol + (lane & 15), ks * 4 + (lane >> 4));
-          vb[q] = frag<HDP>(sV + q * BKV * HDP, ncol + (lane & 15), ks * 4 + (lane >> 4));
+          qa[q] = frag<HDP>(sQ + q * BQ * HDP, fbH, mq * 16, ks);
+          da[q] = frag<HDP>(sdO + q * BQ * HDP, fbH, mq * 16, ks);
+          kb[q] = frag<HDP>(sK + q * BKV * HDP, fbH, ncol, ks);
+          vb[q] = frag<HDP>(sV + q * BKV * HDP, fbH, ncol, ks);
         }
         s = mfma_parts<NP>(qa, kb, s);        // S  = Q K^T
         dp = mfma_parts<NP>(da, vb, dp);      // dP = dO V^T
@@ -533,10 +593,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r;
-        float bv = 0.f;
-        if (bias && qi < a.Tq && j < a.Tk) bv = bias[(long)qi * a.Tk + j];
-        const float x = mask_score(s[r] * a.scale + bv, qi, j, len, a.Tk, a.mode);
-        p[r] = (qi < a.Tq && x != -INFINITY) ? expf(x - lse4[r]) : 0.f;
+        float x = s[r] * a.scale;
+        if (!plain) {
+          float bv = 0.f;
+          if (bias && qi < a.Tq && j < a.Tk) bv = bias[(long)qi * a.Tk + j];
+          x = mask_score(x + bv, qi, j, len, a.Tk, a.mode);
+        }
+        p[r] = (qi < a.Tq && x != -INFINITY) ? fast_exp(x - lse4[r]) : 0.f;
         ds[r] = p[r] * (dp[r] - dl4[r]);
       }
       bf16x4 pp[3], dd[3];
@@ -556,16 +619,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
     bf16x8 pb[3], sb[3];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      pb[q] = frag<BQ>(sPt + q * BKV * BQ, wave * 16 + (lane & 15), lane >> 4);
-      sb[q] = frag<BQ>(sdSt + q * BKV * BQ, wave * 16 + (lane & 15), lane >> 4);
+      pb[q] = frag<BQ>(sPt + q * BKV * BQ, fb32, wave * 16, 0);
+      sb[q] = frag<BQ>(sdSt + q * BKV * BQ, fb32, wave * 16, 0);
     }
 #pragma unroll
     for (int di = 0; di < HDP / 16; ++di) {
       bf16x8 oa[3], qa[3];
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
-        oa[q] = frag<BQ>(sdOt + q * HDP * BQ, di * 16 + (lane & 15), lane >> 4);
-        qa[q] = frag<BQ>(sQt + q * HDP * BQ, di * 16 + (lane & 15), lane >> 4);
+        oa[q] = frag<BQ>(sdOt + q * HDP * BQ, fb32, di * 16, 0);
+        qa[q] = frag<BQ>(sQt + q * HDP * BQ, fb32, di * 16, 0);
       }
       dvacc[di] = mfma_parts<NP>(oa, pb, dvacc[di]);
       dkacc[di] = mfma_parts<NP>(qa, sb, dkacc[di]);
@@ -642,32 +705,85 @@ int dispatch(const AttnArgs& a, int precision, bool bwd, hipStream_t s) {
 int check_common(int B, int H, int Tq, int Tk, int hd, int mode, int precision) {
   if (B < 0 || H <= 0 || Tq < 0 || Tk < 0 || hd <= 0) return VILCO_ERR_BADARG;
   if (mode < 0 || mode > 2 || precision < 0 || precision > 2) return VILCO_ERR_BADARG;
-  if (hd > 64) return VILCO_ERR_UNSUPPORTED;          // head dims up to 64 (P: 64, tests: 8, 16)
+  if (hd > 64 || (hd % 4) != 0) return VILCO_ERR_UNSUPPORTED;      // head dims 4..64 (P: 64, tests: 8, 16, 32)
   return VILCO_OK;
 }
 
+inline long up(long x, long a) { return (x + a - 1) / a * a; }
+inline int np_of(int precision) { return precision == 1 ? 1 : (precision == 0 ? 2 : 3); }
+
+// one operand -> bf16 planes.  natural: [part][B*H][T][HDP]; transposed: [part][B*H][hd][Tp]
+struct PlaneSpec { long elems_per_part; long batch; int row_stride, rows, cols; };
+
+PlaneSpec spec_nat(int B, int H, int T, int HDP) {
+  PlaneSpec p; p.batch = (long)T * HDP; p.elems_per_part = p.batch * B * H; p.row_stride = HDP; p.rows = T; p.cols = HDP;
+  return p;
+}
+PlaneSpec spec_tr(int B, int H, int T, int hd) {
+  const int Tp = (int)up(T, 32);
+  PlaneSpec p; p.batch = (long)hd * Tp; p.elems_per_part = p.batch * B * H; p.row_stride = Tp; p.rows = hd; p.cols = Tp;
+  return p;
+}
+
+// runs the pack kernel for x [B,T,C] (head slices) into `dst` and returns the Planes view + advanced pointer
+Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, int B, int H, int T, int hd, int HDP,
+                    int NP, hipStream_t s) {
+  PackArgs pa;
+  pa.src = x; pa.dst = dst; pa.ld = (long)H * hd;
+  pa.rows = tr ? hd : T; pa.K = tr ? T : hd; pa.Kp = tr ? sp.row_stride : HDP;
+  pa.plane_stride = sp.elems_per_part; pa.batch_stride = sp.batch; pa.nbi = H;
+  pa.so = (long)T * H * hd; pa.si = hd;
+  pa.tap = 0; pa.tapC = 1; pa.tapT = 1; pa.out_rows = T;
+  pa.vec = vilco_aligned(x, 16) && (hd % 4) == 0;
+  dispatch_pack(NP, pa, tr, B * H, s);
+  Planes pl;
+  pl.p = dst; pl.part_stride = sp.elems_per_part; pl.batch_stride = sp.batch;
+  pl.row_stride = sp.row_stride; pl.rows = sp.rows; pl.cols = sp.cols;
+  dst += up(sp.elems_per_part * NP, 128);
+  return pl;
+}
+
+long planes_bytes(const PlaneSpec& sp, int NP) { return up(sp.elems_per_part * NP, 128) * 2; }
+
 }  // namespace
 
-extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 64; }
+extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 64 && (hd % 4) == 0; }
+
+extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
+  const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
+  return (size_t)(planes_bytes(spec_nat(B, H, Tq, HDP), NP) + planes_bytes(spec_nat(B, H, Tk, HDP), NP) +
+                  planes_bytes(spec_tr(B, H, Tk, hd), NP) + 1024);
+}
 
 extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                               const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
-                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, void* stream) {
+                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision);
   if (rc != VILCO_OK) return rc;
   if (!q || !k || !v || !o || !lse) return VILCO_ERR_BADARG;
   if (mode != 2 && !kv_len) return VILCO_ERR_BADARG;
   if (B == 0 || Tq == 0) return VILCO_OK;
   if (Tk == 0) return VILCO_ERR_BADARG;
+  if (!workspace || workspace_bytes < vilco_attn_fwd_workspace(B, H, Tq, Tk, hd, precision)) return VILCO_ERR_WORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.lse = lse; a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  __bf16* w = reinterpret_cast<__bf16*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
+  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s);
+  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s);
+  a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s);
   return hd <= 32 ? dispatch<32>(a, precision, false, s) : dispatch<64>(a, precision, false, s);
 }
 
-extern "C" size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq) {
-  return (size_t)B * H * (Tq > 0 ? Tq : 1) * sizeof(float);
+extern "C" size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
+  const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
+  long bytes = 2 * planes_bytes(spec_nat(B, H, Tq, HDP), NP) + 2 * planes_bytes(spec_tr(B, H, Tq, hd), NP) +
+               2 * planes_bytes(spec_nat(B, H, Tk, HDP), NP) + planes_bytes(spec_tr(B, H, Tk, hd), NP);
+  bytes += up((long)B * H * (Tq > 0 ? Tq : 1) * 4, 256) + 1024;
+  return (size_t)bytes;
 }
 
 extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* bias,
@@ -681,9 +797,12 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   if (mode != 2 && !kv_len) return VILCO_ERR_BADARG;
   if (B == 0 || Tq == 0) return VILCO_OK;
   if (Tk == 0) return VILCO_ERR_BADARG;
-  if (!workspace || workspace_bytes < vilco_attn_bwd_workspace(B, H, Tq)) return VILCO_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < vilco_attn_bwd_workspace(B, H, Tq, Tk, hd, precision)) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  float* delta = reinterpret_cast<float*>(workspace);
+  const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
+  unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
+  float* delta = reinterpret_cast<float*>(wsb);
+  wsb += up((long)B * H * Tq * 4, 256);
   const long rows = (long)B * H * Tq;
   long blocks = (rows + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -692,5 +811,13 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.lse = const_cast<float*>(lse); a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
   a.dout = dout; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
+  __bf16* w = reinterpret_cast<__bf16*>(wsb);
+  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s);
+  a.don = pack_operand(dout, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s);
+  a.qt = pack_operand(q, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s);
+  a.dot = pack_operand(dout, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s);
+  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s);
+  a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s);
+  a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s);
   return hd <= 32 ? dispatch<32>(a, precision, true, s) : dispatch<64>(a, precision, true, s);
 }

@@ -19,9 +19,7 @@
 // Reference arithmetic replaced: see include/vilco_hip.h (vilco_gemm).
 #include <cstdlib>
 #include "common.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+#include "pack.h"
 
 namespace {
 
@@ -31,145 +29,6 @@ constexpr int BN = 128, BK = 32;
 // ({0-3,12-15,20-27}, ...) then touches 16 distinct 16-B slots of the 256-B bank row
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 32 + ((chunk ^ swz(row)) << 3); }
-
-template <int NP>
-__device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3]) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    part[0][e] = h;
-    if (NP >= 2) {
-      const float r1 = v[e] - (float)h;      // exact in fp32
-      const __bf16 m = (__bf16)r1;
-      part[1][e] = m;
-      if (NP >= 3) part[2][e] = (__bf16)(r1 - (float)m);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------ pack
-// "kc" source: element (r,k) at src[r*ld + k];  "tr" source: element (r,k) at src[k*ld + r].
-struct PackArgs {
-  const float* src;
-  __bf16* dst;         // part 0, batch 0
-  long ld;
-  int rows, K, Kp;
-  long plane_stride;   // elements between parts
-  long batch_stride;   // elements between batches inside one part
-  int nbi;             // packed inner batch count
-  long so, si;         // source batch strides
-  // tap modes (k=3 conv):  0 none
-  //  1 (kc, seqpad): rows = B*T source rows of width tapC; output has T+2 rows per sequence (first and last
-  //                  zero) plus zero slack rows; the GEMM reads 3*tapC-wide overlapped spans from it
-  //  2 (kc, expand): output row r = [x[t-1] | x[t] | x[t+1]] explicitly (K = 3*tapC), for tapC % 8 != 0
-  //  3 (tr, taps):   output row (j*tapC + c), column tok = x[tok + j - 1][c], zero across sequence ends
-  int tap, tapC, tapT;
-  int out_rows;        // rows written by the kc kernel
-  int vec;             // 16-byte aligned source rows
-};
-
-template <int NP>
-__global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
-  const int z = blockIdx.z, zo = z / a.nbi, zi = z % a.nbi;
-  const float* src = a.src + zo * a.so + zi * a.si;
-  __bf16* dst = a.dst + (long)z * a.batch_stride;
-  const int width = (a.tap == 1) ? a.tapC : a.Kp;       // elements per output row
-  const int kmax = (a.tap == 1) ? a.tapC : a.K;         // valid source columns
-  const int chunks = width >> 3;
-  const long total = (long)a.out_rows * chunks;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % chunks);
-    const long orow = i / chunks;
-    const int k0 = c * 8;
-    float v[8];
-    long srow = orow;
-    bool row_ok = orow < a.rows;
-    if (a.tap == 1) {
-      const long seq = orow / (a.tapT + 2);
-      const int tt = (int)(orow % (a.tapT + 2)) - 1;
-      srow = seq * a.tapT + tt;
-      row_ok = tt >= 0 && tt < a.tapT && srow < a.rows;
-    }
-    if (a.tap == 2) {
-      const int t = (int)(orow % a.tapT);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = k0 + e;
-        const int j = k / a.tapC, cc = k % a.tapC;
-        const bool ok = row_ok && k < a.K && !((j == 0 && t == 0) || (j == 2 && t == a.tapT - 1));
-        v[e] = ok ? src[(orow + j - 1) * a.ld + cc] : 0.f;
-      }
-    } else if (row_ok && a.vec && k0 + 8 <= kmax) {
-      const float4 v0 = *reinterpret_cast<const float4*>(src + srow * a.ld + k0);
-      const float4 v1 = *reinterpret_cast<const float4*>(src + srow * a.ld + k0 + 4);
-      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (row_ok && k0 + e < kmax) ? src[srow * a.ld + k0 + e] : 0.f;
-    }
-    bf16x8 part[3];
-    splitN<NP>(v, part);
-    const long o = orow * (long)width + k0;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(dst + q * a.plane_stride + o) = part[q];
-  }
-}
-
-// transposing pack: 64(r) x 64(k) tile through LDS.  grid = (ceil(nrows/64), ceil(Kp/64), batch * ntap)
-template <int NP>
-__global__ __launch_bounds__(256) void pack_tr_kernel(PackArgs a) {
-  __shared__ float tile[64][65];
-  const int ntap = (a.tap == 3) ? 3 : 1;
-  const int nrows = (a.tap == 3) ? a.tapC : a.rows;
-  const int z = blockIdx.z / ntap, j = blockIdx.z % ntap;
-  const int zo = z / a.nbi, zi = z % a.nbi;
-  const float* src = a.src + zo * a.so + zi * a.si;
-  __bf16* dst = a.dst + (long)z * a.batch_stride;
-  const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {        // load 64 k-rows x 64 r, float4 along r
-    const int id = tid + it * 256;
-    const int kk = id >> 4, r4 = (id & 15) * 4;
-    const int k = k0 + kk, r = r0 + r4;
-    bool ok = k < a.K;
-    long ksrc = k;
-    if (a.tap == 3) {
-      const int t = k % a.tapT;
-      if ((j == 0 && t == 0) || (j == 2 && t == a.tapT - 1)) ok = false;
-      ksrc = (long)k + j - 1;
-    }
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok && r < nrows) {
-      const float* p = src + ksrc * a.ld + r;
-      if (a.vec && r + 4 <= nrows) v = *reinterpret_cast<const float4*>(p);
-      else {
-        v.x = p[0];
-        if (r + 1 < nrows) v.y = p[1];
-        if (r + 2 < nrows) v.z = p[2];
-        if (r + 3 < nrows) v.w = p[3];
-      }
-    }
-    tile[kk][r4] = v.x; tile[kk][r4 + 1] = v.y; tile[kk][r4 + 2] = v.z; tile[kk][r4 + 3] = v.w;
-  }
-  __syncthreads();
-  const int r = tid & 63;                 // store: thread -> (row r, two 8-k chunks)
-  if (r0 + r < nrows) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int kc = (tid >> 6) + h * 4;
-      if (k0 + kc * 8 >= a.Kp) continue;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = tile[kc * 8 + e][r];
-      bf16x8 part[3];
-      splitN<NP>(v, part);
-      const long o = ((long)j * a.tapC * (a.tap == 3) + r0 + r) * a.Kp + k0 + kc * 8;
-#pragma unroll
-      for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(dst + q * a.plane_stride + o) = part[q];
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------ GEMM on planes
 struct Epi {
@@ -456,28 +315,6 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   }
   p.split_stride = out_span;
   p.part_bytes = p.ksplit > 1 ? align_up(out_span * p.ksplit * 4, 256) : 0;
-}
-
-template <int NP>
-void launch_pack(const PackArgs& a, bool tr, int nbatch, hipStream_t s) {
-  if (!tr) {
-    const int width = (a.tap == 1) ? a.tapC : a.Kp;
-    long blocks = ((long)a.out_rows * (width / 8) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((pack_kc_kernel<NP>), dim3((int)blocks, 1, nbatch), dim3(256), 0, s, a);
-  } else {
-    const int ntap = a.tap == 3 ? 3 : 1;
-    const int nrows = a.tap == 3 ? a.tapC : a.rows;
-    dim3 grid((nrows + 63) / 64, (a.Kp + 63) / 64, nbatch * ntap);
-    hipLaunchKernelGGL((pack_tr_kernel<NP>), grid, dim3(256), 0, s, a);
-  }
-}
-
-void dispatch_pack(int NP, const PackArgs& a, bool tr, int nbatch, hipStream_t s) {
-  if (NP == 1) launch_pack<1>(a, tr, nbatch, s);
-  else if (NP == 2) launch_pack<2>(a, tr, nbatch, s);
-  else launch_pack<3>(a, tr, nbatch, s);
 }
 
 template <int BM, int NP>

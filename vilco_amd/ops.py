@@ -551,8 +551,11 @@ def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode):
     Tk = k.shape[1]
     o = torch.empty_like(q)
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
+    nws = lib.vilco_attn_fwd_workspace(B, H, Tq, Tk, Cn // H, _precision)
+    ws = _ws(nws, q.device)
     _lib.check(lib.vilco_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
-                                  lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, _precision, _stream()))
+                                  lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, _precision, ws.data_ptr(), nws,
+                                  _stream()))
     return o, lse
 
 
@@ -562,7 +565,7 @@ def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias):
     Tk = k.shape[1]
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     dbias = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=q.device) if want_dbias else None
-    nws = lib.vilco_attn_bwd_workspace(B, H, Tq)
+    nws = lib.vilco_attn_bwd_workspace(B, H, Tq, Tk, Cn // H, _precision)
     ws = _ws(nws, q.device)
     _lib.check(lib.vilco_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
                                   lse.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
