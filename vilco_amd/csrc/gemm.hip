@@ -93,8 +93,9 @@ __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
   constexpr int NT = BM * 2;                     // threads
   constexpr int ROWS = BM + BN;                  // staged rows per part (A rows then B rows)
   constexpr int TILE = ROWS * 32;                // bf16 elements per part per stage
-  constexpr int CH = ROWS * 4 * NP / NT;         // 16-byte chunks per thread per stage
-  static_assert((ROWS * 4 * NP) % NT == 0, "chunk split");
+  constexpr int RA = BM * 4 / NT;                // 16-byte chunks per thread per part: A rows (= 2)
+  constexpr int RB = BN * 4 / NT;                //                                     B rows (1 or 2)
+  static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0, "chunk split");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);   // [stage 2][part NP][ROWS][32]
 
@@ -114,20 +115,26 @@ __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
   const __bf16* pa = g.a.p + ((long)(g.a.has_o ? zo : 0) * g.a.nbi + (g.a.has_i ? zi : 0)) * g.a.batch_stride;
   const __bf16* pb = g.b.p + ((long)(g.b.has_o ? zo : 0) * g.b.nbi + (g.b.has_i ? zi : 0)) * g.b.batch_stride;
 
-  const __bf16* gsrc[CH];   // per-thread chunk sources / LDS destinations, fixed over the K loop
-  int ldst[CH];
+  // Everything address-like is fixed over the K loop and kept out of it: per-thread chunk offsets (relative to a
+  // wave-uniform base that advances by BK per step), LDS store offsets, and ONE fragment base per operand
+  // (tile rows are only ever added in multiples of 16, under which the swizzle is invariant).
+  long offA[RA], offB[RB];
+  int ldsA[RA], ldsB[RB];
+  const int crow = tid >> 2, cc = tid & 3;
 #pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int id = tid + i * NT;
-    const int part = id / (ROWS * 4);
-    const int rem = id % (ROWS * 4);
-    const int row = rem >> 2, c = rem & 3;
-    const __bf16* base;
-    if (row < BM) base = pa + part * g.a.plane_stride + row_off(g.a, m0 + row);
-    else          base = pb + part * g.b.plane_stride + row_off(g.b, n0 + row - BM);
-    gsrc[i] = base + c * 8;
-    ldst[i] = part * TILE + lds_off(row, c);
+  for (int r = 0; r < RA; ++r) {
+    const int row = crow + r * (NT / 4);
+    offA[r] = row_off(g.a, m0 + row) + cc * 8;
+    ldsA[r] = lds_off(row, cc);
   }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int row = crow + r * (NT / 4);
+    offB[r] = row_off(g.b, n0 + row) + cc * 8;
+    ldsB[r] = lds_off(BM + row, cc);
+  }
+  const int fbA = lds_off(wm * 64 + (lane & 15), lane >> 4);
+  const int fbB = lds_off(BM + wn * 64 + (lane & 15), lane >> 4);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -140,15 +147,27 @@ __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
   const int nk_all = g.Kp / BK;
   if (kt1 > nk_all) kt1 = nk_all;
 
-  bf16x8 stage[CH];
+  bf16x8 stA[NP][RA], stB[NP][RB];
   auto gload = [&](int kt) {
+    const __bf16* ka = pa + (long)kt * BK;       // wave-uniform bases: scalar arithmetic
+    const __bf16* kb = pb + (long)kt * BK;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) stage[i] = *reinterpret_cast<const bf16x8*>(gsrc[i] + (long)kt * BK);
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int r = 0; r < RA; ++r) stA[q][r] = *reinterpret_cast<const bf16x8*>(ka + q * g.a.plane_stride + offA[r]);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) stB[q][r] = *reinterpret_cast<const bf16x8*>(kb + q * g.b.plane_stride + offB[r]);
+    }
   };
   auto lstore = [&](int st) {
     __bf16* s = smem + st * NP * TILE;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) *reinterpret_cast<bf16x8*>(s + ldst[i]) = stage[i];
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int r = 0; r < RA; ++r) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsA[r]) = stA[q][r];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsB[r]) = stB[q][r];
+    }
   };
 
   if (kt0 < kt1) {
@@ -157,36 +176,44 @@ __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
   }
   __syncthreads();
 
-  const int frow = lane & 15, fchunk = lane >> 4;
   for (int kt = kt0; kt < kt1; ++kt) {
     const int st = (kt - kt0) & 1;
     if (kt + 1 < kt1) gload(kt + 1);
     const __bf16* s = smem + st * NP * TILE;
+    // Part-major order: the part-0 fragments are needed first, so the 16 hi*hi MFMAs can start while the
+    // part-1 / part-2 fragments are still streaming out of LDS (all 8 waves hit the LDS right after the barrier).
     bf16x8 fa[NP][4], fb[NP][4];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + lds_off(wm * 64 + i * 16 + frow, fchunk));
-        fb[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + lds_off(BM + wn * 64 + i * 16 + frow, fchunk));
+        fa[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + fbA + i * 16 * 32);
+        fb[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + fbB + i * 16 * 32);
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 c = acc[i][j];     // smallest terms first
-        if (NP == 3) {
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], c, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+    if (NP >= 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[0][j], acc[i][j], 0, 0, 0);
         }
-        if (NP >= 2) {
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[1][j], c, 0, 0, 0);
+    }
+    if (NP == 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0][j], acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], c, 0, 0, 0);
-      }
+    }
     if (kt + 1 < kt1) lstore(st ^ 1);
     __syncthreads();
   }
