@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=2, help="clips per GPU (mq_vilco.yaml: 2)")
-    ap.add_argument("--precision", default="split3", choices=["split3", "split", "bf16"])
+    ap.add_argument("--precision", default="f16x2", choices=["split3", "split", "bf16", "f16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -203,7 +203,9 @@ def main():
                "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": {"split3": "bf16 MFMA x3-part split, fp32 accumulate (fp32-equivalent)",
-                         "split": "bf16 MFMA x2-part split, fp32 accumulate", "bf16": "bf16"}[args.precision],
+                         "split": "bf16 MFMA x2-part split, fp32 accumulate", "bf16": "bf16",
+                         "f16x2": "fp16 MFMA x2-part split of power-of-two scaled operands (22-bit), fp32 accumulate; "
+                                  "attention on bf16 x3-part split"}[args.precision],
                "data": "synthetic",
                "config": {"workload": "MQ ViLCo backbone config P: T=2304 Cin=2304 D=1024 H=16 arch(2,2,5) XLNet layer "
                                       "(dropout 0) text L=77x768 22 classes, train mode dropout/droppath 0",

@@ -158,7 +158,7 @@ def test_two_part_split_mode_accuracy(dev):
         losses = model(golden_inputs(gold), task_id=gold['task_id'], is_training=True)
         losses['final_loss'].backward()
     finally:
-        ops.set_precision("split3")
+        ops.set_precision(None)
     for k, v in gold['losses'].items():
         assert rel_err(losses[k], v) < 1e-4, k
     errs = sorted(rel_err(p.grad, gold['grads'][k], 1e-6) for k, p in model.named_parameters()

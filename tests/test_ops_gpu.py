@@ -77,7 +77,7 @@ def test_linear_kn(dev):
              lambda x, w, b: x @ w.reshape(64, 96) + b.reshape(96), dict(x=x, w=w, b=b), dev, TOL_GEMM)
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16", 2e-2), ("split", 2e-4), ("split3", 2e-6)])
+@pytest.mark.parametrize("mode,tol", [("bf16", 2e-2), ("split", 2e-4), ("split3", 2e-6), ("f16x2", 4e-6)])
 def test_precision_modes(dev, mode, tol):
     from vilco_amd import ops
     x, w = torch.randn(200, 256), torch.randn(160, 256) / 16
@@ -85,7 +85,29 @@ def test_precision_modes(dev, mode, tol):
     try:
         run_pair(lambda x, w: ops.linear(x, w), lambda x, w: x @ w.t(), dict(x=x, w=w), dev, tol)
     finally:
-        ops.set_precision("split3")
+        ops.set_precision(None)
+
+
+@pytest.mark.parametrize("sx,sw", [(1e-9, 1e6), (3e7, 1e-12), (1.0, 1.0)])
+def test_f16x2_scaling(dev, sx, sw):
+    """The fp16 x2 format rescales every operand by a per-tensor power of two: results must not depend on the
+    operand magnitudes (gradients ~1e-9, fp16 would flush them) and rows far below the tensor max stay accurate."""
+    from vilco_amd import ops
+    torch.manual_seed(5)
+    x, w = torch.randn(300, 200) * sx, torch.randn(96, 200) * sw
+    x[7] *= 1e-4      # a row 2^-13 below the rest
+    x[9] = 0
+    ops.set_precision("f16x2")
+    try:
+        y = ops.linear(x.to(dev), w.to(dev)).cpu().double()
+    finally:
+        ops.set_precision(None)
+    ref = x.double() @ w.double().t()
+    row_scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+    err = ((y - ref).abs() / row_scale)
+    err[9] = (y[9] - ref[9]).abs()
+    assert float(err.max()) < 4e-6, float(err.max())
+    assert float(y[9].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("B,T,Cin,Cout", [(2, 64, 96, 64), (2, 160, 64, 24), (1, 300, 32, 136), (3, 16, 8, 2)])

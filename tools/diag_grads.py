@@ -12,6 +12,8 @@ def report(model, wgrads, tag):
         if w is None or p.grad is None:
             continue
         fro = float((p.grad.double().cpu() - w.double()).norm() / max(float(w.double().norm()), 1e-12))
+        if float(w.abs().max()) < 1e-12:
+            continue
         rows.append((rel_err(p.grad, w, GRAD_FLOOR), k, float(w.abs().max()), fro))
     rows.sort(reverse=True)
     print("==", tag)
@@ -23,7 +25,7 @@ def report(model, wgrads, tag):
 for name in [a for a in sys.argv[1:] if a != "none"]:
     gold = load_golden(name)
     want, wgrads, _ = oracle_run(gold, torch.float64)
-    for prec in ("split",):
+    for prec in os.environ.get("DIAG_PREC", "split3").split(","):
         ops.set_precision(prec)
         model = build_hip_model(gold)
         model.loss_normalizer = golden_cfg(gold)['train_cfg']['init_loss_norm']
@@ -53,7 +55,7 @@ if os.environ.get("DIAG_CFG1"):
     want['final_loss'].backward()
     model = model.to("cuda:0")
     wg = {k: v.grad for k, v in p64.items() if torch.is_tensor(v) and v.is_floating_point()}
-    for prec in ("split", "split3"):
+    for prec in os.environ.get("DIAG_PREC", "split3").split(","):
         ops.set_precision(prec)
         model.zero_grad()
         model.loss_normalizer = cfg['train_cfg']['init_loss_norm']

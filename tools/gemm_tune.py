@@ -17,7 +17,9 @@ dev = torch.device("cuda:0")
 ops.set_precision(sys.argv[1] if len(sys.argv) > 1 else "split3")
 shapes = [("NT", 4608, 1024, 1024), ("NN", 4608, 1024, 1024), ("TN", 1024, 1024, 4608), ("NT", 4608, 4096, 1024),
           ("NT", 4608, 1024, 4096), ("TN", 4096, 1024, 4608), ("NT", 2304, 1024, 1024), ("NT", 1152, 1024, 1024),
-          ("NT", 576, 1024, 1024), ("NT", 154, 1024, 1024), ("NT", 4608, 1024, 3072)]
+          ("NT", 576, 1024, 1024), ("NT", 154, 1024, 1024), ("NT", 4608, 1024, 3072), ("NT", 288, 1024, 3072),
+          ("NT", 144, 1024, 3072), ("TN", 1024, 3072, 1152), ("TN", 1024, 1024, 154), ("TN", 1024, 3072, 4608),
+          ("NN", 4608, 4096, 1024), ("NT", 4608, 2304, 2304), ("TN", 1024, 1024, 288)]
 for form, M, N, K in shapes:
     if form == "NT":
         A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); a_kc, b_kc, lda, ldb = 1, 1, K, K
@@ -38,5 +40,10 @@ for form, M, N, K in shapes:
     t0 = timeit(lambda: ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N))
     res.sort()
     fl = 2.0 * M * N * K
-    print("%s M=%d N=%d K=%d default %.3f ms (%.0f TF) | best: %s" % (form, M, N, K, t0, fl / t0 / 1e9,
-          "  ".join("BM%d ks%d %.3f (%.0f TF)" % (bm, ks, t, fl / t / 1e9) for t, bm, ks in res[:4])))
+    if os.environ.get("TUNE_FULL"):
+        tab = {(bm, ks): t for t, bm, ks in res}
+        print("%s M=%d N=%d K=%d default %.3f | " % (form, M, N, K, t0) + " ".join(
+            "%d/%d:%.3f" % (bm, ks, tab[(bm, ks)]) for bm in (128, 256) for ks in (1, 2, 3, 4, 6, 8)))
+    else:
+        print("%s M=%d N=%d K=%d default %.3f ms (%.0f TF) | best: %s" % (form, M, N, K, t0, fl / t0 / 1e9,
+              "  ".join("BM%d ks%d %.3f (%.0f TF)" % (bm, ks, t, fl / t / 1e9) for t, bm, ks in res[:4])))

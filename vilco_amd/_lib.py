@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvilco_hip.so")
+LIB_PATH = os.environ.get("VILCO_HIP_LIB") or os.path.join(_HERE, "libvilco_hip.so")   # override: tools/lab builds
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 TAP_NONE, TAP_A, TAP_B = 0, 1, 2

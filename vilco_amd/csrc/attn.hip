@@ -704,12 +704,13 @@ int dispatch(const AttnArgs& a, int precision, bool bwd, hipStream_t s) {
 
 int check_common(int B, int H, int Tq, int Tk, int hd, int mode, int precision) {
   if (B < 0 || H <= 0 || Tq < 0 || Tk < 0 || hd <= 0) return VILCO_ERR_BADARG;
-  if (mode < 0 || mode > 2 || precision < 0 || precision > 2) return VILCO_ERR_BADARG;
+  if (mode < 0 || mode > 2 || precision < 0 || precision > 3) return VILCO_ERR_BADARG;
   if (hd > 64 || (hd % 4) != 0) return VILCO_ERR_UNSUPPORTED;      // head dims 4..64 (P: 64, tests: 8, 16, 32)
   return VILCO_OK;
 }
 
 inline long up(long x, long a) { return (x + a - 1) / a * a; }
+// precision 3 (the GEMM's fp16 x2 format) maps to the three bf16 parts here
 inline int np_of(int precision) { return precision == 1 ? 1 : (precision == 0 ? 2 : 3); }
 
 // one operand -> bf16 planes.  natural: [part][B*H][T][HDP]; transposed: [part][B*H][hd][Tp]
@@ -735,6 +736,7 @@ Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, 
   pa.so = (long)T * H * hd; pa.si = hd;
   pa.tap = 0; pa.tapC = 1; pa.tapT = 1; pa.out_rows = T;
   pa.vec = vilco_aligned(x, 16) && (hd % 4) == 0;
+  pa.amax = nullptr; pa.namax = 0; pa.inv_scale = nullptr;   // attention stays on bf16 parts
   dispatch_pack(NP, pa, tr, B * H, s);
   Planes pl;
   pl.p = dst; pl.part_stride = sp.elems_per_part; pl.batch_stride = sp.batch;

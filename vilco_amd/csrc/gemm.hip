@@ -15,7 +15,8 @@
 //      Optional split-K (grid.y) writes fp32 partials that a reduce kernel sums and finishes (used when the
 //      tile count cannot fill 256 CUs: dW problems, pyramid levels with <= 288 tokens, the 77-token text side).
 //
-// precision 0 = NP 2 ("split"), 1 = NP 1 (plain bf16), 2 = NP 3 ("split3": numerically an fp32 GEMM).
+// precision 0 = NP 2 ("split"), 1 = NP 1 (plain bf16), 2 = NP 3 ("split3": numerically an fp32 GEMM),
+// 3 = two fp16 parts of the per-tensor scaled operands ("f16x2": 22 bits, 3 MFMAs; pack.h).
 // Reference arithmetic replaced: see include/vilco_hip.h (vilco_gemm).
 #include <cstdlib>
 #include "common.h"
@@ -24,6 +25,7 @@
 namespace {
 
 constexpr int BN = 128, BK = 32;
+constexpr int EPI_LD = 68;            // floats per staged epilogue row (64 + 4: conflict-free b32 writes / b128 reads)
 
 // rows are 64 B (4 chunks of 16 B); chunk' = chunk ^ f(row>>2), f = {0,3,2,1}: every ds_read_b128 lane group
 // ({0-3,12-15,20-27}, ...) then touches 16 distinct 16-B slots of the 256-B bank row
@@ -66,6 +68,8 @@ struct GArgs {
   int tiles_n, ntiles;
   int ksplit, kchunk;   // kchunk = K-steps per split
   long split_stride;    // elements between split slabs
+  const float* inv_scale;   // fp16 x2 format: {1/sA, 1/sB} left by the pack kernels (null otherwise)
+  int vec_out;              // N, ldc, batch strides multiples of 4 and every epilogue pointer 16-byte aligned
   Epi e;
 };
 
@@ -88,7 +92,35 @@ __device__ __forceinline__ void store_out(const GArgs& g, long idx, int n, float
   g.cfinal[idx] = v;
 }
 
-template <int BM, int NP>
+// 4 consecutive columns of one row (vec_out only)
+__device__ __forceinline__ void store_out4(const GArgs& g, long idx, int n, const f32x4& acc, bool valid) {
+  const Epi& e = g.e;
+  f32x4 v = acc * e.alpha;
+  if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+  if (e.preact) *reinterpret_cast<f32x4*>(e.preact + idx) = v;
+  if (e.act == VILCO_ACT_RELU) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+  } else if (e.act == VILCO_ACT_GELU) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = gelu_f(v[k]);
+  }
+  if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e.colscale) v *= *reinterpret_cast<const f32x4*>(e.colscale + n);
+  if (e.residual && (valid || !e.res_masked)) v += *reinterpret_cast<const f32x4*>(e.residual + idx);
+  if (e.beta != 0.f) v += *reinterpret_cast<const f32x4*>(g.cfinal + idx) * e.beta;
+  *reinterpret_cast<f32x4*>(g.cfinal + idx) = v;
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int BM, int NP, bool F16>
 __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
   constexpr int NT = BM * 2;                     // threads
   constexpr int ROWS = BM + BN;                  // staged rows per part (A rows then B rows)
@@ -194,14 +226,14 @@ __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) acc[i][j] = mma<F16>(fa[0][i], fb[0][j], acc[i][j]);
     if (NP >= 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mma<F16>(fa[0][i], fb[1][j], acc[i][j]);
+          acc[i][j] = mma<F16>(fa[1][i], fb[0][j], acc[i][j]);
         }
     }
     if (NP == 3) {
@@ -209,13 +241,21 @@ __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[2][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2][i], fb[0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mma<F16>(fa[1][i], fb[1][j], acc[i][j]);
+          acc[i][j] = mma<F16>(fa[0][i], fb[2][j], acc[i][j]);
+          acc[i][j] = mma<F16>(fa[2][i], fb[0][j], acc[i][j]);
         }
     }
     if (kt + 1 < kt1) lstore(st ^ 1);
     __syncthreads();
+  }
+
+  if (F16) {   // undo the two per-tensor power-of-two scales (exact)
+    const float inv = g.inv_scale[0] * g.inv_scale[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= inv;
   }
 
   // epilogue.  C/D layout of mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg
@@ -242,6 +282,259 @@ __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ ping-pong kernel
+// Same tiles, planes, LDS image and epilogue as gemm_planes_kernel, different schedule: always 8 waves, split into
+// two groups of four (one wave of each group per SIMD) that run ONE PHASE APART.  A K-step is two phases,
+//   MEM(t):  ds_write the staged registers (tile t+1), re-issue the global loads for tile t+2 into the same registers,
+//            ds_read this wave's fragments of tile t;           MFMA(t):  the wave's MFMAs on those fragments,
+// each closed by a workgroup barrier.  Group 1 executes one extra barrier before its loop (group 0 one after), so while
+// one wave of a SIMD issues its MFMAs back to back the other one does all its LDS / global traffic: the matrix pipe
+// no longer idles through the write -> barrier -> read chain of the one-phase loop (measured there: ~3000 of the
+// ~4800-6000 cycles per K-step).  Hazards: tile t+1 is written in phases 2t (group 0) and 2t+1 (group 1) into the
+// buffer whose last readers (tile t-1) finished in phase 2t-1, and is first read in phase 2t+2.
+#ifdef VILCO_LAB   // tools/lab only: in-kernel cycle stamps of block 0, waves 0 and 4 (never compiled into the product)
+__device__ unsigned long long vilco_lab_stamps[2 * 64 * 8];
+#define STAMP(i)                                                                                              \
+  do {                                                                                                         \
+    if (stamp_on && t < 64) {                                                                                  \
+      const unsigned long long c_ = __builtin_amdgcn_s_memtime();                                              \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+      if (lane == 0) vilco_lab_stamps[((wave >> 2) * 64 + t) * 8 + (i)] = c_;                                  \
+    }                                                                                                          \
+  } while (0)
+#define STAMPX(i)                                                                                             \
+  do {                                                                                                         \
+    if (stamp_on) {                                                                                            \
+      const unsigned long long c_ = __builtin_amdgcn_s_memtime();                                              \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+      if (lane == 0) vilco_lab_stamps[((wave >> 2) * 64 + 63) * 8 + (i)] = c_;                                 \
+    }                                                                                                          \
+  } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#define STAMPX(i) do {} while (0)
+#endif
+
+template <int BM, int NP, bool F16>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
+  constexpr int NT = 512;
+  constexpr int MI = BM / 64;                    // 16-row A fragments per wave (wave tile = 16*MI x 64)
+  constexpr int ROWS = BM + BN;
+  constexpr int TILE = ROWS * 32;
+  constexpr int RA = BM * 4 / NT;                // 16-byte chunks per thread per part: 2 or 1
+  constexpr int RB = BN * 4 / NT;                // 1
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);   // [stage 2][part NP][ROWS][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves; group = wave >> 2
+  const bool late = wave >= 4;
+#ifdef VILCO_LAB
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave & 3) == 0;
+#endif
+  STAMPX(0);
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = g.ntiles, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
+  const int ks = blockIdx.y;
+
+  const __bf16* pa = g.a.p + ((long)(g.a.has_o ? zo : 0) * g.a.nbi + (g.a.has_i ? zi : 0)) * g.a.batch_stride;
+  const __bf16* pb = g.b.p + ((long)(g.b.has_o ? zo : 0) * g.b.nbi + (g.b.has_i ? zi : 0)) * g.b.batch_stride;
+
+  long offA[RA], offB[RB];
+  int ldsA[RA], ldsB[RB];
+  const int crow = tid >> 2, cc = tid & 3;
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    const int row = crow + r * (NT / 4);
+    offA[r] = row_off(g.a, m0 + row) + cc * 8;
+    ldsA[r] = lds_off(row, cc);
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int row = crow + r * (NT / 4);
+    offB[r] = row_off(g.b, n0 + row) + cc * 8;
+    ldsB[r] = lds_off(BM + row, cc);
+  }
+  const int fbA = lds_off(wm * (16 * MI) + (lane & 15), lane >> 4);
+  const int fbB = lds_off(BM + wn * 64 + (lane & 15), lane >> 4);
+
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kt0 = ks * g.kchunk;
+  int kt1 = kt0 + g.kchunk;
+  const int nk_all = g.Kp / BK;
+  if (kt1 > nk_all) kt1 = nk_all;
+  const int nk = kt1 - kt0;
+
+  bf16x8 stA[NP][RA], stB[NP][RB];
+  auto gload = [&](int kt) {
+    const __bf16* ka = pa + (long)kt * BK;
+    const __bf16* kb = pb + (long)kt * BK;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int r = 0; r < RA; ++r) stA[q][r] = *reinterpret_cast<const bf16x8*>(ka + q * g.a.plane_stride + offA[r]);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) stB[q][r] = *reinterpret_cast<const bf16x8*>(kb + q * g.b.plane_stride + offB[r]);
+    }
+  };
+  auto lstore = [&](int st) {
+    __bf16* s = smem + st * NP * TILE;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int r = 0; r < RA; ++r) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsA[r]) = stA[q][r];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsB[r]) = stB[q][r];
+    }
+  };
+
+  if (nk > 0) {
+    gload(kt0);
+    lstore(0);
+    if (nk > 1) gload(kt0 + 1);
+  }
+  __syncthreads();
+  STAMPX(1);
+
+  bf16x8 fa[NP][MI], fb[NP][4];
+  auto mem_phase = [&](int t) {          // stage tile t+1, re-issue tile t+2, fetch this wave's fragments of tile t
+    if (t + 1 < nk) lstore((t + 1) & 1);
+#ifdef VILCO_LAB_FINE
+    STAMP(1);
+#endif
+    if (t + 2 < nk) gload(kt0 + t + 2);
+#ifdef VILCO_LAB_FINE
+    STAMP(2);
+#endif
+    const __bf16* s = smem + (t & 1) * NP * TILE;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + fbA + i * 16 * 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[q][j] = *reinterpret_cast<const bf16x8*>(s + q * TILE + fbB + j * 16 * 32);
+    }
+  };
+  auto mfma_phase = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mma<F16>(fa[0][i], fb[0][j], acc[i][j]);
+    if (NP >= 2) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = mma<F16>(fa[0][i], fb[1][j], acc[i][j]);
+          acc[i][j] = mma<F16>(fa[1][i], fb[0][j], acc[i][j]);
+        }
+    }
+    if (NP == 3) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = mma<F16>(fa[1][i], fb[1][j], acc[i][j]);
+          acc[i][j] = mma<F16>(fa[0][i], fb[2][j], acc[i][j]);
+          acc[i][j] = mma<F16>(fa[2][i], fb[0][j], acc[i][j]);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ONE barrier per K-step.  Group 0 runs [MEM(t) MFMA(t)] between barriers, group 1 [MFMA(t-1) MEM(t)]: the two
+  // waves of a SIMD are always in opposite phases, and the barrier sits exactly where the LDS hazards are
+  // (tile t+1 complete / tile t fully consumed before anyone starts MEM(t+1)).
+  if (!late) {
+    for (int t = 0; t < nk; ++t) {
+      STAMP(0);
+      mem_phase(t);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(3);
+      mfma_phase();
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(5);
+      __syncthreads();
+      STAMP(6);
+    }
+  } else {
+    for (int t = 0; t < nk; ++t) {
+      STAMP(0);
+      if (t > 0) mfma_phase();
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(3);
+      mem_phase(t);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(5);
+      __syncthreads();
+      STAMP(6);
+    }
+    if (nk > 0) mfma_phase();
+  }
+  STAMPX(2);
+
+  if (F16) {
+    const float inv = g.inv_scale[0] * g.inv_scale[1];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= inv;
+  }
+
+  // ---- epilogue through LDS (the pipeline buffers are dead: every fragment read retired before the last barrier):
+  // each wave transposes its 16 x 64 accumulator blocks so that a lane owns 4 consecutive columns of one row and
+  // the stores / residual loads are 16 bytes per lane, 256 contiguous bytes per row, instead of 4-byte scatters
+  // (measured before: 24k of a 112k-cycle block at K = 1024).
+  const long coff = zo * g.sCo + zi * g.sCi;
+  const bool partial = g.ksplit > 1;
+  float* cp = g.c + (partial ? (long)ks * g.split_stride : 0);
+  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (16 * EPI_LD);
+  const int n = n0 + wn * 64 + (lane & 15) * 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) stg[((lane >> 4) * 4 + rr) * EPI_LD + j * 16 + (lane & 15)] = acc[i][j][rr];
+#pragma unroll
+    for (int p4 = 0; p4 < 4; ++p4) {
+      const int row = p4 * 4 + (lane >> 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 15) * 4);
+      const int m = m0 + wm * (16 * MI) + i * 16 + row;
+      if (m >= g.M || n >= g.N) continue;
+      const long idx = coff + (long)m * g.ldc + n;
+      if (partial) {
+        if (g.vec_out) *reinterpret_cast<f32x4*>(cp + idx) = v;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[idx + e] = v[e];
+      } else {
+        const bool valid = g.e.row_len ? (m % g.e.rowT) < g.e.row_len[m / g.e.rowT] : true;
+        if (g.vec_out) store_out4(g, idx, n, v, valid);
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) store_out(g, idx + e, n + e, v[e], valid);
+      }
+    }
+  }
+  STAMPX(3);
+}
+
 // out = epilogue(alpha * sum_s part[s])
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
   const long per = (long)g.M * g.N;
@@ -262,6 +555,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
 
 // ------------------------------------------------------------------------------------------ host side
 inline long align_up(long x, long a) { return (x + a - 1) / a * a; }
+constexpr long SCALE_BYTES = 2 * AMAX_MAX_BLOCKS * 4 + 256;   // fp16 x2 format: amax partials of A and B, then {1/sA, 1/sB}
 
 struct Plan {
   int NP, Kp, BM, ksplit, kchunk;
@@ -276,7 +570,7 @@ struct Plan {
 };
 
 void make_plan(const vilco_gemm_desc* d, Plan& p) {
-  p.NP = d->precision == 1 ? 1 : (d->precision == 0 ? 2 : 3);
+  p.NP = d->precision == 1 ? 1 : ((d->precision == 0 || d->precision == 3) ? 2 : 3);
   p.Kp = (int)align_up(d->K > 0 ? d->K : 1, 32);
   p.a_tr = !d->a_kcontig;
   p.b_tr = !d->b_kcontig;
@@ -344,33 +638,59 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   p.part_bytes = p.ksplit > 1 ? align_up(out_span * p.ksplit * 4, 256) : 0;
 }
 
-template <int BM, int NP>
+template <int BM, int NP, bool F16 = false>
 void launch_gemm(const GArgs& g, dim3 grid, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * NP * (BM + BN) * 32 * sizeof(__bf16);   // up to 144 KiB
   static const bool once = [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_kernel<BM, NP>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_kernel<BM, NP, F16>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL((gemm_planes_kernel<BM, NP>), grid, dim3(BM * 2), lds, s, g);
+  hipLaunchKernelGGL((gemm_planes_kernel<BM, NP, F16>), grid, dim3(BM * 2), lds, s, g);
+}
+
+template <int BM, int NP, bool F16 = false>
+void launch_pp(const GArgs& g, dim3 grid, hipStream_t s) {
+  constexpr size_t pipe = (size_t)2 * NP * (BM + BN) * 32 * sizeof(__bf16), epi = (size_t)8 * 16 * EPI_LD * 4;
+  constexpr size_t lds = pipe > epi ? pipe : epi;
+  static const bool once = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, NP, F16>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    return true;
+  }();
+  (void)once;
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, NP, F16>), grid, dim3(512), lds, s, g);
+}
+
+inline bool use_pp() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VILCO_GEMM_PP"); v = e ? atoi(e) : 1; }
+  return v != 0;
 }
 
 }  // namespace
+
+#ifdef VILCO_LAB
+extern "C" int vilco_lab_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vilco_lab_stamps), sizeof(unsigned long long) * 2 * 64 * 8);
+}
+#endif
 
 extern "C" size_t vilco_gemm_workspace(const vilco_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K < 0) return 512;
   Plan p;
   make_plan(d, p);
-  return (size_t)(p.a_bytes + p.b_bytes + p.part_bytes + 512);
+  return (size_t)(p.a_bytes + p.b_bytes + p.part_bytes + 512 + SCALE_BYTES);
 }
 
 extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return VILCO_ERR_BADARG;
   if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch_outer < 1 || d->batch_inner < 1) return VILCO_ERR_BADARG;
   if (d->M == 0 || d->N == 0) return VILCO_OK;
-  if (d->precision < 0 || d->precision > 2) return VILCO_ERR_BADARG;
+  if (d->precision < 0 || d->precision > 3) return VILCO_ERR_BADARG;
   if (d->act < 0 || d->act > 2) return VILCO_ERR_BADARG;
   if (d->row_len && d->rowT <= 0) return VILCO_ERR_BADARG;
   if (d->a_kcontig == 0 && d->b_kcontig == 1) return VILCO_ERR_UNSUPPORTED;  // "TT" is never needed
@@ -387,14 +707,17 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   }
   Plan p;
   make_plan(d, p);
-  const size_t need = (size_t)(p.a_bytes + p.b_bytes + p.part_bytes + 512);
+  const size_t need = (size_t)(p.a_bytes + p.b_bytes + p.part_bytes + 512 + SCALE_BYTES);
   if (!d->workspace || d->workspace_bytes < need) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
   unsigned char* ws = reinterpret_cast<unsigned char*>(align_up((long)reinterpret_cast<uintptr_t>(d->workspace), 256));
+  float* scales = reinterpret_cast<float*>(ws);            // [A partials | B partials | 1/sA, 1/sB]
+  ws += SCALE_BYTES;
   __bf16* planesA = reinterpret_cast<__bf16*>(ws);
   __bf16* planesB = reinterpret_cast<__bf16*>(ws + p.a_bytes);
   float* parts = reinterpret_cast<float*>(ws + p.a_bytes + p.b_bytes);
+  const bool f16 = d->precision == 3;
 
   // ---- pack A and B into bf16 planes
   PackArgs pa;
@@ -404,7 +727,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   pa.tap = p.a_tap; pa.tapC = d->tapC > 0 ? d->tapC : 1; pa.tapT = d->tapT > 0 ? d->tapT : 1;
   pa.out_rows = p.a_out_rows;
   pa.vec = vilco_aligned(d->A, 16) && (d->lda % 4) == 0 && (d->sAo % 4) == 0 && (d->sAi % 4) == 0;
-  dispatch_pack(p.NP, pa, p.a_tr, p.a_nbo * p.a_nbi, s);
+  pa.amax = f16 ? scales : nullptr; pa.namax = 0; pa.inv_scale = scales + 2 * AMAX_MAX_BLOCKS;
 
   PackArgs pb;
   pb.src = d->B; pb.dst = planesB; pb.ld = d->ldb; pb.rows = d->N; pb.K = d->K; pb.Kp = p.Kp;
@@ -413,6 +736,15 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   pb.tap = p.b_tap; pb.tapC = d->tapC > 0 ? d->tapC : 1; pb.tapT = d->tapT > 0 ? d->tapT : 1;
   pb.out_rows = p.b_out_rows;
   pb.vec = vilco_aligned(d->B, 16) && (d->ldb % 4) == 0 && (d->sBo % 4) == 0 && (d->sBi % 4) == 0;
+  pb.amax = f16 ? scales + AMAX_MAX_BLOCKS : nullptr; pb.namax = 0; pb.inv_scale = scales + 2 * AMAX_MAX_BLOCKS + 1;
+  if (f16) {
+    AmaxArgs am;
+    am.op[0] = amax_view(pa, p.a_tr, p.a_nbo, scales);
+    am.op[1] = amax_view(pb, p.b_tr, p.b_nbo, scales + AMAX_MAX_BLOCKS);
+    pa.namax = am.op[0].nblocks; pb.namax = am.op[1].nblocks;
+    launch_amax(am, s);
+  }
+  dispatch_pack(p.NP, pa, p.a_tr, p.a_nbo * p.a_nbi, s);
   dispatch_pack(p.NP, pb, p.b_tr, p.b_nbo * p.b_nbi, s);
 
   // ---- MFMA kernel
@@ -429,13 +761,31 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   g.tiles_n = (d->N + BN - 1) / BN;
   g.ntiles = g.tiles_n * ((d->M + p.BM - 1) / p.BM);
   g.ksplit = p.ksplit; g.kchunk = p.kchunk; g.split_stride = p.split_stride;
+  g.inv_scale = f16 ? scales + 2 * AMAX_MAX_BLOCKS : nullptr;
+  g.vec_out = (d->N % 4) == 0 && (d->ldc % 4) == 0 && (d->sCo % 4) == 0 && (d->sCi % 4) == 0 && vilco_aligned(d->C, 16) &&
+              vilco_aligned(d->bias, 16) && vilco_aligned(d->preact, 16) && vilco_aligned(d->colscale, 16) &&
+              vilco_aligned(d->residual, 16);
   g.c = p.ksplit > 1 ? parts : d->C;
   g.cfinal = d->C;
   g.e = Epi{d->alpha, d->beta, d->bias, d->preact, d->act, d->row_len, d->rowT, d->colscale, d->residual,
             d->res_masked};
   const int nz = d->batch_outer * d->batch_inner;
   dim3 grid(g.ntiles, p.ksplit, nz);
-  if (p.BM == 256) {
+  if (use_pp()) {
+    if (f16) { if (p.BM == 256) launch_pp<256, 2, true>(g, grid, s); else launch_pp<128, 2, true>(g, grid, s); }
+    else if (p.BM == 256) {
+      if (p.NP == 1) launch_pp<256, 1>(g, grid, s);
+      else if (p.NP == 2) launch_pp<256, 2>(g, grid, s);
+      else launch_pp<256, 3>(g, grid, s);
+    } else {
+      if (p.NP == 1) launch_pp<128, 1>(g, grid, s);
+      else if (p.NP == 2) launch_pp<128, 2>(g, grid, s);
+      else launch_pp<128, 3>(g, grid, s);
+    }
+  } else if (f16) {
+    if (p.BM == 256) launch_gemm<256, 2, true>(g, grid, s);
+    else launch_gemm<128, 2, true>(g, grid, s);
+  } else if (p.BM == 256) {
     if (p.NP == 1) launch_gemm<256, 1>(g, grid, s);
     else if (p.NP == 2) launch_gemm<256, 2>(g, grid, s);
     else launch_gemm<256, 3>(g, grid, s);

@@ -5,12 +5,32 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// fmt 1 ("f16x2"): two fp16 parts of x * s, s a per-tensor power of two that puts max|x| in [2^14, 2^15):
+// x*s = h0 + h1 to 22 bits (h0 = fp16(x*s), h1 = fp16(x*s - h0); absolute floor 2^-25 = 2^-40 of the tensor max),
+// so hi*hi + hi*lo + lo*hi = 3 MFMAs reach 2^-22 -- against 6 MFMAs for the three bf16 parts.  The planes are 16-bit
+// either way and share every layout below; amax_kernel leaves per-block partial maxima in the GEMM workspace and
+// every pack block folds them (<= 4 KB from L2) into the scale: no atomics, no memset, no extra launch.
 
 namespace {
 
 template <int NP>
-__device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3]) {
+__device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3], float f16_scale = 0.f) {
+  if (f16_scale != 0.f) {          // fmt 1: NP == 2 fp16 parts of the scaled value
+    f16x8 h0, h1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = v[e] * f16_scale;   // exact (power of two)
+      const _Float16 h = (_Float16)x;
+      h0[e] = h;
+      h1[e] = (_Float16)(x - (float)h);
+    }
+    part[0] = __builtin_bit_cast(bf16x8, h0);
+    part[1] = __builtin_bit_cast(bf16x8, h1);
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const __bf16 h = (__bf16)v[e];
@@ -22,6 +42,22 @@ __device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3]) {
       if (NP >= 3) part[2][e] = (__bf16)(r1 - (float)m);
     }
   }
+}
+
+// fmt 1 scale from the amax partials: s = 2^(141 - e), e the biased exponent of amax, so amax * s is in [2^14, 2^15)
+__device__ __forceinline__ float f16_scale_from(const float* parts, int nparts, float* out, bool writer) {
+  __shared__ float red_[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, parts[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red_[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red_[0], red_[1]), fmaxf(red_[2], red_[3]));
+  int e = (int)((__float_as_uint(m) >> 23) & 0xff);
+  if (e < 15) e = 15;                                     // tiny / zero tensors: any scale works
+  if (e > 250) e = 250;                                   // inf input: the result is garbage either way
+  if (writer) out[0] = __uint_as_float((unsigned)(e - 14) << 23);       // 1/s for the GEMM epilogue
+  return __uint_as_float((unsigned)(268 - e) << 23);
 }
 
 // ------------------------------------------------------------------------------------------ pack
@@ -43,6 +79,9 @@ struct PackArgs {
   int tap, tapC, tapT;
   int out_rows;        // rows written by the kc kernel
   int vec;             // 16-byte aligned source rows
+  const float* amax;   // fmt 1: per-block partial maxima of |src| from amax_kernel (null = bf16 parts)
+  int namax;
+  float* inv_scale;    // fmt 1: where block 0 leaves 1/s for the GEMM kernel
 };
 
 template <int NP>
@@ -54,6 +93,7 @@ __global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
   const int kmax = (a.tap == 1) ? a.tapC : a.K;         // valid source columns
   const int chunks = width >> 3;
   const long total = (long)a.out_rows * chunks;
+  const float fs = a.amax ? f16_scale_from(a.amax, a.namax, a.inv_scale, blockIdx.x == 0 && z == 0 && threadIdx.x == 0) : 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % chunks);
     const long orow = i / chunks;
@@ -85,7 +125,7 @@ __global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
       for (int e = 0; e < 8; ++e) v[e] = (row_ok && k0 + e < kmax) ? src[srow * a.ld + k0 + e] : 0.f;
     }
     bf16x8 part[3];
-    splitN<NP>(v, part);
+    splitN<NP>(v, part, fs);
     const long o = orow * (long)width + k0;
 #pragma unroll
     for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(dst + q * a.plane_stride + o) = part[q];
@@ -104,6 +144,7 @@ __global__ __launch_bounds__(256) void pack_tr_kernel(PackArgs a) {
   __bf16* dst = a.dst + (long)z * a.batch_stride;
   const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
+  const float fs = a.amax ? f16_scale_from(a.amax, a.namax, a.inv_scale, (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) : 0.f;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {        // load 64 k-rows x 64 r, float4 along r
     const int id = tid + it * 256;
@@ -140,12 +181,77 @@ __global__ __launch_bounds__(256) void pack_tr_kernel(PackArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = tile[kc * 8 + e][r];
       bf16x8 part[3];
-      splitN<NP>(v, part);
+      splitN<NP>(v, part, fs);
       const long o = ((long)j * a.tapC * (a.tap == 3) + r0 + r) * a.Kp + k0 + kc * 8;
 #pragma unroll
       for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(dst + q * a.plane_stride + o) = part[q];
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------ amax (fmt 1)
+// Every pack source is a strided matrix [R][W] (W contiguous) per batch; up to two operands per launch
+// (blockIdx.y); block b leaves max|x| over its rows in parts[b].
+constexpr int AMAX_MAX_BLOCKS = 1024;
+
+struct AmaxOp {
+  const float* src;
+  long ld, so, si;
+  int R, W, nbo, nbi, vec;
+  int tw;              // threads per row (power of two <= 256)
+  int nblocks;
+  float* parts;        // nblocks partial maxima
+};
+struct AmaxArgs { AmaxOp op[2]; };
+
+__global__ __launch_bounds__(256) void amax_kernel(AmaxArgs args) {
+  const AmaxOp& o = args.op[blockIdx.y];
+  if ((int)blockIdx.x >= o.nblocks) return;
+  __shared__ float red[4];
+  float m = 0.f;
+  // rows are dealt to blocks; inside a block `tw` threads (a power of two) walk one row, 256/tw rows at a time:
+  // no per-element division
+  const int total_rows = o.nbo * o.nbi * o.R;
+  const int sub = threadIdx.x / o.tw, col = threadIdx.x & (o.tw - 1), rpi = 256 / o.tw;
+  const bool vec = o.vec && (o.W & 3) == 0;
+  const int wq = vec ? (o.W >> 2) : o.W;
+  for (int row = blockIdx.x * rpi + sub; row < total_rows; row += o.nblocks * rpi) {
+    const int z = row / o.R, r = row - z * o.R;
+    const float* p = o.src + (long)(z / o.nbi) * o.so + (long)(z % o.nbi) * o.si + (long)r * o.ld;
+    if (vec) {
+      for (int c = col; c < wq; c += o.tw) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    } else {
+      for (int c = col; c < wq; c += o.tw) m = fmaxf(m, fabsf(p[c]));
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) o.parts[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// the [R][W] view of a pack source
+inline AmaxOp amax_view(const PackArgs& a, bool tr, int nbo, float* parts) {
+  AmaxOp o;
+  o.src = a.src; o.ld = a.ld; o.so = a.so; o.si = a.si; o.nbo = nbo; o.nbi = a.nbi; o.vec = a.vec; o.parts = parts;
+  const bool tapped = a.tap != 0;
+  if (!tr) { o.R = a.rows; o.W = tapped ? a.tapC : a.K; }
+  else { o.R = a.K; o.W = tapped ? a.tapC : a.rows; }
+  const int wq = (o.vec && (o.W & 3) == 0) ? o.W >> 2 : o.W;
+  o.tw = 1;
+  while (o.tw < 256 && o.tw < wq) o.tw <<= 1;
+  const long elems = (long)o.R * o.W * nbo * a.nbi;
+  long nb = (elems + 8191) / 8192;                        // ~8 float4 per thread
+  o.nblocks = (int)(nb < 1 ? 1 : (nb > AMAX_MAX_BLOCKS ? AMAX_MAX_BLOCKS : nb));
+  return o;
+}
+
+inline void launch_amax(AmaxArgs& am, hipStream_t s) {
+  const int gx = am.op[0].nblocks > am.op[1].nblocks ? am.op[0].nblocks : am.op[1].nblocks;
+  hipLaunchKernelGGL(amax_kernel, dim3(gx, 2), dim3(256), 0, s, am);
 }
 
 template <int NP>

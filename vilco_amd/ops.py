@@ -8,21 +8,27 @@ There is deliberately no CPU / ATen fallback: a non-CUDA tensor raises.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
 from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, TAP_A, TAP_B, TAP_NONE, GemmDesc
 
-# 0 = split-bf16 (hi+lo, 3 MFMAs), 1 = single bf16 pass, 2 = three-part split (6 MFMAs, fp32-equivalent)
-_precision = 2
+# 0 = split-bf16 (hi+lo, 3 MFMAs), 1 = single bf16 pass, 2 = three-part bf16 split (6 MFMAs, ~2^-25),
+# 3 = two fp16 parts of per-tensor scaled operands (3 MFMAs, ~2^-22; attention keeps the three bf16 parts)
+_PRECISIONS = {"split": 0, 0: 0, "bf16": 1, 1: 1, "split3": 2, "fp32": 2, 2: 2, "f16x2": 3, 3: 3}
+DEFAULT_PRECISION = _PRECISIONS[os.environ.get("VILCO_PRECISION", "f16x2")]
+_precision = DEFAULT_PRECISION
 
 
-def set_precision(p):
+def set_precision(p=None):
     """'split' / 0: two-part split-bf16 MFMA (~2^-17);  'bf16' / 1: single bf16 pass;
-    'split3' / 'fp32' / 2: three-part split, numerically an fp32 GEMM (~2^-25)."""
+    'split3' / 'fp32' / 2: three-part bf16 split, numerically an fp32 GEMM (~2^-25);
+    'f16x2' / 3: two fp16 parts of power-of-two scaled operands (~2^-22, half the MFMAs of split3).
+    None restores the default (env VILCO_PRECISION, else f16x2)."""
     global _precision
-    _precision = {"split": 0, 0: 0, "bf16": 1, 1: 1, "split3": 2, "fp32": 2, 2: 2}[p]
+    _precision = DEFAULT_PRECISION if p is None else _PRECISIONS[p]
 
 
 def get_precision():
