@@ -26,6 +26,7 @@
 #include "pack.h"
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 namespace {
 
@@ -69,6 +70,25 @@ __device__ __forceinline__ void split4(const float (&v)[4], bf16x4 (&part)[3]) {
       if (NP >= 3) part[2][e] = (__bf16)(r1 - (float)m);
     }
   }
+}
+
+// fp16 x2 parts of values the caller has already scaled into fp16 range (pack.h fmt 1)
+__device__ __forceinline__ void split4h(const float (&v)[4], bf16x4 (&part)[3]) {
+  f16x4 h0, h1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 h = (_Float16)v[e];
+    h0[e] = h;
+    h1[e] = (_Float16)(v[e] - (float)h);
+  }
+  part[0] = __builtin_bit_cast(bf16x4, h0);
+  part[1] = __builtin_bit_cast(bf16x4, h1);
+}
+
+template <int NP, bool F16>
+__device__ __forceinline__ void split4s(const float (&v)[4], bf16x4 (&part)[3]) {
+  if constexpr (F16) split4h(v, part);
+  else split4<NP>(v, part);
 }
 
 // ---- operand planes (built by pack.h): part q of batch z starts at p + q*part_stride + z*batch_stride
@@ -128,19 +148,33 @@ __device__ __forceinline__ bf16x8 frag(const __bf16* tile, int fb, int row_add, 
 }
 
 // acc += sum over part pairs of A_parts x B_parts (smallest terms first)
-template <int NP>
+template <int NP, bool F16>
 __device__ __forceinline__ f32x4 mfma_parts(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
-  if (NP == 3) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+  if constexpr (F16) {
+    const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
+    const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);
+  } else {
+    if (NP == 3) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+    }
+    if (NP >= 2) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
   }
-  if (NP >= 2) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
-  }
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
 }
+
+// fp16 x2 mode: q/k/v/dO planes hold x * s (per-tensor power of two, pack.h); products computed in-kernel are brought
+// into fp16 range by fixed powers of two: P <= 1 is stored as P * 2^15, and dS = P (dP - delta) as dS * 2^-22 sdO sV,
+// which is < 2^15 because |dP|, |delta| <= hd * amax(dO) * amax(V) with hd <= 64 and amax * s < 2^15.
+constexpr float P_SCALE = 32768.f, P_INV = 1.f / 32768.f, DS_SCALE = 1.f / 4194304.f, DS_INV = 4194304.f;
+struct AttnScales { float iq, sq, ik, sk, iv, sv, ido, sdo; };    // {1/s, s} of q, k, v, dO (pack.h order)
 
 struct AttnArgs {
   const float* q; const float* k; const float* v; const float* bias;
@@ -152,8 +186,9 @@ struct AttnArgs {
   // backward
   const float* dout; const float* delta;
   float* dq; float* dk; float* dv; float* dbias;
-  // bf16 planes (natural [tok][HDP] and transposed [d][Tp]) of k, v, q, dout
+  // 16-bit planes (natural [tok][HDP] and transposed [d][Tp]) of k, v, q, dout
   Planes kn, vn, kt, vt, qn, don, qt, dot;
+  const AttnScales* sc;   // fp16 x2 mode only
 };
 
 // registers holding the B-operand fragments of this wave's 16 query rows (all k-steps, all parts)
@@ -188,7 +223,7 @@ __device__ __forceinline__ float mask_score(float s, int i, int j, int len, int 
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int HDP, int NP>
+template <int HDP, int NP, bool F16>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   constexpr int BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -208,6 +243,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   const __bf16* vbase = a.vt.p + (long)bh * a.vt.batch_stride;
   const int fbH = toff<HDP>(lane & 15, lane >> 4);        // fragment bases (see frag())
   const int fb64 = toff<64>(lane & 15, lane >> 4);
+  AttnScales sc = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  if (F16) sc = *a.sc;
+  const float qk_scale = F16 ? a.scale * sc.iq * sc.ik : a.scale;     // S = acc / (sq sk)
 
   QFrag<HDP, NP> qf;
   load_qfrag<HDP, NP>(qf, a.qn, a.qn.p + (long)bh * a.qn.batch_stride, q0, lane);
@@ -250,7 +288,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         bf16x8 ka[3];
 #pragma unroll
         for (int q = 0; q < NP; ++q) ka[q] = frag<HDP>(sK + q * BKV * HDP, fbH, mi * 16, ks);
-        c = mfma_parts<NP>(ka, qf.f[ks], c);
+        c = mfma_parts<NP, F16>(ka, qf.f[ks], c);
       }
       s[mi] = c;
     }
@@ -262,7 +300,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
       const int jb = k0 + mi * 16 + (lane >> 4) * 4;
       if (plain) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s[mi][r] *= a.scale; tmax = fmaxf(tmax, s[mi][r]); }
+        for (int r = 0; r < 4; ++r) { s[mi][r] *= qk_scale; tmax = fmaxf(tmax, s[mi][r]); }
       } else {
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (bias && qi < a.Tq) {
@@ -271,7 +309,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float x = mask_score(s[mi][r] * a.scale + bv[r], qi, jb + r, len, a.Tk, a.mode);
+          const float x = mask_score(s[mi][r] * qk_scale + bv[r], qi, jb + r, len, a.Tk, a.mode);
           s[mi][r] = x;
           tmax = fmaxf(tmax, x);
         }
@@ -290,9 +328,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         p[r] = dead ? 0.f : fast_exp(s[mi][r] - m_new);
         psum += p[r];
+        if (F16) p[r] *= P_SCALE;
       }
       bf16x4 pp[3];
-      split4<NP>(p, pp);
+      split4s<NP, F16>(p, pp);
       // P[q][keys mi*16 + 4*(lane>>4) .. +3]: chunk = 2*mi + (lane>>5), half = (lane>>4)&1
       const int off = toff<BKV>(lane & 15, 2 * mi + (lane >> 5)) + ((lane >> 4) & 1) * 4;
 #pragma unroll
@@ -319,14 +358,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         bf16x8 va[3];
 #pragma unroll
         for (int q = 0; q < NP; ++q) va[q] = frag<BKV>(sVt + q * HDP * BKV, fb64, di * 16, ks);
-        oacc[di] = mfma_parts<NP>(va, pb, oacc[di]);
+        oacc[di] = mfma_parts<NP, F16>(va, pb, oacc[di]);
       }
     }
   }
 
   // finish: lane holds query qi, channels di*16 + 4*(lane>>4) + r
   if (qi < a.Tq) {
-    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    const float inv = (l_run > 0.f ? 1.f / l_run : 0.f) * (F16 ? P_INV * sc.iv : 1.f);
     float* og = a.o + ((long)b * a.Tq + qi) * ld + h * a.hd;
 #pragma unroll
     for (int di = 0; di < HDP / 16; ++di) {
@@ -359,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dBias)
-template <int HDP, int NP>
+template <int HDP, int NP, bool F16>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -383,12 +422,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   const __bf16* ktb = a.kt.p + (long)bh * a.kt.batch_stride;
   const int fbH = toff<HDP>(lane & 15, lane >> 4);
   const int fb64 = toff<64>(lane & 15, lane >> 4);
+  AttnScales sc = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  if (F16) sc = *a.sc;
+  const float qk_scale = F16 ? a.scale * sc.iq * sc.ik : a.scale;
+  // fp16 x2: dp stays in plane units (dP * sdO * sV), delta is brought there, and dS' = P (dp - delta') * 2^-22
+  const float dl_scale = F16 ? sc.sdo * sc.sv : 1.f;
+  const float ds_unscale = F16 ? DS_INV * sc.ido * sc.iv : 1.f;       // dS = dS' * this
 
   QFrag<HDP, NP> qf, dof;
   load_qfrag<HDP, NP>(qf, a.qn, a.qn.p + (long)bh * a.qn.batch_stride, q0, lane);
   load_qfrag<HDP, NP>(dof, a.don, a.don.p + (long)bh * a.don.batch_stride, q0, lane);
   const float lse = qi < a.Tq ? a.lse[row_bh + qi] : 0.f;
-  const float dlt = qi < a.Tq ? a.delta[row_bh + qi] : 0.f;
+  const float dlt = (qi < a.Tq ? a.delta[row_bh + qi] : 0.f) * dl_scale;
 
   f32x4 dqacc[HDP / 16];
 #pragma unroll
@@ -432,14 +477,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
           ka[q] = frag<HDP>(sK + q * BKV * HDP, fbH, mi * 16, ks);
           va[q] = frag<HDP>(sV + q * BKV * HDP, fbH, mi * 16, ks);
         }
-        s = mfma_parts<NP>(ka, qf.f[ks], s);       // S^T  = K Q^T
-        dp = mfma_parts<NP>(va, dof.f[ks], dp);    // dP^T = V dO^T
+        s = mfma_parts<NP, F16>(ka, qf.f[ks], s);       // S^T  = K Q^T
+        dp = mfma_parts<NP, F16>(va, dof.f[ks], dp);    // dP^T = V dO^T
       }
       const int jb = k0 + mi * 16 + (lane >> 4) * 4;
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = s[r] * a.scale;
+        float x = s[r] * qk_scale;
         if (!plain) {
           float bv = 0.f;
           if (bias && qi < a.Tq && jb + r < a.Tk) bv = bias[(long)qi * a.Tk + jb + r];
@@ -447,13 +492,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
         }
         const float p = (x == -INFINITY) ? 0.f : fast_exp(x - lse);
         ds[r] = p * (dp[r] - dlt);
+        if (F16) ds[r] *= DS_SCALE;
       }
       if (dbias && qi < a.Tq) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (jb + r < a.Tk) dbias[(long)qi * a.Tk + jb + r] = ds[r];
+        for (int r = 0; r < 4; ++r) if (jb + r < a.Tk) dbias[(long)qi * a.Tk + jb + r] = ds[r] * ds_unscale;
       }
       bf16x4 pp[3];
-      split4<NP>(ds, pp);
+      split4s<NP, F16>(ds, pp);
       const int off = toff<BKV>(lane & 15, 2 * mi + (lane >> 5)) + ((lane >> 4) & 1) * 4;
 #pragma unroll
       for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4*>(myS + q * 16 * BKV + off) = pp[q];
@@ -471,7 +517,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
         bf16x8 ka[3];
 #pragma unroll
         for (int q = 0; q < NP; ++q) ka[q] = frag<BKV>(sKt + q * HDP * BKV, fb64, di * 16, ks);
-        dqacc[di] = mfma_parts<NP>(ka, sb, dqacc[di]);
+        dqacc[di] = mfma_parts<NP, F16>(ka, sb, dqacc[di]);
       }
     }
   }
@@ -485,7 +531,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int di = 0; di < HDP / 16; ++di) {
       const int d = di * 16 + (lane >> 4) * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (d + r < a.hd) g[d + r] = dqacc[di][r] * a.scale;
+      for (int r = 0; r < 4; ++r) if (d + r < a.hd) g[d + r] = dqacc[di][r] * (a.scale * ds_unscale * sc.ik);
     }
   }
 }
@@ -493,7 +539,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // one workgroup per (b, h, 64-key tile); inner loop over 32-query tiles.  S = Q K^T orientation: the C layout
 // gives each lane one key (col) and 4 consecutive queries (rows), so P^T / dS^T go to LDS as packed stores.
-template <int HDP, int NP>
+template <int HDP, int NP, bool F16>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) {
   constexpr int BKV = 64, BQ = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -520,6 +566,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
   const __bf16* dotb = a.dot.p + (long)bh * a.dot.batch_stride;
   const int fbH = toff<HDP>(lane & 15, lane >> 4);
   const int fb32 = toff<32>(lane & 15, lane >> 4);
+  AttnScales sc = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  if (F16) sc = *a.sc;
+  const float qk_scale = F16 ? a.scale * sc.iq * sc.ik : a.scale;
+  const float dl_scale = F16 ? sc.sdo * sc.sv : 1.f;
+  const float ds_unscale = F16 ? DS_INV * sc.ido * sc.iv : 1.f;
 
   {
     TileStage<HDP, BKV, NP> st;
@@ -569,7 +620,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
     for (int r = 0; r < 4; ++r) {
       const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r;
       lse4[r] = qi < a.Tq ? a.lse[row_bh + qi] : 0.f;
-      dl4[r] = qi < a.Tq ? a.delta[row_bh + qi] : 0.f;
+      dl4[r] = (qi < a.Tq ? a.delta[row_bh + qi] : 0.f) * dl_scale;
     }
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
@@ -585,15 +636,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
           kb[q] = frag<HDP>(sK + q * BKV * HDP, fbH, ncol, ks);
           vb[q] = frag<HDP>(sV + q * BKV * HDP, fbH, ncol, ks);
         }
-        s = mfma_parts<NP>(qa, kb, s);        // S  = Q K^T
-        dp = mfma_parts<NP>(da, vb, dp);      // dP = dO V^T
+        s = mfma_parts<NP, F16>(qa, kb, s);        // S  = Q K^T
+        dp = mfma_parts<NP, F16>(da, vb, dp);      // dP = dO V^T
       }
       const int j = k0 + ncol + (lane & 15);
       float p[4], ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r;
-        float x = s[r] * a.scale;
+        float x = s[r] * qk_scale;
         if (!plain) {
           float bv = 0.f;
           if (bias && qi < a.Tq && j < a.Tk) bv = bias[(long)qi * a.Tk + j];
@@ -601,10 +652,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
         }
         p[r] = (qi < a.Tq && x != -INFINITY) ? fast_exp(x - lse4[r]) : 0.f;
         ds[r] = p[r] * (dp[r] - dl4[r]);
+        if (F16) { ds[r] *= DS_SCALE; p[r] *= P_SCALE; }
       }
       bf16x4 pp[3], dd[3];
-      split4<NP>(p, pp);
-      split4<NP>(ds, dd);
+      split4s<NP, F16>(p, pp);
+      split4s<NP, F16>(ds, dd);
       // P^T[key][q .. q+3]: row = ncol + (lane&15), 4 queries at mq*16 + 4*(lane>>4): chunk = mq*2 + (lane>>5)
       const int off = toff<BQ>(ncol + (lane & 15), mq * 2 + (lane >> 5)) + ((lane >> 4) & 1) * 4;
 #pragma unroll
@@ -630,8 +682,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
         oa[q] = frag<BQ>(sdOt + q * HDP * BQ, fb32, di * 16, 0);
         qa[q] = frag<BQ>(sQt + q * HDP * BQ, fb32, di * 16, 0);
       }
-      dvacc[di] = mfma_parts<NP>(oa, pb, dvacc[di]);
-      dkacc[di] = mfma_parts<NP>(qa, sb, dkacc[di]);
+      dvacc[di] = mfma_parts<NP, F16>(oa, pb, dvacc[di]);
+      dkacc[di] = mfma_parts<NP, F16>(qa, sb, dkacc[di]);
     }
   }
 
@@ -646,8 +698,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (d + r < a.hd) {
-          gk[d + r] = dkacc[di][r] * a.scale;
-          gv[d + r] = dvacc[di][r];
+          gk[d + r] = dkacc[di][r] * (a.scale * ds_unscale * sc.iq);
+          gv[d + r] = dvacc[di][r] * (F16 ? P_INV * sc.ido : 1.f);
         }
       }
     }
@@ -667,31 +719,31 @@ void set_lds(K kernel, size_t bytes) {
   (void)hipGetLastError();
 }
 
-template <int HDP, int NP>
+template <int HDP, int NP, bool F16 = false>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
   static const bool once = [] {
-    set_lds(&attn_fwd_kernel<HDP, NP>, fwd_lds<HDP, NP>());
+    set_lds(&attn_fwd_kernel<HDP, NP, F16>, fwd_lds<HDP, NP>());
     return true;
   }();
   (void)once;
   dim3 grid((a.Tq + 63) / 64, a.H, a.B);
   const size_t lds = fwd_lds<HDP, NP>();
-  hipLaunchKernelGGL((attn_fwd_kernel<HDP, NP>), grid, dim3(ATT_THREADS), lds, s, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<HDP, NP, F16>), grid, dim3(ATT_THREADS), lds, s, a);
   return vilco_launch_status();
 }
 
-template <int HDP, int NP>
+template <int HDP, int NP, bool F16 = false>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
   static const bool once = [] {
-    set_lds(&attn_bwd_dq_kernel<HDP, NP>, dq_lds<HDP, NP>());
-    set_lds(&attn_bwd_dkdv_kernel<HDP, NP>, dkdv_lds<HDP, NP>());
+    set_lds(&attn_bwd_dq_kernel<HDP, NP, F16>, dq_lds<HDP, NP>());
+    set_lds(&attn_bwd_dkdv_kernel<HDP, NP, F16>, dkdv_lds<HDP, NP>());
     return true;
   }();
   (void)once;
   dim3 gq((a.Tq + 63) / 64, a.H, a.B), gk((a.Tk + 63) / 64, a.H, a.B);
   const size_t lq = dq_lds<HDP, NP>(), lk = dkdv_lds<HDP, NP>();
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP>), gq, dim3(ATT_THREADS), lq, s, a);
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NP>), gk, dim3(ATT_THREADS), lk, s, a);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16>), gq, dim3(ATT_THREADS), lq, s, a);
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NP, F16>), gk, dim3(ATT_THREADS), lk, s, a);
   return vilco_launch_status();
 }
 
@@ -699,6 +751,7 @@ template <int HDP>
 int dispatch(const AttnArgs& a, int precision, bool bwd, hipStream_t s) {
   if (precision == 1) return bwd ? launch_bwd<HDP, 1>(a, s) : launch_fwd<HDP, 1>(a, s);
   if (precision == 0) return bwd ? launch_bwd<HDP, 2>(a, s) : launch_fwd<HDP, 2>(a, s);
+  if (precision == 3) return bwd ? launch_bwd<HDP, 2, true>(a, s) : launch_fwd<HDP, 2, true>(a, s);
   return bwd ? launch_bwd<HDP, 3>(a, s) : launch_fwd<HDP, 3>(a, s);
 }
 
@@ -710,8 +763,8 @@ int check_common(int B, int H, int Tq, int Tk, int hd, int mode, int precision) 
 }
 
 inline long up(long x, long a) { return (x + a - 1) / a * a; }
-// precision 3 (the GEMM's fp16 x2 format) maps to the three bf16 parts here
-inline int np_of(int precision) { return precision == 1 ? 1 : (precision == 0 ? 2 : 3); }
+inline int np_of(int precision) { return precision == 1 ? 1 : ((precision == 0 || precision == 3) ? 2 : 3); }
+constexpr long ATT_SCALE_BYTES = 4 * AMAX_MAX_BLOCKS * 4 + 256;    // fp16 x2: amax partials of q, k, v, dO + AttnScales
 
 // one operand -> bf16 planes.  natural: [part][B*H][T][HDP]; transposed: [part][B*H][hd][Tp]
 struct PlaneSpec { long elems_per_part; long batch; int row_stride, rows, cols; };
@@ -728,7 +781,7 @@ PlaneSpec spec_tr(int B, int H, int T, int hd) {
 
 // runs the pack kernel for x [B,T,C] (head slices) into `dst` and returns the Planes view + advanced pointer
 Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, int B, int H, int T, int hd, int HDP,
-                    int NP, hipStream_t s) {
+                    int NP, hipStream_t s, const float* amax = nullptr, int namax = 0, float* inv_scale = nullptr) {
   PackArgs pa;
   pa.src = x; pa.dst = dst; pa.ld = (long)H * hd;
   pa.rows = tr ? hd : T; pa.K = tr ? T : hd; pa.Kp = tr ? sp.row_stride : HDP;
@@ -736,7 +789,7 @@ Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, 
   pa.so = (long)T * H * hd; pa.si = hd;
   pa.tap = 0; pa.tapC = 1; pa.tapT = 1; pa.out_rows = T;
   pa.vec = vilco_aligned(x, 16) && (hd % 4) == 0;
-  pa.amax = nullptr; pa.namax = 0; pa.inv_scale = nullptr;   // attention stays on bf16 parts
+  pa.amax = amax; pa.namax = namax; pa.inv_scale = inv_scale;
   dispatch_pack(NP, pa, tr, B * H, s);
   Planes pl;
   pl.p = dst; pl.part_stride = sp.elems_per_part; pl.batch_stride = sp.batch;
@@ -747,6 +800,25 @@ Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, 
 
 long planes_bytes(const PlaneSpec& sp, int NP) { return up(sp.elems_per_part * NP, 128) * 2; }
 
+// fp16 x2: one amax launch over the [B*T][C] operands (q, k, v[, dO]); returns the partial counts
+struct ScaleWs { float* parts[4]; int n[4]; float* out; };
+ScaleWs run_amax(unsigned char* region, const float* const (&x)[4], const int (&T)[4], int nops, int B, int C, hipStream_t s) {
+  ScaleWs w;
+  float* f = reinterpret_cast<float*>(region);
+  w.out = f + 4 * AMAX_MAX_BLOCKS;
+  AmaxArgs am;
+  for (int i = 0; i < nops; ++i) {
+    PackArgs pa = {};
+    pa.src = x[i]; pa.ld = C; pa.rows = B * T[i]; pa.K = C; pa.nbi = 1; pa.so = 0; pa.si = 0; pa.tap = 0;
+    pa.vec = vilco_aligned(x[i], 16) && (C % 4) == 0;
+    w.parts[i] = f + i * AMAX_MAX_BLOCKS;
+    am.op[i] = amax_view(pa, false, 1, w.parts[i]);
+    w.n[i] = am.op[i].nblocks;
+  }
+  launch_amax(am, nops, s);
+  return w;
+}
+
 }  // namespace
 
 extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 64 && (hd % 4) == 0; }
@@ -754,7 +826,7 @@ extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 64 && (
 extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
   const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
   return (size_t)(planes_bytes(spec_nat(B, H, Tq, HDP), NP) + planes_bytes(spec_nat(B, H, Tk, HDP), NP) +
-                  planes_bytes(spec_tr(B, H, Tk, hd), NP) + 1024);
+                  planes_bytes(spec_tr(B, H, Tk, hd), NP) + 1024 + ATT_SCALE_BYTES);
 }
 
 extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
@@ -773,10 +845,19 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.lse = lse; a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
-  __bf16* w = reinterpret_cast<__bf16*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
-  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s);
-  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s);
-  a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s);
+  unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
+  ScaleWs sw = {};
+  if (precision == 3) {
+    const float* const xs[4] = {q, k, v, nullptr};
+    const int Ts[4] = {Tq, Tk, Tk, 0};
+    sw = run_amax(wsb, xs, Ts, 3, B, H * hd, s);
+    a.sc = reinterpret_cast<const AttnScales*>(sw.out);
+  }
+  float* so = sw.out;
+  __bf16* w = reinterpret_cast<__bf16*>(wsb + ATT_SCALE_BYTES);
+  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so);
+  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2);
+  a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4);
   return hd <= 32 ? dispatch<32>(a, precision, false, s) : dispatch<64>(a, precision, false, s);
 }
 
@@ -784,7 +865,7 @@ extern "C" size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int
   const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
   long bytes = 2 * planes_bytes(spec_nat(B, H, Tq, HDP), NP) + 2 * planes_bytes(spec_tr(B, H, Tq, hd), NP) +
                2 * planes_bytes(spec_nat(B, H, Tk, HDP), NP) + planes_bytes(spec_tr(B, H, Tk, hd), NP);
-  bytes += up((long)B * H * (Tq > 0 ? Tq : 1) * 4, 256) + 1024;
+  bytes += up((long)B * H * (Tq > 0 ? Tq : 1) * 4, 256) + 1024 + ATT_SCALE_BYTES;
   return (size_t)bytes;
 }
 
@@ -813,13 +894,21 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.lse = const_cast<float*>(lse); a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
   a.dout = dout; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
-  __bf16* w = reinterpret_cast<__bf16*>(wsb);
-  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s);
-  a.don = pack_operand(dout, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s);
-  a.qt = pack_operand(q, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s);
-  a.dot = pack_operand(dout, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s);
-  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s);
-  a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s);
-  a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s);
+  ScaleWs sw = {};
+  if (precision == 3) {
+    const float* const xs[4] = {q, k, v, dout};
+    const int Ts[4] = {Tq, Tk, Tk, Tq};
+    sw = run_amax(wsb, xs, Ts, 4, B, H * hd, s);
+    a.sc = reinterpret_cast<const AttnScales*>(sw.out);
+  }
+  float* so = sw.out;
+  __bf16* w = reinterpret_cast<__bf16*>(wsb + ATT_SCALE_BYTES);
+  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so);
+  a.don = pack_operand(dout, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6);
+  a.qt = pack_operand(q, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so);
+  a.dot = pack_operand(dout, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6);
+  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2);
+  a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4);
+  a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2);
   return hd <= 32 ? dispatch<32>(a, precision, true, s) : dispatch<64>(a, precision, true, s);
 }

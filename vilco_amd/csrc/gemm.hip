@@ -251,7 +251,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
   }
 
   if (F16) {   // undo the two per-tensor power-of-two scales (exact)
-    const float inv = g.inv_scale[0] * g.inv_scale[1];
+    const float inv = g.inv_scale[0] * g.inv_scale[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   STAMPX(2);
 
   if (F16) {
-    const float inv = g.inv_scale[0] * g.inv_scale[1];
+    const float inv = g.inv_scale[0] * g.inv_scale[2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
 
 // ------------------------------------------------------------------------------------------ host side
 inline long align_up(long x, long a) { return (x + a - 1) / a * a; }
-constexpr long SCALE_BYTES = 2 * AMAX_MAX_BLOCKS * 4 + 256;   // fp16 x2 format: amax partials of A and B, then {1/sA, 1/sB}
+constexpr long SCALE_BYTES = 2 * AMAX_MAX_BLOCKS * 4 + 256;   // fp16 x2 format: amax partials of A and B, then {1/sA, sA, 1/sB, sB}
 
 struct Plan {
   int NP, Kp, BM, ksplit, kchunk;
@@ -736,13 +736,13 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   pb.tap = p.b_tap; pb.tapC = d->tapC > 0 ? d->tapC : 1; pb.tapT = d->tapT > 0 ? d->tapT : 1;
   pb.out_rows = p.b_out_rows;
   pb.vec = vilco_aligned(d->B, 16) && (d->ldb % 4) == 0 && (d->sBo % 4) == 0 && (d->sBi % 4) == 0;
-  pb.amax = f16 ? scales + AMAX_MAX_BLOCKS : nullptr; pb.namax = 0; pb.inv_scale = scales + 2 * AMAX_MAX_BLOCKS + 1;
+  pb.amax = f16 ? scales + AMAX_MAX_BLOCKS : nullptr; pb.namax = 0; pb.inv_scale = scales + 2 * AMAX_MAX_BLOCKS + 2;
   if (f16) {
     AmaxArgs am;
     am.op[0] = amax_view(pa, p.a_tr, p.a_nbo, scales);
     am.op[1] = amax_view(pb, p.b_tr, p.b_nbo, scales + AMAX_MAX_BLOCKS);
     pa.namax = am.op[0].nblocks; pb.namax = am.op[1].nblocks;
-    launch_amax(am, s);
+    launch_amax(am, 2, s);
   }
   dispatch_pack(p.NP, pa, p.a_tr, p.a_nbo * p.a_nbi, s);
   dispatch_pack(p.NP, pb, p.b_tr, p.b_nbo * p.b_nbi, s);

@@ -56,8 +56,9 @@ __device__ __forceinline__ float f16_scale_from(const float* parts, int nparts, 
   int e = (int)((__float_as_uint(m) >> 23) & 0xff);
   if (e < 15) e = 15;                                     // tiny / zero tensors: any scale works
   if (e > 250) e = 250;                                   // inf input: the result is garbage either way
-  if (writer) out[0] = __uint_as_float((unsigned)(e - 14) << 23);       // 1/s for the GEMM epilogue
-  return __uint_as_float((unsigned)(268 - e) << 23);
+  const float sc = __uint_as_float((unsigned)(268 - e) << 23);
+  if (writer) { out[0] = __uint_as_float((unsigned)(e - 14) << 23); out[1] = sc; }   // {1/s, s} for the consumer kernel
+  return sc;
 }
 
 // ------------------------------------------------------------------------------------------ pack
@@ -81,7 +82,7 @@ struct PackArgs {
   int vec;             // 16-byte aligned source rows
   const float* amax;   // fmt 1: per-block partial maxima of |src| from amax_kernel (null = bf16 parts)
   int namax;
-  float* inv_scale;    // fmt 1: where block 0 leaves 1/s for the GEMM kernel
+  float* inv_scale;    // fmt 1: where block 0 leaves {1/s, s} for the consumer kernel
 };
 
 template <int NP>
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void pack_tr_kernel(PackArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ amax (fmt 1)
-// Every pack source is a strided matrix [R][W] (W contiguous) per batch; up to two operands per launch
+// Every pack source is a strided matrix [R][W] (W contiguous) per batch; up to four operands per launch
 // (blockIdx.y); block b leaves max|x| over its rows in parts[b].
 constexpr int AMAX_MAX_BLOCKS = 1024;
 
@@ -202,7 +203,7 @@ struct AmaxOp {
   int nblocks;
   float* parts;        // nblocks partial maxima
 };
-struct AmaxArgs { AmaxOp op[2]; };
+struct AmaxArgs { AmaxOp op[4]; };
 
 __global__ __launch_bounds__(256) void amax_kernel(AmaxArgs args) {
   const AmaxOp& o = args.op[blockIdx.y];
@@ -249,9 +250,10 @@ inline AmaxOp amax_view(const PackArgs& a, bool tr, int nbo, float* parts) {
   return o;
 }
 
-inline void launch_amax(AmaxArgs& am, hipStream_t s) {
-  const int gx = am.op[0].nblocks > am.op[1].nblocks ? am.op[0].nblocks : am.op[1].nblocks;
-  hipLaunchKernelGGL(amax_kernel, dim3(gx, 2), dim3(256), 0, s, am);
+inline void launch_amax(AmaxArgs& am, int nops, hipStream_t s) {
+  int gx = 1;
+  for (int i = 0; i < nops; ++i) gx = am.op[i].nblocks > gx ? am.op[i].nblocks : gx;
+  hipLaunchKernelGGL(amax_kernel, dim3(gx, nops), dim3(256), 0, s, am);
 }
 
 template <int NP>
