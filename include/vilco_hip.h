@@ -46,7 +46,8 @@ const char* vilco_version(void);
 /* NT MFMA kernel (256x128 / 128x128 tiles, optional split-K) runs on the planes.                */
 /* bf16 MFMA (v_mfma_f32_16x16x32_bf16) with fp32 accumulate; precision 0 = split-bf16 (hi+lo, */
 /* 3 MFMAs, ~2^-17 relative), 1 = single bf16 pass, 2 = three-part split (6 MFMAs, ~2^-25:    */
-/* numerically an fp32 GEMM).                                                                  */
+/* numerically an fp32 GEMM), 3 = two fp16 parts of operands scaled by a per-tensor power of   */
+/* two (v_mfma_f32_16x16x32_f16, 3 MFMAs, ~2^-22; the default).                                */
 /* ------------------------------------------------------------------------------------------ */
 enum { VILCO_ACT_NONE = 0, VILCO_ACT_RELU = 1, VILCO_ACT_GELU = 2 };
 enum { VILCO_TAP_NONE = 0, VILCO_TAP_A = 1, VILCO_TAP_B = 2 };
@@ -80,10 +81,23 @@ typedef struct vilco_gemm_desc {
   /* device scratch for the bf16 operand planes and split-K partials; size from vilco_gemm_workspace() */
   void* workspace;
   size_t workspace_bytes;
+  /* optional operands already packed by vilco_pack (NULL: the call packs A / B itself).  The packed tensor is the  */
+  /* row-major matrix the operand lives in: [M][K] (a_kcontig = 1) or [K][M] (a_kcontig = 0), likewise [N][K] /    */
+  /* [K][N] for B -- ONE pack of an activation, a weight or an output gradient serves every product it appears in  */
+  /* (forward, dX = dY W and dW = dY^T X).  Only for tap_operand = NONE and batch 1; A / B may then be NULL.        */
+  const void* a_planes;
+  const void* b_planes;
 } vilco_gemm_desc;
 
 size_t vilco_gemm_workspace(const vilco_gemm_desc* d);
 int vilco_gemm(const vilco_gemm_desc* d, void* stream);
+
+/* Splits the fp32 row-major matrix src[rows][cols] (row stride ld) ONCE into the 16-bit operand planes of         */
+/* `precision` ([part][rows32][cols32], zero padded; precision 3 also leaves the per-tensor power-of-two scale in  */
+/* the buffer's header).  `planes` is device memory, 256-byte aligned, vilco_pack_bytes() long.                     */
+size_t vilco_pack_bytes(int64_t rows, int64_t cols, int32_t precision);
+int vilco_pack(const float* src, int64_t rows, int64_t cols, int64_t ld, int32_t precision, void* planes,
+               size_t planes_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* LayerNorm over the channel dim of token-major rows: blocks.py:160-175 (biased variance, eps   */

@@ -2,10 +2,17 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
 from vilco_amd import ops
-ops.set_precision(sys.argv[1] if len(sys.argv) > 1 else "split3")
+ops.set_precision(sys.argv[1] if len(sys.argv) > 1 else "f16x2")
 M, N, K = [int(x) for x in (sys.argv[2:5] or (4608, 4096, 1024))]
+form = sys.argv[5] if len(sys.argv) > 5 else "NT"
 dev = torch.device("cuda:0")
-A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); C = torch.empty(M, N, device=dev)
+if form == "NT":
+    A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); a_kc, b_kc, lda, ldb = 1, 1, K, K
+elif form == "NN":
+    A = torch.randn(M, K, device=dev); B = torch.randn(K, N, device=dev); a_kc, b_kc, lda, ldb = 1, 0, K, N
+else:
+    A = torch.randn(K, M, device=dev); B = torch.randn(K, N, device=dev); a_kc, b_kc, lda, ldb = 0, 0, M, N
+C = torch.empty(M, N, device=dev)
 for _ in range(5):
-    ops.gemm(A, B, C, M, N, K, 1, 1, K, K, N)
+    ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N)
 torch.cuda.synchronize()

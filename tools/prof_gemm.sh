@@ -1,7 +1,8 @@
-# per-kernel time of one GEMM call (amax / pack / mfma / reduce) for a few shapes
+# per-kernel time of one GEMM call (amax / pack / mfma / reduce) for a few shapes; SHAPES="M N K FORM;..."
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-for shp in "4608 1024 1024" "4608 4096 1024" "4608 1024 4096" "154 1024 1024"; do
+IFS=';' read -ra SH <<< "${SHAPES:-4608 1024 1024 NT;4608 4096 1024 NT;4608 1024 4096 NT;154 1024 1024 NT}"
+for shp in "${SH[@]}"; do
   rm -rf /tmp/pg
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pg -o g -- python3 $R/tools/gemm_one.py ${PREC:-f16x2} $shp > /dev/null 2>&1
   echo "== $shp"

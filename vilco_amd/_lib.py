@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("row_len", c_fp), ("rowT", i32),
         ("colscale", c_fp), ("residual", c_fp), ("res_masked", i32),
         ("workspace", c_fp), ("workspace_bytes", sz),
+        ("a_planes", c_fp), ("b_planes", c_fp),
     ]
 
 
@@ -42,6 +43,8 @@ SIGNATURES = {
     "vilco_version": (C.c_char_p, []),
     "vilco_gemm_workspace": (sz, [C.POINTER(GemmDesc)]),
     "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "vilco_pack_bytes": (sz, [i64, i64, i32]),
+    "vilco_pack": (C.c_int, [c_fp, i64, i64, i64, i32, c_fp, sz, c_fp]),
     "vilco_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp]),
     "vilco_layernorm_bwd_workspace": (sz, [i64, i32]),
     "vilco_layernorm_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32,

@@ -55,6 +55,7 @@ struct PlaneOp {
   int seqT;             // rows per sequence for the overlapped-row layout (INT_MAX otherwise)
   long seq_stride;      // elements between sequences
   long row_stride;      // elements between rows
+  int cols;             // k-major planes: padded row length (multiple of 32); tile columns are clamped to cols - 8
 };
 
 struct GArgs {
@@ -68,7 +69,8 @@ struct GArgs {
   int tiles_n, ntiles;
   int ksplit, kchunk;   // kchunk = K-steps per split
   long split_stride;    // elements between split slabs
-  const float* inv_scale;   // fp16 x2 format: {1/sA, 1/sB} left by the pack kernels (null otherwise)
+  const float* inv_a;       // fp16 x2 format: {1/s, s} of each operand, left by the pack kernels
+  const float* inv_b;
   int vec_out;              // N, ldc, batch strides multiples of 4 and every epilogue pointer 16-byte aligned
   Epi e;
 };
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
   }
 
   if (F16) {   // undo the two per-tensor power-of-two scales (exact)
-    const float inv = g.inv_scale[0] * g.inv_scale[2];
+    const float inv = g.inv_a[0] * g.inv_b[0];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -315,16 +317,33 @@ __device__ unsigned long long vilco_lab_stamps[2 * 64 * 8];
 #define STAMPX(i) do {} while (0)
 #endif
 
-template <int BM, int NP, bool F16>
+// k-major ("km") operands.  A tensor stored [a][b] (b contiguous) is packed ONCE as planes [a][b]; an operand whose
+// contraction index is a (the activations and output gradients in dW = dY^T X, the weights in dX = dY W) reads those
+// same planes k-major: the tile is 32 k-rows x R contiguous row indices (coalesced 16-byte chunks), kept in LDS as
+// [k][R + 16] with column bit 6 flipped on odd 8-row groups, and the MFMA fragment (8 consecutive k of one row per
+// lane) comes out of two ds_read_b64_tr_b16 -- gfx950's transposing LDS read (lane 4q+p of a 16-lane group supplies
+// row q / columns 4p..4p+3 of a 4 x 16 block, lane i receives column i).  Row stride = 8 dwords mod 64 banks plus the
+// bit-6 flip puts the 8 row segments of a 32-lane half on 8 disjoint 8-bank ranges: conflict free.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int rs4) {     // rows k..k+3 at p, rows k+4..k+7 at p + rs4
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + rs4));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int BM, int NP, bool F16, bool AKM, bool BKM>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   constexpr int NT = 512;
   constexpr int MI = BM / 64;                    // 16-row A fragments per wave (wave tile = 16*MI x 64)
-  constexpr int ROWS = BM + BN;
-  constexpr int TILE = ROWS * 32;
+  constexpr int RSA = BM + 16, RSB = BN + 16;    // k-major LDS row strides (elements)
+  constexpr int A_EL = AKM ? 32 * RSA : BM * 32; // elements per part per stage
+  constexpr int B_EL = BKM ? 32 * RSB : BN * 32;
+  constexpr int TILE = A_EL + B_EL;
   constexpr int RA = BM * 4 / NT;                // 16-byte chunks per thread per part: 2 or 1
   constexpr int RB = BN * 4 / NT;                // 1
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);   // [stage 2][part NP][ROWS][32]
+  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);   // [stage 2][part NP][A tile | B tile]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves; group = wave >> 2
@@ -352,18 +371,49 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   const int crow = tid >> 2, cc = tid & 3;
 #pragma unroll
   for (int r = 0; r < RA; ++r) {
-    const int row = crow + r * (NT / 4);
-    offA[r] = row_off(g.a, m0 + row) + cc * 8;
-    ldsA[r] = lds_off(row, cc);
+    if (AKM) {
+      constexpr int CPR = BM / 8;                // chunks per k-row
+      const int id = tid + r * NT, k = id / CPR, c = id % CPR;
+      int col = m0 + c * 8;
+      if (col > g.a.cols - 8) col = g.a.cols - 8;
+      offA[r] = (long)k * g.a.row_stride + col;
+      ldsA[r] = k * RSA + ((c * 8) ^ (((k >> 3) & 1) << 6));
+    } else {
+      const int row = crow + r * (NT / 4);
+      offA[r] = row_off(g.a, m0 + row) + cc * 8;
+      ldsA[r] = lds_off(row, cc);
+    }
   }
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
-    const int row = crow + r * (NT / 4);
-    offB[r] = row_off(g.b, n0 + row) + cc * 8;
-    ldsB[r] = lds_off(BM + row, cc);
+    if (BKM) {
+      constexpr int CPR = BN / 8;
+      const int id = tid + r * NT, k = id / CPR, c = id % CPR;
+      int col = n0 + c * 8;
+      if (col > g.b.cols - 8) col = g.b.cols - 8;
+      offB[r] = (long)k * g.b.row_stride + col;
+      ldsB[r] = A_EL + k * RSB + ((c * 8) ^ (((k >> 3) & 1) << 6));
+    } else {
+      const int row = crow + r * (NT / 4);
+      offB[r] = row_off(g.b, n0 + row) + cc * 8;
+      ldsB[r] = A_EL + lds_off(row, cc);
+    }
   }
-  const int fbA = lds_off(wm * (16 * MI) + (lane & 15), lane >> 4);
-  const int fbB = lds_off(BM + wn * 64 + (lane & 15), lane >> 4);
+  const long stepA = AKM ? (long)BK * g.a.row_stride : BK;   // elements per K-step
+  const long stepB = BKM ? (long)BK * g.b.row_stride : BK;
+  // fragment addresses (elements inside one part's tile)
+  int fbA[MI], fbB[4];
+  {
+    const int grp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      fbA[i] = AKM ? (8 * grp + q4) * RSA + ((wm * (16 * MI) + i * 16 + 4 * p4) ^ ((grp & 1) << 6))
+                   : lds_off(wm * (16 * MI) + (lane & 15), lane >> 4) + i * 16 * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      fbB[j] = A_EL + (BKM ? (8 * grp + q4) * RSB + ((wn * 64 + j * 16 + 4 * p4) ^ ((grp & 1) << 6))
+                           : lds_off(wn * 64 + (lane & 15), lane >> 4) + j * 16 * 32);
+  }
 
   f32x4 acc[MI][4];
 #pragma unroll
@@ -379,8 +429,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 
   bf16x8 stA[NP][RA], stB[NP][RB];
   auto gload = [&](int kt) {
-    const __bf16* ka = pa + (long)kt * BK;
-    const __bf16* kb = pb + (long)kt * BK;
+    const __bf16* ka = pa + (long)kt * stepA;
+    const __bf16* kb = pb + (long)kt * stepB;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
 #pragma unroll
@@ -422,9 +472,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + fbA + i * 16 * 32);
+      for (int i = 0; i < MI; ++i)
+        fa[q][i] = AKM ? tr_frag(s + q * TILE + fbA[i], 4 * RSA) : *reinterpret_cast<const bf16x8*>(s + q * TILE + fbA[i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[q][j] = *reinterpret_cast<const bf16x8*>(s + q * TILE + fbB + j * 16 * 32);
+      for (int j = 0; j < 4; ++j)
+        fb[q][j] = BKM ? tr_frag(s + q * TILE + fbB[j], 4 * RSB) : *reinterpret_cast<const bf16x8*>(s + q * TILE + fbB[j]);
     }
   };
   auto mfma_phase = [&]() {
@@ -433,7 +485,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = mma<F16>(fa[0][i], fb[0][j], acc[i][j]);
-    if (NP >= 2) {
+    if constexpr (NP >= 2) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -442,7 +494,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
           acc[i][j] = mma<F16>(fa[1][i], fb[0][j], acc[i][j]);
         }
     }
-    if (NP == 3) {
+    if constexpr (NP == 3) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -489,7 +541,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   STAMPX(2);
 
   if (F16) {
-    const float inv = g.inv_scale[0] * g.inv_scale[2];
+    const float inv = g.inv_a[0] * g.inv_b[0];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -555,11 +607,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
 
 // ------------------------------------------------------------------------------------------ host side
 inline long align_up(long x, long a) { return (x + a - 1) / a * a; }
+inline bool use_pp() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VILCO_GEMM_PP"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+inline bool use_km() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("VILCO_GEMM_KM"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
 constexpr long SCALE_BYTES = 2 * AMAX_MAX_BLOCKS * 4 + 256;   // fp16 x2 format: amax partials of A and B, then {1/sA, sA, 1/sB, sB}
+constexpr long PACK_HDR = AMAX_MAX_BLOCKS * 4 + 512;          // vilco_pack buffers: amax partials, {1/s, s}, then the planes
 
 struct Plan {
   int NP, Kp, BM, ksplit, kchunk;
   bool a_tr, b_tr;
+  bool a_km, b_km;                // operand consumed k-major from natural-layout planes (ping-pong kernel only)
   int a_tap, b_tap;               // pack tap mode
   int a_out_rows, b_out_rows;     // plane rows written by the kc pack
   long a_plane, b_plane;          // elements per part (all batches)
@@ -578,6 +642,12 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   p.a_out_rows = d->M;
   p.b_out_rows = d->N;
   long a_batch = (long)d->M * p.Kp, b_batch = (long)d->N * p.Kp;
+  // k-major consumption instead of a transposing pack: plain (no tap, unbatched) operands, 16-byte aligned rows
+  const bool km_ok = use_pp() && use_km() && d->tap_operand == VILCO_TAP_NONE && d->batch_outer == 1 && d->batch_inner == 1;
+  p.a_km = km_ok && p.a_tr;
+  p.b_km = km_ok && p.b_tr;
+  if (p.a_km) { p.a_tr = false; p.a_out_rows = p.Kp; a_batch = (long)p.Kp * align_up(d->M, 32); }
+  if (p.b_km) { p.b_tr = false; p.b_out_rows = p.Kp; b_batch = (long)p.Kp * align_up(d->N, 32); }
   if (d->tap_operand == VILCO_TAP_A) {
     if ((d->tapC % 8) == 0) {
       p.a_tap = 1;
@@ -651,24 +721,27 @@ void launch_gemm(const GArgs& g, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((gemm_planes_kernel<BM, NP, F16>), grid, dim3(BM * 2), lds, s, g);
 }
 
-template <int BM, int NP, bool F16 = false>
-void launch_pp(const GArgs& g, dim3 grid, hipStream_t s) {
-  constexpr size_t pipe = (size_t)2 * NP * (BM + BN) * 32 * sizeof(__bf16), epi = (size_t)8 * 16 * EPI_LD * 4;
+template <int BM, int NP, bool F16, bool AKM, bool BKM>
+void launch_pp_km(const GArgs& g, dim3 grid, hipStream_t s) {
+  constexpr size_t a_el = AKM ? 32 * (BM + 16) : BM * 32, b_el = BKM ? 32 * (BN + 16) : BN * 32;
+  constexpr size_t pipe = (size_t)2 * NP * (a_el + b_el) * sizeof(__bf16), epi = (size_t)8 * 16 * EPI_LD * 4;
   constexpr size_t lds = pipe > epi ? pipe : epi;
   static const bool once = [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, NP, F16>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, NP, F16, AKM, BKM>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL((gemm_pp_kernel<BM, NP, F16>), grid, dim3(512), lds, s, g);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, NP, F16, AKM, BKM>), grid, dim3(512), lds, s, g);
 }
 
-inline bool use_pp() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("VILCO_GEMM_PP"); v = e ? atoi(e) : 1; }
-  return v != 0;
+// operand orientations in use: (kc,kc) forward / convs, (kc,km) dX = dY W, (km,km) dW = dY^T X
+template <int BM, int NP, bool F16 = false>
+void launch_pp(const GArgs& g, dim3 grid, hipStream_t s, bool akm = false, bool bkm = false) {
+  if (akm && bkm) launch_pp_km<BM, NP, F16, true, true>(g, grid, s);
+  else if (bkm) launch_pp_km<BM, NP, F16, false, true>(g, grid, s);
+  else launch_pp_km<BM, NP, F16, false, false>(g, grid, s);
 }
 
 }  // namespace
@@ -679,6 +752,39 @@ extern "C" int vilco_lab_read(unsigned long long* out) {
 }
 #endif
 
+static inline int np_of_precision(int precision) { return precision == 1 ? 1 : ((precision == 0 || precision == 3) ? 2 : 3); }
+
+extern "C" size_t vilco_pack_bytes(int64_t rows, int64_t cols, int32_t precision) {
+  if (rows < 0 || cols < 0) return 0;
+  return (size_t)(PACK_HDR + align_up(rows > 0 ? rows : 1, 32) * align_up(cols > 0 ? cols : 1, 32) * 2 * np_of_precision(precision));
+}
+
+extern "C" int vilco_pack(const float* src, int64_t rows, int64_t cols, int64_t ld, int32_t precision, void* planes,
+                          size_t planes_bytes, void* stream) {
+  if (!src || !planes || rows <= 0 || cols <= 0 || ld < cols || precision < 0 || precision > 3) return VILCO_ERR_BADARG;
+  if (rows > 0x7fffffff || cols > 0x7fffffff || !vilco_aligned(planes, 256)) return VILCO_ERR_BADARG;
+  if (planes_bytes < vilco_pack_bytes(rows, cols, precision)) return VILCO_ERR_WORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int NP = np_of_precision(precision);
+  const long rows32 = align_up(rows, 32), cols32 = align_up(cols, 32);
+  float* hdr = reinterpret_cast<float*>(planes);
+  PackArgs pa;
+  pa.src = src; pa.dst = reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(planes) + PACK_HDR);
+  pa.ld = ld; pa.rows = (int)rows; pa.K = (int)cols; pa.Kp = (int)cols32;
+  pa.plane_stride = rows32 * cols32; pa.batch_stride = rows32 * cols32; pa.nbi = 1; pa.so = 0; pa.si = 0;
+  pa.tap = 0; pa.tapC = 1; pa.tapT = 1; pa.out_rows = (int)rows32;
+  pa.vec = vilco_aligned(src, 16) && (ld % 4) == 0;
+  pa.amax = nullptr; pa.namax = 0; pa.inv_scale = hdr + AMAX_MAX_BLOCKS;
+  if (precision == 3) {
+    AmaxArgs am;
+    am.op[0] = amax_view(pa, false, 1, hdr);
+    pa.amax = hdr; pa.namax = am.op[0].nblocks;
+    launch_amax(am, 1, s);
+  }
+  dispatch_pack(NP, pa, false, 1, s);
+  return vilco_launch_status();
+}
+
 extern "C" size_t vilco_gemm_workspace(const vilco_gemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->K < 0) return 512;
   Plan p;
@@ -687,7 +793,11 @@ extern "C" size_t vilco_gemm_workspace(const vilco_gemm_desc* d) {
 }
 
 extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
-  if (!d || !d->A || !d->B || !d->C) return VILCO_ERR_BADARG;
+  if (!d || !d->C || (!d->A && !d->a_planes) || (!d->B && !d->b_planes)) return VILCO_ERR_BADARG;
+  if (d->a_planes || d->b_planes) {
+    if (d->tap_operand != VILCO_TAP_NONE || d->batch_outer != 1 || d->batch_inner != 1 || !use_pp() || !use_km()) return VILCO_ERR_UNSUPPORTED;
+    if (!vilco_aligned(d->a_planes, 256) || !vilco_aligned(d->b_planes, 256)) return VILCO_ERR_BADARG;
+  }
   if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch_outer < 1 || d->batch_inner < 1) return VILCO_ERR_BADARG;
   if (d->M == 0 || d->N == 0) return VILCO_OK;
   if (d->precision < 0 || d->precision > 3) return VILCO_ERR_BADARG;
@@ -726,8 +836,10 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   pa.so = p.a_nbo > 1 ? d->sAo : 0; pa.si = p.a_nbi > 1 ? d->sAi : 0;
   pa.tap = p.a_tap; pa.tapC = d->tapC > 0 ? d->tapC : 1; pa.tapT = d->tapT > 0 ? d->tapT : 1;
   pa.out_rows = p.a_out_rows;
+  if (p.a_km) { pa.rows = d->K; pa.K = d->M; pa.Kp = (int)align_up(d->M, 32); }   // natural [K][M] view
   pa.vec = vilco_aligned(d->A, 16) && (d->lda % 4) == 0 && (d->sAo % 4) == 0 && (d->sAi % 4) == 0;
   pa.amax = f16 ? scales : nullptr; pa.namax = 0; pa.inv_scale = scales + 2 * AMAX_MAX_BLOCKS;
+  const bool packA = d->a_planes == nullptr, packB = d->b_planes == nullptr;
 
   PackArgs pb;
   pb.src = d->B; pb.dst = planesB; pb.ld = d->ldb; pb.rows = d->N; pb.K = d->K; pb.Kp = p.Kp;
@@ -735,17 +847,34 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   pb.so = p.b_nbo > 1 ? d->sBo : 0; pb.si = p.b_nbi > 1 ? d->sBi : 0;
   pb.tap = p.b_tap; pb.tapC = d->tapC > 0 ? d->tapC : 1; pb.tapT = d->tapT > 0 ? d->tapT : 1;
   pb.out_rows = p.b_out_rows;
+  if (p.b_km) { pb.rows = d->K; pb.K = d->N; pb.Kp = (int)align_up(d->N, 32); }   // natural [K][N] view
   pb.vec = vilco_aligned(d->B, 16) && (d->ldb % 4) == 0 && (d->sBo % 4) == 0 && (d->sBi % 4) == 0;
   pb.amax = f16 ? scales + AMAX_MAX_BLOCKS : nullptr; pb.namax = 0; pb.inv_scale = scales + 2 * AMAX_MAX_BLOCKS + 2;
-  if (f16) {
+  if (f16 && (packA || packB)) {
     AmaxArgs am;
-    am.op[0] = amax_view(pa, p.a_tr, p.a_nbo, scales);
-    am.op[1] = amax_view(pb, p.b_tr, p.b_nbo, scales + AMAX_MAX_BLOCKS);
-    pa.namax = am.op[0].nblocks; pb.namax = am.op[1].nblocks;
-    launch_amax(am, 2, s);
+    int nops = 0;
+    if (packA) { am.op[nops] = amax_view(pa, p.a_tr, p.a_nbo, scales); pa.namax = am.op[nops++].nblocks; }
+    if (packB) { am.op[nops] = amax_view(pb, p.b_tr, p.b_nbo, scales + AMAX_MAX_BLOCKS); pb.namax = am.op[nops++].nblocks; }
+    launch_amax(am, nops, s);
   }
-  dispatch_pack(p.NP, pa, p.a_tr, p.a_nbo * p.a_nbi, s);
-  dispatch_pack(p.NP, pb, p.b_tr, p.b_nbo * p.b_nbi, s);
+  if (packA) dispatch_pack(p.NP, pa, p.a_tr, p.a_nbo * p.a_nbi, s);
+  if (packB) dispatch_pack(p.NP, pb, p.b_tr, p.b_nbo * p.b_nbi, s);
+  const float* inv_a = pa.inv_scale;
+  const float* inv_b = pb.inv_scale;
+  if (!packA) {    // planes from vilco_pack: [part][rows32][cols32] behind the header
+    const unsigned char* u = reinterpret_cast<const unsigned char*>(d->a_planes);
+    planesA = reinterpret_cast<__bf16*>(const_cast<unsigned char*>(u) + PACK_HDR);
+    inv_a = reinterpret_cast<const float*>(u) + AMAX_MAX_BLOCKS;
+    p.a_plane = p.a_km ? (long)p.Kp * align_up(d->M, 32) : align_up(d->M, 32) * (long)p.Kp;
+    p.a_batch = p.a_plane;
+  }
+  if (!packB) {
+    const unsigned char* u = reinterpret_cast<const unsigned char*>(d->b_planes);
+    planesB = reinterpret_cast<__bf16*>(const_cast<unsigned char*>(u) + PACK_HDR);
+    inv_b = reinterpret_cast<const float*>(u) + AMAX_MAX_BLOCKS;
+    p.b_plane = p.b_km ? (long)p.Kp * align_up(d->N, 32) : align_up(d->N, 32) * (long)p.Kp;
+    p.b_batch = p.b_plane;
+  }
 
   // ---- MFMA kernel
   GArgs g;
@@ -753,15 +882,19 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   g.a.has_o = p.a_nbo > 1; g.a.has_i = p.a_nbi > 1; g.a.rows = d->M;
   if (p.a_tap == 1) { g.a.seqT = d->tapT; g.a.seq_stride = (long)(d->tapT + 2) * d->tapC; g.a.row_stride = d->tapC; }
   else { g.a.seqT = 0x7fffffff; g.a.seq_stride = 0; g.a.row_stride = p.Kp; }
+  g.a.cols = 0;
+  if (p.a_km) { g.a.row_stride = align_up(d->M, 32); g.a.cols = (int)align_up(d->M, 32); }
   g.b.p = planesB; g.b.plane_stride = p.b_plane; g.b.batch_stride = p.b_batch; g.b.nbi = p.b_nbi;
   g.b.has_o = p.b_nbo > 1; g.b.has_i = p.b_nbi > 1; g.b.rows = d->N;
   g.b.seqT = 0x7fffffff; g.b.seq_stride = 0; g.b.row_stride = p.Kp;
+  g.b.cols = 0;
+  if (p.b_km) { g.b.row_stride = align_up(d->N, 32); g.b.cols = (int)align_up(d->N, 32); }
   g.ldc = d->ldc; g.M = d->M; g.N = d->N; g.Kp = p.Kp;
   g.batch_inner = d->batch_inner; g.sCo = d->sCo; g.sCi = d->sCi;
   g.tiles_n = (d->N + BN - 1) / BN;
   g.ntiles = g.tiles_n * ((d->M + p.BM - 1) / p.BM);
   g.ksplit = p.ksplit; g.kchunk = p.kchunk; g.split_stride = p.split_stride;
-  g.inv_scale = f16 ? scales + 2 * AMAX_MAX_BLOCKS : nullptr;
+  g.inv_a = inv_a; g.inv_b = inv_b;
   g.vec_out = (d->N % 4) == 0 && (d->ldc % 4) == 0 && (d->sCo % 4) == 0 && (d->sCi % 4) == 0 && vilco_aligned(d->C, 16) &&
               vilco_aligned(d->bias, 16) && vilco_aligned(d->preact, 16) && vilco_aligned(d->colscale, 16) &&
               vilco_aligned(d->residual, 16);
@@ -772,15 +905,16 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   const int nz = d->batch_outer * d->batch_inner;
   dim3 grid(g.ntiles, p.ksplit, nz);
   if (use_pp()) {
-    if (f16) { if (p.BM == 256) launch_pp<256, 2, true>(g, grid, s); else launch_pp<128, 2, true>(g, grid, s); }
+    const bool ak = p.a_km, bk = p.b_km;
+    if (f16) { if (p.BM == 256) launch_pp<256, 2, true>(g, grid, s, ak, bk); else launch_pp<128, 2, true>(g, grid, s, ak, bk); }
     else if (p.BM == 256) {
-      if (p.NP == 1) launch_pp<256, 1>(g, grid, s);
-      else if (p.NP == 2) launch_pp<256, 2>(g, grid, s);
-      else launch_pp<256, 3>(g, grid, s);
+      if (p.NP == 1) launch_pp<256, 1>(g, grid, s, ak, bk);
+      else if (p.NP == 2) launch_pp<256, 2>(g, grid, s, ak, bk);
+      else launch_pp<256, 3>(g, grid, s, ak, bk);
     } else {
-      if (p.NP == 1) launch_pp<128, 1>(g, grid, s);
-      else if (p.NP == 2) launch_pp<128, 2>(g, grid, s);
-      else launch_pp<128, 3>(g, grid, s);
+      if (p.NP == 1) launch_pp<128, 1>(g, grid, s, ak, bk);
+      else if (p.NP == 2) launch_pp<128, 2>(g, grid, s, ak, bk);
+      else launch_pp<128, 3>(g, grid, s, ak, bk);
     }
   } else if (f16) {
     if (p.BM == 256) launch_gemm<256, 2, true>(g, grid, s);

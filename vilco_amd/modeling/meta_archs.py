@@ -13,6 +13,7 @@ reductions are [4536 x N] / [#valid x ncls] device tensor expressions under auto
 """
 import copy
 import math
+import os
 
 import numpy as np
 import torch
@@ -129,6 +130,58 @@ class _ConvHead(nn.Module):
             x = norm.forward_tm(x, relu=True) if isinstance(norm, LayerNorm) else torch.relu(x)
         return x
 
+    # ---- all pyramid levels in one pass.  The head weights are shared across levels (meta_archs.py:216-235), so the
+    # levels of each clip are laid end to end as ONE token sequence with a zero row between neighbours: a k=3 conv
+    # over it equals the per-level convs (each level sees the zero padding it would get alone), the GEMMs get
+    # M = B * sum(T_l) rows instead of six small problems, and every other kernel of the trunk runs once.
+    # Rows beyond a level's valid length keep the reference's semantics (conv output * mask, then LN / ReLU of the
+    # zero row); separator rows are forced back to zero after every layer.
+    def _conv_cat(self, conv, x, cat):
+        c = conv.conv
+        assert c.kernel_size[0] == 3 and conv.stride == 1 and c.groups == 1
+        return ops.conv3(x, c.weight, c.bias, None) * cat.valid
+
+    def _trunk_cat(self, x, cat):
+        for conv, norm in zip(self.head, self.norm):
+            x = self._conv_cat(conv, x, cat)
+            if isinstance(norm, LayerNorm):
+                x = norm.forward_tm(x, relu=True) * cat.notgap
+            else:
+                x = torch.relu(x)
+        return x
+
+    @staticmethod
+    def can_cat(heads):
+        return all(m.conv.kernel_size[0] == 3 and m.stride == 1 and m.conv.groups == 1 for m in heads)
+
+
+class LevelCat:
+    """Pyramid levels [B,T_l,C] of every clip concatenated along T with one zero row between levels."""
+
+    def __init__(self, feats, lens):
+        B, dev = feats[0].shape[0], feats[0].device
+        self.T = [f.shape[1] for f in feats]
+        self.off, pieces, valid, o = [], [], [], 0
+        zero = feats[0].new_zeros(B, 1, feats[0].shape[2])
+        for i, (f, l) in enumerate(zip(feats, lens)):
+            if i:
+                pieces.append(zero)
+                valid.append(torch.zeros(B, 1, dtype=torch.bool, device=dev))
+                o += 1
+            self.off.append(o)
+            pieces.append(f)
+            valid.append(torch.arange(f.shape[1], device=dev)[None, :] < l[:, None])
+            o += f.shape[1]
+        self.x = torch.cat(pieces, dim=1)
+        self.valid = torch.cat(valid, dim=1).to(torch.float32)[:, :, None]          # [B,Tc,1]
+        notgap = torch.ones(o, dtype=torch.float32, device=dev)
+        for t0, T in zip(self.off[1:], self.T[:-1]):
+            notgap[t0 - 1] = 0.0
+        self.notgap = notgap[None, :, None]                                            # [1,Tc,1]
+
+    def split(self, y):
+        return [y[:, o:o + T] for o, T in zip(self.off, self.T)]
+
 
 class PtTransformerClsHead(_ConvHead):
     def __init__(self, input_dim, feat_dim, num_classes, prior_prob=0.01, num_layers=3, kernel_size=3,
@@ -148,8 +201,11 @@ class PtTransformerClsHead(_ConvHead):
         self.cls_head.augment_classification(num_new_classes, device)
         self.num_classes += num_new_classes
 
-    def forward_tm(self, feats, lens):
+    def forward_tm(self, feats, lens, cat=None):
         """-> list of logits [B, T_l, ncls] (already the permuted layout of meta_archs.py:848)."""
+        if cat is not None and self.can_cat(list(self.head) + [self.cls_head]):
+            x = self._trunk_cat(cat.x.detach() if self.detach_feat else cat.x, cat)
+            return cat.split(self._conv_cat(self.cls_head, x, cat))
         out = []
         for x, l in zip(feats, lens):
             x = self._trunk(x.detach() if self.detach_feat else x, l)
@@ -173,8 +229,11 @@ class PtTransformerRegHead(_ConvHead):
                                         padding=kernel_size // 2)
         self.reg_params = {}
 
-    def forward_tm(self, feats, lens):
+    def forward_tm(self, feats, lens, cat=None):
         assert len(feats) == self.fpn_levels
+        if cat is not None and self.can_cat(list(self.head) + [self.offset_head]):
+            off = cat.split(self._conv_cat(self.offset_head, self._trunk_cat(cat.x, cat), cat))
+            return [F.relu(self.scale[l](o)) for l, o in enumerate(off)]
         out = []
         for l, (x, ln) in enumerate(zip(feats, lens)):
             x = self._trunk(x, ln)
@@ -261,6 +320,9 @@ class PtTransformer(nn.Module):
         self.reg_head = PtTransformerRegHead(fpn_dim, head_dim, len(self.fpn_strides),
                                              kernel_size=head_kernel_size, num_layers=head_num_layers,
                                              with_ln=head_with_ln, num_bins=0)
+
+        # run both heads over all pyramid levels at once (LevelCat); VILCO_LEVEL_CAT=0 keeps the per-level loop
+        self.level_cat = os.environ.get("VILCO_LEVEL_CAT", "1") != "0"
 
         nc = self.num_classes
         self.mu = nn.Parameter(torch.zeros(nc, 1), requires_grad=True)
@@ -401,8 +463,9 @@ class PtTransformer(nn.Module):
     def _run_network(self, x_tm, lens, text_tm, text_lens):
         feats, all_lens = self.backbone.forward_tm(x_tm, lens, text_tm, text_lens)
         fpn_feats, fpn_lens = self.neck.forward_tm(feats, all_lens)
-        out_offsets = self.reg_head.forward_tm(fpn_feats, fpn_lens)
-        out_cls_logits = self.cls_head.forward_tm(fpn_feats, fpn_lens)
+        cat = LevelCat(fpn_feats, fpn_lens) if (self.level_cat and len(fpn_feats) > 1) else None
+        out_offsets = self.reg_head.forward_tm(fpn_feats, fpn_lens, cat)
+        out_cls_logits = self.cls_head.forward_tm(fpn_feats, fpn_lens, cat)
         return fpn_feats, fpn_lens, out_cls_logits, out_offsets
 
     def forward(self, video_list, task_id=-1, ensemble=False, hidden_state=False, is_training=True,

@@ -64,12 +64,14 @@ def _ws(nbytes, device):
 def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), sB=(0, 0),
          sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
          bias=None, preact=None, act=ACT_NONE, row_len=None, rowT=0, colscale=None, residual=None,
-         res_masked=0, precision=None):
-    """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements."""
+         res_masked=0, precision=None, a_planes=None, b_planes=None):
+    """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements.  a_planes / b_planes: operands
+    already packed by `pack` (the fp32 tensor may then be None)."""
     lib = _lib.load()
     d = GemmDesc()
-    d.A = A.data_ptr() + 4 * offA
-    d.B = B.data_ptr() + 4 * offB
+    d.A = None if A is None else A.data_ptr() + 4 * offA
+    d.B = None if B is None else B.data_ptr() + 4 * offB
+    d.a_planes, d.b_planes = _p(a_planes), _p(b_planes)
     d.C = Cc.data_ptr() + 4 * offC
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.a_kcontig, d.b_kcontig = int(a_kc), int(b_kc)
@@ -93,6 +95,21 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     ws = torch.empty(nbytes, dtype=torch.uint8, device=Cc.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     _lib.check(lib.vilco_gemm(C.byref(d), _stream()))
+
+
+def pack(x, rows, cols, precision=None):
+    """One pass over the fp32 row-major matrix x[rows][cols] -> 16-bit operand planes (a uint8 tensor) that every
+    product the tensor appears in consumes, in either orientation (vilco_pack, include/vilco_hip.h)."""
+    lib = _lib.load()
+    prec = _precision if precision is None else int(precision)
+    nbytes = lib.vilco_pack_bytes(int(rows), int(cols), prec)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.vilco_pack(x.data_ptr(), int(rows), int(cols), int(cols), prec, buf.data_ptr(), nbytes, _stream()))
+    return buf
+
+
+# packed operands are shared between forward, dX and dW (env VILCO_PACK_REUSE=0: every GEMM packs its own operands)
+_reuse_packs = os.environ.get("VILCO_PACK_REUSE", "1") != "0"
 
 
 def _act_bwd(dy, aux, act, lens, T, want_bias):
@@ -130,16 +147,20 @@ class _Linear(torch.autograd.Function):
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         pre = torch.empty_like(y) if act == ACT_GELU else None
+        px = pw = None
+        if _reuse_packs:
+            ctx.prec = _precision
+            px, pw = pack(x, M, K), pack(w, N, K)
         gemm(x, w, y, M, N, K, 1, 1, K, K, N, bias=b, preact=pre, act=act, row_len=lens,
-             rowT=T or 0)
+             rowT=T or 0, a_planes=px, b_planes=pw)
         ctx.act, ctx.T = act, T
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x, w, pre if act == ACT_GELU else (y if act == ACT_RELU else None), lens)
+        ctx.save_for_backward(x, w, pre if act == ACT_GELU else (y if act == ACT_RELU else None), lens, px, pw)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, aux, lens = ctx.saved_tensors
+        x, w, aux, lens, px, pw = ctx.saved_tensors
         dy = dy.contiguous()
         K, N = x.shape[-1], w.shape[0]
         M = x.numel() // K
@@ -148,13 +169,17 @@ class _Linear(torch.autograd.Function):
             dz, db = _act_bwd(dy, aux, ctx.act, lens, ctx.T, need_db)
         else:
             dz, db = dy, (colsum(dy.view(M, N)) if need_db else None)
-        dx = dw = None
+        dx = dw = pz = None
+        prec = None
+        if px is not None:                       # one pack of dZ feeds dX and dW; X and W planes come from forward
+            prec = ctx.prec
+            pz = pack(dz, M, N, prec)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(dz, w, dx, M, K, N, 1, 0, N, K, K)            # dX = dZ W        (NN)
+            gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=prec, a_planes=pz, b_planes=pw)   # dX = dZ W     (NN)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            gemm(dz, x, dw, N, K, M, 0, 0, N, K, K)            # dW = dZ^T X      (TN)
+            gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=prec, a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
         return dx, dw, db, None, None, None
 
 
@@ -173,26 +198,34 @@ class _LinearKN(torch.autograd.Function):
         N = w.numel() // K
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
-        gemm(x, w, y, M, N, K, 1, 0, K, N, N, bias=b)                 # NN
+        px = pw = None
+        if _reuse_packs:
+            ctx.prec = _precision
+            px, pw = pack(x, M, K), pack(w, K, N)
+        gemm(x, w, y, M, N, K, 1, 0, K, N, N, bias=b, a_planes=px, b_planes=pw)                 # NN
         ctx.has_bias = b is not None
         ctx.bshape = None if b is None else b.shape
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, px, pw)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, px, pw = ctx.saved_tensors
         dy = dy.contiguous()
         K = x.shape[-1]
         N = w.numel() // K
         M = x.numel() // K
-        dx = dw = db = None
+        dx = dw = db = pz = None
+        prec = None
+        if px is not None:
+            prec = ctx.prec
+            pz = pack(dy, M, N, prec)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(dy, w, dx, M, K, N, 1, 1, N, N, K)                   # dX = dY W^T   (NT)
+            gemm(dy, w, dx, M, K, N, 1, 1, N, N, K, precision=prec, a_planes=pz, b_planes=pw)   # dX = dY W^T   (NT)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            gemm(x, dy, dw, K, N, M, 0, 0, K, N, N)                   # dW = X^T dY   (TN)
+            gemm(x, dy, dw, K, N, M, 0, 0, K, N, N, precision=prec, a_planes=px, b_planes=pz)   # dW = X^T dY   (TN)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy.view(M, N)).view(ctx.bshape)
         return dx, dw, db
