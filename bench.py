@@ -100,37 +100,65 @@ def cpu_baseline(timeout_s=240):
                 "sample": "oracle step did not finish within %d s (%s)" % (timeout_s, type(e).__name__)}
 
 
-def gemm_profile(step_fn, n=2):
-    """per-launch HIP-event timing of the GEMM kernel on the launch stream, over `n` extra steps.
-    Returns (avg launch us, algorithmic TFLOP/s, launches per step, gemm ms per step)."""
-    from vilco_amd import ops
+def gemm_profile(step_fn, n=3):
+    """HIP-event timing of the MFMA GEMM kernel alone (gemm_pp_kernel, all instantiations), on the stream it is
+    launched on, over `n` extra steps: vilco_gemm brackets its main kernel with events (vilco_gemm_profile_*), the
+    algorithmic FLOPs are counted at the ops.gemm call sites.  Also times the whole vilco_gemm calls (packs, kernel,
+    split-K reduce) with torch events.  Returns a dict."""
+    import ctypes
+    from vilco_amd import ops, _lib
+    lib = _lib.load()
     recs = []
-    real = ops.gemm
+    real_gemm, real_pack = ops.gemm, ops.pack
 
-    def timed(A, B, Cc, M, N, K, *a, **k):
+    def timed(fn, flop):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        real(A, B, Cc, M, N, K, *a, **k)
+        out = fn()
         e1.record()
+        recs.append((e0, e1, flop))
+        return out
+
+    def gemm(A, B, Cc, M, N, K, *a, **k):
         batch = k.get("batch", (1, 1))
-        recs.append((e0, e1, 2.0 * M * N * K * batch[0] * batch[1]))
-    ops.gemm = timed
+        return timed(lambda: real_gemm(A, B, Cc, M, N, K, *a, **k), 2.0 * M * N * K * batch[0] * batch[1])
+
+    def pack(*a, **k):
+        return timed(lambda: real_pack(*a, **k), 0.0)
+    ops.gemm, ops.pack = gemm, pack
     try:
+        _lib.check(lib.vilco_gemm_profile_begin())
         for _ in range(n):
             step_fn()
         torch.cuda.synchronize()
+        ms, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+        _lib.check(lib.vilco_gemm_profile_end(ctypes.byref(ms), ctypes.byref(cnt)))
     finally:
-        ops.gemm = real
-    t_us = sum(a.elapsed_time(b) for a, b, _ in recs) * 1e3
+        ops.gemm, ops.pack = real_gemm, real_pack
     flops = sum(f for _, _, f in recs)
-    return t_us / len(recs), flops / (t_us * 1e-6) / 1e12, len(recs) // n, t_us / n / 1e3, flops / len(recs)
+    call_ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+    launches = int(cnt.value)
+    return {"avg_launch_us": ms.value * 1e3 / launches, "tflops": flops / (ms.value * 1e-3) / 1e12,
+            "launches_per_step": launches // n, "kernel_ms_per_step": ms.value / n,
+            "gflop_per_launch": flops / launches / 1e9,
+            "call_ms_per_step": call_ms / n, "call_tflops": flops / (call_ms * 1e-3) / 1e12}
+
+
+def pmc_traffic():
+    """HBM bytes per GEMM-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950
+    note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); None when the summary is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        return json.load(open(path))["gemm_pp_kernel"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="clips per GPU (mq_vilco.yaml: 2)")
     ap.add_argument("--precision", default="f16x2", choices=["split3", "split", "bf16", "f16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -204,8 +232,8 @@ def main():
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": {"split3": "bf16 MFMA x3-part split, fp32 accumulate (fp32-equivalent)",
                          "split": "bf16 MFMA x2-part split, fp32 accumulate", "bf16": "bf16",
-                         "f16x2": "fp16 MFMA x2-part split of power-of-two scaled operands (22-bit), fp32 accumulate; "
-                                  "attention on bf16 x3-part split"}[args.precision],
+                         "f16x2": "fp16 MFMA on 2-part splits of power-of-two scaled fp32 operands (22 significant bits, "
+                                  "3 MFMAs per product), fp32 accumulate: fp32-equivalent"}[args.precision],
                "data": "synthetic",
                "config": {"workload": "MQ ViLCo backbone config P: T=2304 Cin=2304 D=1024 H=16 arch(2,2,5) XLNet layer "
                                       "(dropout 0) text L=77x768 22 classes, train mode dropout/droppath 0",
@@ -213,11 +241,18 @@ def main():
                           "parallelism": "dp%d" % world},
                "clips_per_s_per_gpu": clips_per_s / world,
                "model_mfma_frac": clips_per_s / world * GFLOP_PER_CLIP_FWD_BWD / 1e3 / PEAK_BF16_TFLOPS}
-        avg_us, tflops, n_launch, gemm_ms, flop_per_launch = gemm_profile(step)
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (all instantiations)", "achieved": tflops,
-                           "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_BF16_TFLOPS,
-                           "traffic": None, "avg_launch_us": avg_us, "launches_per_step": n_launch,
-                           "gemm_ms_per_step": gemm_ms, "algorithmic_gflop_per_launch": flop_per_launch / 1e9}
+        gp = gemm_profile(step)
+        mfma_per_product = {"f16x2": 3, "split3": 6, "split": 3, "bf16": 1}[args.precision]
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp_kernel (all instantiations)", "achieved": gp["tflops"],
+                           "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gp["tflops"] / PEAK_BF16_TFLOPS,
+                           "traffic": pmc_traffic(), "avg_launch_us": gp["avg_launch_us"],
+                           "launches_per_step": gp["launches_per_step"],
+                           "kernel_ms_per_step": gp["kernel_ms_per_step"],
+                           "algorithmic_gflop_per_launch": gp["gflop_per_launch"],
+                           "mfma_per_algorithmic_product": mfma_per_product,
+                           "mfma_issue_frac": gp["tflops"] * mfma_per_product / PEAK_BF16_TFLOPS,
+                           "gemm_calls_ms_per_step_incl_pack_and_reduce": gp["call_ms_per_step"],
+                           "gemm_calls_tflops_incl_pack_and_reduce": gp["call_tflops"]}
         # the optimizer step is reported separately (BASELINE.json metric = fwd+bwd): fused clip-norm + AdamW
         from vilco_amd.utils.train_utils import make_optimizer
         opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-4))

@@ -92,6 +92,11 @@ typedef struct vilco_gemm_desc {
 size_t vilco_gemm_workspace(const vilco_gemm_desc* d);
 int vilco_gemm(const vilco_gemm_desc* d, void* stream);
 
+/* Timing of the MFMA kernel alone (not the packs, not the split-K reduce): between begin and end every vilco_gemm   */
+/* brackets its main kernel with HIP events on the caller's stream; end waits for them and returns the sum.          */
+int vilco_gemm_profile_begin(void);
+int vilco_gemm_profile_end(double* kernel_ms, int64_t* launches);
+
 /* Splits the fp32 row-major matrix src[rows][cols] (row stride ld) ONCE into the 16-bit operand planes of         */
 /* `precision` ([part][rows32][cols32], zero padded; precision 3 also leaves the per-tensor power-of-two scale in  */
 /* the buffer's header).  `planes` is device memory, 256-byte aligned, vilco_pack_bytes() long.                     */

@@ -165,3 +165,29 @@ def test_two_part_split_mode_accuracy(dev):
                   if gold['grads'][k] is not None)
     assert errs[len(errs) // 2] < 1e-4
     assert errs[int(len(errs) * 0.95)] < 1e-3
+
+
+def test_level_cat_heads_match_per_level_loop(dev):
+    """Both heads over all pyramid levels at once (LevelCat: levels end to end, zero separator rows) == the
+    reference's per-level loop, forward and gradients, with ragged valid lengths."""
+    from vilco_amd.modeling import meta_archs as MA
+    torch.manual_seed(3)
+    B, C, Ts = 2, 64, [40, 20, 10]
+    for with_ln in (True, False):
+        cls = MA.PtTransformerClsHead(C, C, 5, with_ln=with_ln).to(dev)
+        reg = MA.PtTransformerRegHead(C, C, len(Ts), with_ln=with_ln, num_bins=0).to(dev)
+        feats = [torch.randn(B, T, C, device=dev, requires_grad=True) for T in Ts]
+        lens = [torch.tensor([T, max(1, T - 3 - i)], dtype=torch.int32, device=dev) for i, T in enumerate(Ts)]
+        res = []
+        for use_cat in (False, True):
+            for f in feats:
+                f.grad = None
+            cls.zero_grad(); reg.zero_grad()
+            cat = MA.LevelCat(feats, lens) if use_cat else None
+            outs = cls.forward_tm(feats, lens, cat) + reg.forward_tm(feats, lens, cat)
+            torch.manual_seed(4)
+            sum((o * torch.randn_like(o)).sum() for o in outs).backward()
+            res.append([o.detach() for o in outs] + [f.grad.clone() for f in feats] +
+                       [p.grad.clone() for p in list(cls.parameters()) + list(reg.parameters())])
+        for a, b in zip(*res):
+            assert rel_err(b, a, 1e-6) < 2e-5

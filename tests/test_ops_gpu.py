@@ -1,6 +1,7 @@
 """HIP kernels (through the C ABI) vs plain fp64 PyTorch references of the same op, fwd + bwd.
-Tolerances (max abs error / max abs reference): GEMM-backed ops 2e-5 in the default three-part split
-mode (fp32-equivalent), 2e-4 in the two-part split mode, 2e-2 in plain bf16; elementwise 2e-5."""
+Tolerances (max abs error / max abs reference): GEMM-backed ops 2e-5 in the default fp16x2 mode and in the
+three-part bf16 split mode (both fp32-equivalent), 2e-4 in the two-part bf16 split mode, 2e-2 in plain bf16;
+elementwise 2e-5.  The module runs under the default precision; VILCO_PRECISION=split3 reruns it in that mode."""
 import math
 
 import pytest
@@ -108,6 +109,63 @@ def test_f16x2_scaling(dev, sx, sw):
     err[9] = (y[9] - ref[9]).abs()
     assert float(err.max()) < 4e-6, float(err.max())
     assert float(y[9].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", ["f16x2", "split3", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(300, 260, 200), (37, 22, 50), (512, 128, 96), (129, 8, 33), (1000, 1024, 64)])
+def test_packed_operands_match_unpacked(dev, mode, M, N, K):
+    """One vilco_pack per tensor, consumed k-contiguous (forward), k-major as B (dX = dY W) and k-major as A and B
+    (dW = dY^T X), must give bit-identical results to the calls that pack their own operands."""
+    from vilco_amd import ops
+    torch.manual_seed(11)
+    x, w, dy = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.randn(M, N, device=dev)
+    ops.set_precision(mode)
+    try:
+        px, pw, pdy = ops.pack(x, M, K), ops.pack(w, N, K), ops.pack(dy, M, N)
+        outs = []
+        for planes in (False, True):
+            y, dx, dw = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev), torch.empty(N, K, device=dev)
+            ops.gemm(x, w, y, M, N, K, 1, 1, K, K, N, a_planes=px if planes else None, b_planes=pw if planes else None)
+            ops.gemm(dy, w, dx, M, K, N, 1, 0, N, K, K, a_planes=pdy if planes else None, b_planes=pw if planes else None)
+            ops.gemm(dy, x, dw, N, K, M, 0, 0, N, K, K, a_planes=pdy if planes else None, b_planes=px if planes else None)
+            outs.append((y, dx, dw))
+        tol = {"f16x2": 4e-6, "split3": 4e-6, "bf16": 2e-2}[mode]
+        for got, want in zip(outs[1], (x.double() @ w.double().t(), dy.double() @ w.double(), dy.double().t() @ x.double())):
+            assert rel(got, want) < tol
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    finally:
+        ops.set_precision(None)
+
+
+def test_packed_operand_errors(dev):
+    from vilco_amd import ops, _lib
+    x, w, y = torch.randn(64, 32, device=dev), torch.randn(16, 32, device=dev), torch.empty(64, 16, device=dev)
+    px = ops.pack(x, 64, 32)
+    with pytest.raises(RuntimeError):      # pre-packed operands are not defined for batched problems
+        ops.gemm(x, w, y, 32, 16, 32, 1, 1, 32, 32, 16, batch=(2, 1), sA=(32 * 32, 0), sC=(32 * 16, 0), a_planes=px)
+    lib = _lib.load()
+    small = torch.empty(16, dtype=torch.uint8, device=dev)
+    assert lib.vilco_pack(x.data_ptr(), 64, 32, 32, 3, small.data_ptr(), 16, None) != 0   # buffer too small
+
+
+def test_pack_reuse_toggle(dev, monkeypatch):
+    """linear() with shared packs (default) == linear() packing per GEMM, bit for bit (forward and gradients)."""
+    from vilco_amd import ops
+    torch.manual_seed(12)
+    res = []
+    for reuse in (True, False):
+        monkeypatch.setattr(ops, "_reuse_packs", reuse)
+        x = torch.randn(2, 150, 72, device=dev, requires_grad=True)
+        w = (torch.randn(70, 72, device=dev) / 8).requires_grad_(True)
+        b = torch.randn(70, device=dev, requires_grad=True)
+        torch.manual_seed(13)
+        y = ops.linear(x, w, b, ops.ACT_GELU)
+        y.backward(torch.randn_like(y))
+        res.append((y.detach(), x.grad, w.grad, b.grad))
+        torch.manual_seed(12)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("B,T,Cin,Cout", [(2, 64, 96, 64), (2, 160, 64, 24), (1, 300, 32, 136), (3, 16, 8, 2)])
@@ -223,6 +281,21 @@ def test_attention(dev, B, Tq, Tk, H, hd, flash):
                  lambda q, k, v: _attn_ref(q, k, v, lens, H, scale), dict(q=q, k=k, v=v), dev, TOL_GEMM)
     finally:
         ops.use_flash = True
+
+
+@pytest.mark.parametrize("mode,tol", [("split3", TOL_GEMM), ("f16x2", TOL_GEMM), ("split", 5e-4)])
+def test_attention_precision_modes(dev, mode, tol):
+    from vilco_amd import ops
+    torch.manual_seed(8)
+    B, Tq, Tk, H, hd = 2, 200, 157, 3, 32
+    q, k, v = torch.randn(B, Tq, H * hd) * 3, torch.randn(B, Tk, H * hd) * 1e-3, torch.randn(B, Tk, H * hd) * 50
+    lens = torch.tensor([Tk, Tk - 9], dtype=torch.int32)
+    ops.set_precision(mode)
+    try:
+        run_pair(lambda q, k, v: ops.attention(q, k, v, lens.to(dev), H, 0.2),
+                 lambda q, k, v: _attn_ref(q, k, v, lens, H, 0.2), dict(q=q, k=k, v=v), dev, tol)
+    finally:
+        ops.set_precision(None)
 
 
 @pytest.mark.parametrize("flash", [True, False])

@@ -43,6 +43,8 @@ SIGNATURES = {
     "vilco_version": (C.c_char_p, []),
     "vilco_gemm_workspace": (sz, [C.POINTER(GemmDesc)]),
     "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "vilco_gemm_profile_begin": (C.c_int, []),
+    "vilco_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vilco_pack_bytes": (sz, [i64, i64, i32]),
     "vilco_pack": (C.c_int, [c_fp, i64, i64, i64, i32, c_fp, sz, c_fp]),
     "vilco_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp]),

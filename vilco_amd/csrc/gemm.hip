@@ -19,6 +19,8 @@
 // 3 = two fp16 parts of the per-tensor scaled operands ("f16x2": 22 bits, 3 MFMAs; pack.h).
 // Reference arithmetic replaced: see include/vilco_hip.h (vilco_gemm).
 #include <cstdlib>
+#include <utility>
+#include <vector>
 #include "common.h"
 #include "pack.h"
 
@@ -752,6 +754,37 @@ extern "C" int vilco_lab_read(unsigned long long* out) {
 }
 #endif
 
+// ---- optional timing of the MFMA kernel alone (bench.py's roofline line): HIP events on the caller's stream
+namespace {
+struct ProfState { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+ProfState& prof() { static ProfState p; return p; }
+}  // namespace
+
+extern "C" int vilco_gemm_profile_begin(void) {
+  ProfState& p = prof();
+  for (auto& e : p.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  p.ev.clear();
+  p.on = true;
+  return VILCO_OK;
+}
+
+extern "C" int vilco_gemm_profile_end(double* kernel_ms, int64_t* launches) {
+  ProfState& p = prof();
+  p.on = false;
+  double total = 0.0;
+  for (auto& e : p.ev) {
+    if (hipEventSynchronize(e.second) != hipSuccess) return VILCO_ERR_LAUNCH;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e.first, e.second);
+    total += ms;
+  }
+  if (kernel_ms) *kernel_ms = total;
+  if (launches) *launches = (int64_t)p.ev.size();
+  for (auto& e : p.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  p.ev.clear();
+  return VILCO_OK;
+}
+
 static inline int np_of_precision(int precision) { return precision == 1 ? 1 : ((precision == 0 || precision == 3) ? 2 : 3); }
 
 extern "C" size_t vilco_pack_bytes(int64_t rows, int64_t cols, int32_t precision) {
@@ -904,6 +937,8 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
             d->res_masked};
   const int nz = d->batch_outer * d->batch_inner;
   dim3 grid(g.ntiles, p.ksplit, nz);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
   if (use_pp()) {
     const bool ak = p.a_km, bk = p.b_km;
     if (f16) { if (p.BM == 256) launch_pp<256, 2, true>(g, grid, s, ak, bk); else launch_pp<128, 2, true>(g, grid, s, ak, bk); }
@@ -928,6 +963,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     else if (p.NP == 2) launch_gemm<128, 2>(g, grid, s);
     else launch_gemm<128, 3>(g, grid, s);
   }
+  if (ev0) { hipEventRecord(ev1, s); prof().ev.emplace_back(ev0, ev1); }
   if (p.ksplit > 1) {
     long blocks = ((long)d->M * d->N * nz + 255) / 256;
     if (blocks > 2048) blocks = 2048;
