@@ -103,6 +103,14 @@ int vilco_gemm_profile_end(double* kernel_ms, int64_t* launches);
 size_t vilco_pack_bytes(int64_t rows, int64_t cols, int32_t precision);
 int vilco_pack(const float* src, int64_t rows, int64_t cols, int64_t ld, int32_t precision, void* planes,
                size_t planes_bytes, void* stream);
+/* up to four tensors in the same two launches (an activation and its layer's weight) */
+typedef struct vilco_pack_item {
+  const float* src;
+  int64_t rows, cols, ld;
+  void* planes;
+  size_t planes_bytes;
+} vilco_pack_item;
+int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t precision, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* LayerNorm over the channel dim of token-major rows: blocks.py:160-175 (biased variance, eps   */

@@ -37,6 +37,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    """Mirror of `vilco_pack_item`."""
+    _fields_ = [("src", c_fp), ("rows", i64), ("cols", i64), ("ld", i64), ("planes", c_fp), ("planes_bytes", sz)]
+
+
 # name -> (restype, argtypes); must list every symbol include/vilco_hip.h declares
 SIGNATURES = {
     "vilco_status_str": (C.c_char_p, [C.c_int]),
@@ -47,6 +52,7 @@ SIGNATURES = {
     "vilco_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vilco_pack_bytes": (sz, [i64, i64, i32]),
     "vilco_pack": (C.c_int, [c_fp, i64, i64, i64, i32, c_fp, sz, c_fp]),
+    "vilco_pack_many": (C.c_int, [C.POINTER(PackItem), i32, i32, c_fp]),
     "vilco_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp]),
     "vilco_layernorm_bwd_workspace": (sz, [i64, i32]),
     "vilco_layernorm_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32,

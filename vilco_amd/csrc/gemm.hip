@@ -792,30 +792,41 @@ extern "C" size_t vilco_pack_bytes(int64_t rows, int64_t cols, int32_t precision
   return (size_t)(PACK_HDR + align_up(rows > 0 ? rows : 1, 32) * align_up(cols > 0 ? cols : 1, 32) * 2 * np_of_precision(precision));
 }
 
-extern "C" int vilco_pack(const float* src, int64_t rows, int64_t cols, int64_t ld, int32_t precision, void* planes,
-                          size_t planes_bytes, void* stream) {
-  if (!src || !planes || rows <= 0 || cols <= 0 || ld < cols || precision < 0 || precision > 3) return VILCO_ERR_BADARG;
-  if (rows > 0x7fffffff || cols > 0x7fffffff || !vilco_aligned(planes, 256)) return VILCO_ERR_BADARG;
-  if (planes_bytes < vilco_pack_bytes(rows, cols, precision)) return VILCO_ERR_WORKSPACE;
+extern "C" int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t precision, void* stream) {
+  if (!items || n < 1 || n > 4 || precision < 0 || precision > 3) return VILCO_ERR_BADARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int NP = np_of_precision(precision);
-  const long rows32 = align_up(rows, 32), cols32 = align_up(cols, 32);
-  float* hdr = reinterpret_cast<float*>(planes);
-  PackArgs pa;
-  pa.src = src; pa.dst = reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(planes) + PACK_HDR);
-  pa.ld = ld; pa.rows = (int)rows; pa.K = (int)cols; pa.Kp = (int)cols32;
-  pa.plane_stride = rows32 * cols32; pa.batch_stride = rows32 * cols32; pa.nbi = 1; pa.so = 0; pa.si = 0;
-  pa.tap = 0; pa.tapC = 1; pa.tapT = 1; pa.out_rows = (int)rows32;
-  pa.vec = vilco_aligned(src, 16) && (ld % 4) == 0;
-  pa.amax = nullptr; pa.namax = 0; pa.inv_scale = hdr + AMAX_MAX_BLOCKS;
-  if (precision == 3) {
-    AmaxArgs am;
-    am.op[0] = amax_view(pa, false, 1, hdr);
-    pa.amax = hdr; pa.namax = am.op[0].nblocks;
-    launch_amax(am, 1, s);
+  PackArgs4 pk;
+  AmaxArgs am;
+  for (int i = 0; i < n; ++i) {
+    const vilco_pack_item& it = items[i];
+    if (!it.src || !it.planes || it.rows <= 0 || it.cols <= 0 || it.ld < it.cols) return VILCO_ERR_BADARG;
+    if (it.rows > 0x7fffffff || it.cols > 0x7fffffff || !vilco_aligned(it.planes, 256)) return VILCO_ERR_BADARG;
+    if (it.planes_bytes < vilco_pack_bytes(it.rows, it.cols, precision)) return VILCO_ERR_WORKSPACE;
+    const long rows32 = align_up(it.rows, 32), cols32 = align_up(it.cols, 32);
+    float* hdr = reinterpret_cast<float*>(it.planes);
+    PackArgs& pa = pk.a[i];
+    pa.src = it.src; pa.dst = reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(it.planes) + PACK_HDR);
+    pa.ld = it.ld; pa.rows = (int)it.rows; pa.K = (int)it.cols; pa.Kp = (int)cols32;
+    pa.plane_stride = rows32 * cols32; pa.batch_stride = rows32 * cols32; pa.nbi = 1; pa.so = 0; pa.si = 0;
+    pa.tap = 0; pa.tapC = 1; pa.tapT = 1; pa.out_rows = (int)rows32;
+    pa.vec = vilco_aligned(it.src, 16) && (it.ld % 4) == 0;
+    pa.amax = nullptr; pa.namax = 0; pa.inv_scale = hdr + AMAX_MAX_BLOCKS;
+    if (precision == 3) {
+      am.op[i] = amax_view(pa, false, 1, hdr);
+      pa.amax = hdr; pa.namax = am.op[i].nblocks;
+    }
   }
-  dispatch_pack(NP, pa, false, 1, s);
+  if (precision == 3) launch_amax(am, n, s);
+  if (n == 1) dispatch_pack(NP, pk.a[0], false, 1, s);
+  else dispatch_pack_multi(NP, pk, n, s);
   return vilco_launch_status();
+}
+
+extern "C" int vilco_pack(const float* src, int64_t rows, int64_t cols, int64_t ld, int32_t precision, void* planes,
+                          size_t planes_bytes, void* stream) {
+  const vilco_pack_item it = {src, rows, cols, ld, planes, planes_bytes};
+  return vilco_pack_many(&it, 1, precision, stream);
 }
 
 extern "C" size_t vilco_gemm_workspace(const vilco_gemm_desc* d) {

@@ -86,16 +86,16 @@ struct PackArgs {
 };
 
 template <int NP>
-__global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
-  const int z = blockIdx.z, zo = z / a.nbi, zi = z % a.nbi;
+__device__ __forceinline__ void pack_kc_body(const PackArgs& a, int z, int bx, int nbx) {
+  const int zo = z / a.nbi, zi = z % a.nbi;
   const float* src = a.src + zo * a.so + zi * a.si;
   __bf16* dst = a.dst + (long)z * a.batch_stride;
   const int width = (a.tap == 1) ? a.tapC : a.Kp;       // elements per output row
   const int kmax = (a.tap == 1) ? a.tapC : a.K;         // valid source columns
   const int chunks = width >> 3;
   const long total = (long)a.out_rows * chunks;
-  const float fs = a.amax ? f16_scale_from(a.amax, a.namax, a.inv_scale, blockIdx.x == 0 && z == 0 && threadIdx.x == 0) : 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  const float fs = a.amax ? f16_scale_from(a.amax, a.namax, a.inv_scale, bx == 0 && z == 0 && threadIdx.x == 0) : 0.f;
+  for (long i = (long)bx * blockDim.x + threadIdx.x; i < total; i += (long)nbx * blockDim.x) {
     const int c = (int)(i % chunks);
     const long orow = i / chunks;
     const int k0 = c * 8;
@@ -131,6 +131,16 @@ __global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(dst + q * a.plane_stride + o) = part[q];
   }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) { pack_kc_body<NP>(a, blockIdx.z, blockIdx.x, gridDim.x); }
+
+// up to four unbatched kc packs in one launch (blockIdx.y = operand): an activation and its layer's weight
+struct PackArgs4 { PackArgs a[4]; };
+template <int NP>
+__global__ __launch_bounds__(256) void pack_kc_multi_kernel(PackArgs4 args) {
+  pack_kc_body<NP>(args.a[blockIdx.y], 0, blockIdx.x, gridDim.x);
 }
 
 // transposing pack: 64(r) x 64(k) tile through LDS.  grid = (ceil(nrows/64), ceil(Kp/64), batch * ntap)
@@ -270,6 +280,21 @@ void launch_pack(const PackArgs& a, bool tr, int nbatch, hipStream_t s) {
     dim3 grid((nrows + 63) / 64, (a.Kp + 63) / 64, nbatch * ntap);
     hipLaunchKernelGGL((pack_tr_kernel<NP>), grid, dim3(256), 0, s, a);
   }
+}
+
+inline int kc_blocks(const PackArgs& a) {
+  const int width = (a.tap == 1) ? a.tapC : a.Kp;
+  long blocks = ((long)a.out_rows * (width / 8) + 255) / 256;
+  return (int)(blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks));
+}
+
+void dispatch_pack_multi(int NP, const PackArgs4& args, int n, hipStream_t s) {
+  int gx = 1;
+  for (int i = 0; i < n; ++i) gx = kc_blocks(args.a[i]) > gx ? kc_blocks(args.a[i]) : gx;
+  const dim3 grid(gx, n);
+  if (NP == 1) hipLaunchKernelGGL((pack_kc_multi_kernel<1>), grid, dim3(256), 0, s, args);
+  else if (NP == 2) hipLaunchKernelGGL((pack_kc_multi_kernel<2>), grid, dim3(256), 0, s, args);
+  else hipLaunchKernelGGL((pack_kc_multi_kernel<3>), grid, dim3(256), 0, s, args);
 }
 
 void dispatch_pack(int NP, const PackArgs& a, bool tr, int nbatch, hipStream_t s) {

@@ -108,6 +108,21 @@ def pack(x, rows, cols, precision=None):
     return buf
 
 
+def pack_many(items, precision=None):
+    """[(x, rows, cols), ...] (at most four) packed by the same two launches -> list of plane buffers."""
+    lib = _lib.load()
+    prec = _precision if precision is None else int(precision)
+    arr = (_lib.PackItem * len(items))()
+    bufs = []
+    for it, (x, rows, cols) in zip(arr, items):
+        nbytes = lib.vilco_pack_bytes(int(rows), int(cols), prec)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        it.src, it.rows, it.cols, it.ld, it.planes, it.planes_bytes = x.data_ptr(), int(rows), int(cols), int(cols), buf.data_ptr(), nbytes
+        bufs.append(buf)
+    _lib.check(lib.vilco_pack_many(arr, len(items), prec, _stream()))
+    return bufs
+
+
 # packed operands are shared between forward, dX and dW (env VILCO_PACK_REUSE=0: every GEMM packs its own operands)
 _reuse_packs = os.environ.get("VILCO_PACK_REUSE", "1") != "0"
 
@@ -150,7 +165,7 @@ class _Linear(torch.autograd.Function):
         px = pw = None
         if _reuse_packs:
             ctx.prec = _precision
-            px, pw = pack(x, M, K), pack(w, N, K)
+            px, pw = pack_many([(x, M, K), (w, N, K)])
         gemm(x, w, y, M, N, K, 1, 1, K, K, N, bias=b, preact=pre, act=act, row_len=lens,
              rowT=T or 0, a_planes=px, b_planes=pw)
         ctx.act, ctx.T = act, T
@@ -201,7 +216,7 @@ class _LinearKN(torch.autograd.Function):
         px = pw = None
         if _reuse_packs:
             ctx.prec = _precision
-            px, pw = pack(x, M, K), pack(w, K, N)
+            px, pw = pack_many([(x, M, K), (w, K, N)])
         gemm(x, w, y, M, N, K, 1, 0, K, N, N, bias=b, a_planes=px, b_planes=pw)                 # NN
         ctx.has_bias = b is not None
         ctx.bshape = None if b is None else b.shape
