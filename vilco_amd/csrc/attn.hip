@@ -780,8 +780,12 @@ PlaneSpec spec_tr(int B, int H, int T, int hd) {
 }
 
 // runs the pack kernel for x [B,T,C] (head slices) into `dst` and returns the Planes view + advanced pointer
+// natural (kc) packs queued here go out together in ONE launch (flush_packs)
+struct PackQueue { PackArgs4 a; int n = 0; PackArgs4 t; int nt = 0; };
+
 Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, int B, int H, int T, int hd, int HDP,
-                    int NP, hipStream_t s, const float* amax = nullptr, int namax = 0, float* inv_scale = nullptr) {
+                    int NP, hipStream_t s, const float* amax = nullptr, int namax = 0, float* inv_scale = nullptr,
+                    PackQueue* queue = nullptr) {
   PackArgs pa;
   pa.src = x; pa.dst = dst; pa.ld = (long)H * hd;
   pa.rows = tr ? hd : T; pa.K = tr ? T : hd; pa.Kp = tr ? sp.row_stride : HDP;
@@ -790,7 +794,9 @@ Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, 
   pa.tap = 0; pa.tapC = 1; pa.tapT = 1; pa.out_rows = T;
   pa.vec = vilco_aligned(x, 16) && (hd % 4) == 0;
   pa.amax = amax; pa.namax = namax; pa.inv_scale = inv_scale;
-  dispatch_pack(NP, pa, tr, B * H, s);
+  if (queue && !tr) queue->a.a[queue->n++] = pa;
+  else if (queue) queue->t.a[queue->nt++] = pa;
+  else dispatch_pack(NP, pa, tr, B * H, s);
   Planes pl;
   pl.p = dst; pl.part_stride = sp.elems_per_part; pl.batch_stride = sp.batch;
   pl.row_stride = sp.row_stride; pl.rows = sp.rows; pl.cols = sp.cols;
@@ -855,9 +861,12 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   }
   float* so = sw.out;
   __bf16* w = reinterpret_cast<__bf16*>(wsb + ATT_SCALE_BYTES);
-  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so);
-  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2);
-  a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4);
+  PackQueue pq;
+  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
+  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
+  a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
+  dispatch_pack_multi(NP, pq.a, pq.n, s, B * H);
+  dispatch_pack_tr_multi(NP, pq.t, pq.nt, s, B * H);
   return hd <= 32 ? dispatch<32>(a, precision, false, s) : dispatch<64>(a, precision, false, s);
 }
 
@@ -903,12 +912,15 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   }
   float* so = sw.out;
   __bf16* w = reinterpret_cast<__bf16*>(wsb + ATT_SCALE_BYTES);
-  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so);
-  a.don = pack_operand(dout, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6);
-  a.qt = pack_operand(q, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so);
-  a.dot = pack_operand(dout, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6);
-  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2);
-  a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4);
-  a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2);
+  PackQueue pq;
+  a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
+  a.don = pack_operand(dout, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6, &pq);
+  a.qt = pack_operand(q, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
+  a.dot = pack_operand(dout, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6, &pq);
+  a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
+  a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
+  a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
+  dispatch_pack_multi(NP, pq.a, pq.n, s, B * H);
+  dispatch_pack_tr_multi(NP, pq.t, pq.nt, s, B * H);
   return hd <= 32 ? dispatch<32>(a, precision, true, s) : dispatch<64>(a, precision, true, s);
 }

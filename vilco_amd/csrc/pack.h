@@ -136,20 +136,22 @@ __device__ __forceinline__ void pack_kc_body(const PackArgs& a, int z, int bx, i
 template <int NP>
 __global__ __launch_bounds__(256) void pack_kc_kernel(PackArgs a) { pack_kc_body<NP>(a, blockIdx.z, blockIdx.x, gridDim.x); }
 
-// up to four unbatched kc packs in one launch (blockIdx.y = operand): an activation and its layer's weight
+// up to four kc packs with the same batch count in one launch (blockIdx.y = operand): an activation and its
+// layer's weight, or the natural planes of q / k / v / dO
 struct PackArgs4 { PackArgs a[4]; };
 template <int NP>
 __global__ __launch_bounds__(256) void pack_kc_multi_kernel(PackArgs4 args) {
-  pack_kc_body<NP>(args.a[blockIdx.y], 0, blockIdx.x, gridDim.x);
+  pack_kc_body<NP>(args.a[blockIdx.y], blockIdx.z, blockIdx.x, gridDim.x);
 }
 
 // transposing pack: 64(r) x 64(k) tile through LDS.  grid = (ceil(nrows/64), ceil(Kp/64), batch * ntap)
 template <int NP>
-__global__ __launch_bounds__(256) void pack_tr_kernel(PackArgs a) {
+__device__ __forceinline__ void pack_tr_body(const PackArgs& a, int bz) {
   __shared__ float tile[64][65];
   const int ntap = (a.tap == 3) ? 3 : 1;
   const int nrows = (a.tap == 3) ? a.tapC : a.rows;
-  const int z = blockIdx.z / ntap, j = blockIdx.z % ntap;
+  if ((int)blockIdx.x * 64 >= nrows || (int)blockIdx.y * 64 >= a.Kp) return;     // multi launch: grid is the max
+  const int z = bz / ntap, j = bz % ntap;
   const int zo = z / a.nbi, zi = z % a.nbi;
   const float* src = a.src + zo * a.so + zi * a.si;
   __bf16* dst = a.dst + (long)z * a.batch_stride;
@@ -267,6 +269,15 @@ inline void launch_amax(AmaxArgs& am, int nops, hipStream_t s) {
 }
 
 template <int NP>
+__global__ __launch_bounds__(256) void pack_tr_kernel(PackArgs a) { pack_tr_body<NP>(a, blockIdx.z); }
+
+// untapped transposing packs with the same batch count in one launch: blockIdx.z = operand * nbatch + batch
+template <int NP>
+__global__ __launch_bounds__(256) void pack_tr_multi_kernel(PackArgs4 args, int nbatch) {
+  pack_tr_body<NP>(args.a[blockIdx.z / nbatch], blockIdx.z % nbatch);
+}
+
+template <int NP>
 void launch_pack(const PackArgs& a, bool tr, int nbatch, hipStream_t s) {
   if (!tr) {
     const int width = (a.tap == 1) ? a.tapC : a.Kp;
@@ -288,13 +299,25 @@ inline int kc_blocks(const PackArgs& a) {
   return (int)(blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks));
 }
 
-void dispatch_pack_multi(int NP, const PackArgs4& args, int n, hipStream_t s) {
+void dispatch_pack_multi(int NP, const PackArgs4& args, int n, hipStream_t s, int nbatch = 1) {
   int gx = 1;
   for (int i = 0; i < n; ++i) gx = kc_blocks(args.a[i]) > gx ? kc_blocks(args.a[i]) : gx;
-  const dim3 grid(gx, n);
+  const dim3 grid(gx, n, nbatch);
   if (NP == 1) hipLaunchKernelGGL((pack_kc_multi_kernel<1>), grid, dim3(256), 0, s, args);
   else if (NP == 2) hipLaunchKernelGGL((pack_kc_multi_kernel<2>), grid, dim3(256), 0, s, args);
   else hipLaunchKernelGGL((pack_kc_multi_kernel<3>), grid, dim3(256), 0, s, args);
+}
+
+void dispatch_pack_tr_multi(int NP, const PackArgs4& args, int n, hipStream_t s, int nbatch) {
+  int gx = 1, gy = 1;
+  for (int i = 0; i < n; ++i) {
+    gx = (args.a[i].rows + 63) / 64 > gx ? (args.a[i].rows + 63) / 64 : gx;
+    gy = (args.a[i].Kp + 63) / 64 > gy ? (args.a[i].Kp + 63) / 64 : gy;
+  }
+  const dim3 grid(gx, gy, n * nbatch);
+  if (NP == 1) hipLaunchKernelGGL((pack_tr_multi_kernel<1>), grid, dim3(256), 0, s, args, nbatch);
+  else if (NP == 2) hipLaunchKernelGGL((pack_tr_multi_kernel<2>), grid, dim3(256), 0, s, args, nbatch);
+  else hipLaunchKernelGGL((pack_tr_multi_kernel<3>), grid, dim3(256), 0, s, args, nbatch);
 }
 
 void dispatch_pack(int NP, const PackArgs& a, bool tr, int nbatch, hipStream_t s) {
