@@ -191,3 +191,25 @@ def test_level_cat_heads_match_per_level_loop(dev):
                        [p.grad.clone() for p in list(cls.parameters()) + list(reg.parameters())])
         for a, b in zip(*res):
             assert rel_err(b, a, 1e-6) < 2e-5
+
+
+def test_sync_free_losses_match_gather_losses(dev):
+    """The dense, host-sync-free evaluation of the losses (default) == the reference-style boolean-gather evaluation:
+    losses, loss_normalizer EMA and every parameter gradient."""
+    gold = load_golden("xl")
+    res = []
+    for sync_free in (False, True):
+        model = build_hip_model(gold)
+        model.sync_free_loss = sync_free
+        model.loss_normalizer = golden_cfg(gold)['train_cfg']['init_loss_norm']
+        losses = model(golden_inputs(gold), task_id=gold['task_id'], is_training=True)
+        losses['final_loss'].backward()
+        res.append(({k: v.detach().double().cpu() for k, v in losses.items()}, model.loss_normalizer,
+                    {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (la, na, ga), (lb, nb, gb) = res
+    for k in la:
+        assert rel_err(lb[k], la[k]) < 1e-5, k
+    assert abs(na - nb) < 1e-4 * max(1.0, abs(na))
+    assert ga.keys() == gb.keys()
+    for k in ga:
+        assert rel_err(gb[k], ga[k], 1e-6) < 2e-5, k     # floor: analytically-zero key-bias gradients are 1e-12 noise

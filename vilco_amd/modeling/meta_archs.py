@@ -332,7 +332,8 @@ class PtTransformer(nn.Module):
         self.mu_reg_right = nn.Parameter(torch.ones(nc, 1) * 0.5, requires_grad=True)
         self.sigma_reg_right = nn.Parameter(torch.ones(nc, 1), requires_grad=True)
 
-        self.loss_normalizer = t['init_loss_norm']     # python-float EMA, not checkpointed (:611)
+        self.loss_normalizer = t['init_loss_norm']     # EMA, not checkpointed (:611); a device scalar in the sync-free path
+        self.sync_free_loss = os.environ.get("VILCO_SYNC_FREE_LOSS", "1") != "0"
         self.loss_normalizer_momentum = 0.9
         self.reg_params = {}
 
@@ -626,6 +627,20 @@ class PtTransformer(nn.Module):
                                           p_right[rows, min_len_inds])
 
     # ------------------------------------------------------------------ losses
+    @property
+    def loss_normalizer(self):
+        """python float like the reference's attribute; reading it after a sync-free step waits for the device."""
+        v = self._loss_norm
+        return float(v) if torch.is_tensor(v) else v
+
+    @loss_normalizer.setter
+    def loss_normalizer(self, v):
+        self._loss_norm = float(v)
+
+    def _loss_norm_tensor(self, device):
+        v = self._loss_norm
+        return v if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float32, device=device)
+
     def losses(self, fpn_masks, out_cls_logits, out_offsets, gt_cls_labels, gt_offsets, label_list=None,
                normal_probs_cls=None, normal_probs_reg=None, out_importances=None, out_start=None,
                out_end=None, prev_out_cls_logits=None, stage_id=0, reduce_sim=None):
@@ -638,18 +653,42 @@ class PtTransformer(nn.Module):
         w_right = torch.stack([x[1] for x in normal_probs_reg])
         pos_mask = torch.logical_and((gt_cls.sum(-1) > 0), valid_mask)
         logits_all = torch.cat(out_cls_logits, dim=1)
-        pred_offsets = torch.cat(out_offsets, dim=1)[pos_mask]
-        gt_off = torch.stack(gt_offsets)[pos_mask]
-
-        num_pos = pos_mask.sum().item()
-        self.loss_normalizer = self.loss_normalizer_momentum * self.loss_normalizer + (
-            1 - self.loss_normalizer_momentum) * max(num_pos, 1)
-
-        gt_target = gt_cls[valid_mask]
-        gt_target = gt_target * (1 - self.train_label_smoothing) + self.train_label_smoothing / (self.num_classes + 1)
-        cls_loss = sigmoid_focal_loss(logits_all[valid_mask], gt_target, reduction='None')
+        offsets_all = torch.cat(out_offsets, dim=1)
+        gt_off_all = torch.stack(gt_offsets)
+        gt_target = gt_cls * (1 - self.train_label_smoothing) + self.train_label_smoothing / (self.num_classes + 1)
         w_cls = torch.where(pos_mask, w_cls, torch.ones_like(w_cls))           # negatives weigh 1
-        cls_loss = (cls_loss.sum(-1) * w_cls[valid_mask]).sum() / self.loss_normalizer
+
+        if self.sync_free_loss:
+            # Same sums as the reference, evaluated densely over all points with 0/1 weights instead of boolean
+            # gathers: no host round trip anywhere in the step (the reference syncs on num_pos, on every boolean
+            # index and in the DIoU asserts), so the GPU never waits for the host between forward and backward.
+            num_pos = pos_mask.sum()
+            norm = self._loss_norm_tensor(logits_all.device)
+            norm = self.loss_normalizer_momentum * norm + (1 - self.loss_normalizer_momentum) * num_pos.clamp(min=1).to(norm.dtype)
+            self._loss_norm = norm.detach()
+            vf, pf = valid_mask.to(logits_all.dtype), pos_mask.to(logits_all.dtype)
+            cls_loss = sigmoid_focal_loss(logits_all, gt_target, reduction='None')
+            cls_loss = (cls_loss.sum(-1) * w_cls * vf).sum() / norm
+            one = torch.ones_like(gt_off_all)
+            reg = ctr_diou_loss_1d(torch.where(pos_mask[..., None], offsets_all, one).reshape(-1, 2),
+                                   torch.where(pos_mask[..., None], gt_off_all, one).reshape(-1, 2),
+                                   reduction='None', check=False).reshape(pos_mask.shape)
+            reg_loss = (reg * ((w_left + w_right) / 2.0) * w_cls * pf).sum() / norm
+        else:
+            pred_offsets = offsets_all[pos_mask]
+            gt_off = gt_off_all[pos_mask]
+            num_pos = pos_mask.sum().item()
+            self.loss_normalizer = self.loss_normalizer_momentum * self.loss_normalizer + (
+                1 - self.loss_normalizer_momentum) * max(num_pos, 1)
+            norm = self.loss_normalizer
+            cls_loss = sigmoid_focal_loss(logits_all[valid_mask], gt_target[valid_mask], reduction='None')
+            cls_loss = (cls_loss.sum(-1) * w_cls[valid_mask]).sum() / norm
+            if num_pos == 0:
+                reg_loss = 0 * pred_offsets.sum()
+            else:
+                reg_loss = ctr_diou_loss_1d(pred_offsets, gt_off, reduction='None')
+                reg_loss = reg_loss * ((w_left[pos_mask] + w_right[pos_mask]) / 2.0) * w_cls[pos_mask]
+                reg_loss = reg_loss.sum() / norm
 
         if label_list is not None and (out_cls_logits[0].shape[-1] != 1):
             score = logits_all.masked_fill(valid_mask.unsqueeze(-1) == False, -1e7)   # noqa: E712
@@ -657,16 +696,10 @@ class PtTransformer(nn.Module):
             involved = torch.zeros_like(score)
             for i in range(involved.shape[0]):
                 involved[i, label_list[i]] = 1
-            al_loss = (-involved * score.log() - (1 - involved) * (1 - score).log()).sum() / self.loss_normalizer
+            al_loss = (-involved * score.log() - (1 - involved) * (1 - score).log()).sum() / norm
         else:
             al_loss = torch.zeros((1,), device=cls_loss.device)
 
-        if num_pos == 0:
-            reg_loss = 0 * pred_offsets.sum()
-        else:
-            reg_loss = ctr_diou_loss_1d(pred_offsets, gt_off, reduction='None')
-            reg_loss = reg_loss * ((w_left[pos_mask] + w_right[pos_mask]) / 2.0) * w_cls[pos_mask]
-            reg_loss = reg_loss.sum() / self.loss_normalizer
         if self.train_loss_weight > 0:
             loss_weight = self.train_loss_weight
         else:
