@@ -214,6 +214,31 @@ __device__ __forceinline__ void load_qfrag(QFrag<HDP, NP>& qf, const Planes& pl,
 // expf; |relative error| <= ~2^-21 for the |x| <= 40 range of softmax arguments, far inside the 1e-3 budget.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
+// additive bias of (query i, key j).  mode 3: `bias` holds XLNet's UNSHIFTED position scores bd[b,h,i,p] = qr_i . kr_p,
+// p in [0, Tq+Tk); rel_shift_bnij (modeling_xlnet_x.py:204-214) picks p = Tq - i + j, and the 1/sqrt(d) scale of the
+// score applies to it: the shifted [Tq,Tk] bias tensor is never materialised.
+__device__ __forceinline__ float bias_at(const float* bias, int i, int j, int ld, const AttnArgs& a) {
+  if (a.mode == 3) return a.scale * bias[(long)i * ld + (a.Tq - i + j)];
+  return bias[(long)i * ld + j];
+}
+
+// 4 consecutive keys jb..jb+3 of query row i: ONE 16-byte access per lane (the address is only 4-byte aligned in mode 3;
+// gfx950 global loads take that) instead of four scattered dword accesses -- the bias / dS traffic of the XLNet layer is
+// 680 MB per pass and was 3/4 of that layer's attention time as scalar loads.
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+__device__ __forceinline__ void bias4(float (&bv)[4], const float* bias, int i, int jb, int ld, const AttnArgs& a) {
+  if (jb + 4 <= a.Tk) {
+    const float* p = a.mode == 3 ? bias + (long)i * ld + (a.Tq - i + jb) : bias + (long)i * ld + jb;
+    const f4u t = *reinterpret_cast<const f4u*>(p);
+    const float sc = a.mode == 3 ? a.scale : 1.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = sc * t.v[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = jb + r < a.Tk ? bias_at(bias, i, jb + r, ld, a) : 0.f;
+  }
+}
+
 // score of (query i, key j) after scale + bias: apply the mask
 __device__ __forceinline__ float mask_score(float s, int i, int j, int len, int Tk, int mode) {
   if (j >= Tk) return -INFINITY;
@@ -238,7 +263,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   const int q0 = qt * 64 + wave * 16;
   const int qi = q0 + (lane & 15);                 // this lane's query
   const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
-  const float* bias = a.bias ? a.bias + ((long)bh * a.Tq) * a.Tk : nullptr;
+  const int bias_ld = a.mode == 3 ? a.Tq + a.Tk : a.Tk;       // mode 3: unshifted XLNet position scores (see AttnArgs)
+  const float* bias = a.bias ? a.bias + ((long)bh * a.Tq) * bias_ld : nullptr;
+  const int mmode = a.mode == 3 ? 1 : a.mode;
   const __bf16* kbase = a.kn.p + (long)bh * a.kn.batch_stride;
   const __bf16* vbase = a.vt.p + (long)bh * a.vt.batch_stride;
   const int fbH = toff<HDP>(lane & 15, lane >> 4);        // fragment bases (see frag())
@@ -256,7 +283,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   int kend = a.Tk;
-  if (a.mode == 0 && len < kend) kend = len;      // tiles entirely beyond kv_len contribute nothing
+  if (mmode == 0 && len < kend) kend = len;      // tiles entirely beyond kv_len contribute nothing
   const int ntiles = (kend + BKV - 1) / BKV;
   const int kfull = len < a.Tk ? len : a.Tk;      // keys below this index need no masking in any mode
   __bf16* myP = sP + wave * NP * 16 * BKV;
@@ -278,6 +305,17 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
       gload_tile<BKV, HDP, NP>(stV, a.vt, vbase, 0, k0 + BKV, tid);
     }
 
+    // the additive bias of this tile is requested before the S MFMAs so its latency hides under them
+    const bool plain = (bias == nullptr) && (k0 + BKV <= kfull);      // wave-uniform: no bias, nothing masked
+    float bvt[4][4];
+    if (bias) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bvt[mi][r] = 0.f;
+        if (qi < a.Tq) bias4(bvt[mi], bias, qi, k0 + mi * 16 + (lane >> 4) * 4, bias_ld, a);
+      }
+    }
     // S^T[key][q] = K Q^T : 4 m-tiles of 16 keys, this wave's 16 queries
     f32x4 s[4];
 #pragma unroll
@@ -293,7 +331,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
       s[mi] = c;
     }
     // lane holds query qi, keys k0 + mi*16 + 4*(lane>>4) + r
-    const bool plain = (bias == nullptr) && (k0 + BKV <= kfull);      // wave-uniform: no bias, nothing masked
     float tmax = -INFINITY;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -302,14 +339,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s[mi][r] *= qk_scale; tmax = fmaxf(tmax, s[mi][r]); }
       } else {
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias && qi < a.Tq) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (jb + r < a.Tk) bv[r] = bias[(long)qi * a.Tk + jb + r];
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float x = mask_score(s[mi][r] * qk_scale + bv[r], qi, jb + r, len, a.Tk, a.mode);
+          const float x = mask_score(s[mi][r] * qk_scale + (bias ? bvt[mi][r] : 0.f), qi, jb + r, len, a.Tk, mmode);
           s[mi][r] = x;
           tmax = fmaxf(tmax, x);
         }
@@ -415,8 +447,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   const int qi = q0 + (lane & 15);
   const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
   const long row_bh = (long)bh * a.Tq;
-  const float* bias = a.bias ? a.bias + row_bh * a.Tk : nullptr;
+  const int bias_ld = a.mode == 3 ? a.Tq + a.Tk : a.Tk;
+  const float* bias = a.bias ? a.bias + row_bh * bias_ld : nullptr;
   float* dbias = a.dbias ? a.dbias + row_bh * a.Tk : nullptr;
+  const int mmode = a.mode == 3 ? 1 : a.mode;
   const __bf16* knb = a.kn.p + (long)bh * a.kn.batch_stride;
   const __bf16* vnb = a.vn.p + (long)bh * a.vn.batch_stride;
   const __bf16* ktb = a.kt.p + (long)bh * a.kt.batch_stride;
@@ -440,7 +474,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   for (int i = 0; i < HDP / 16; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int kend = a.Tk;
-  if (a.mode == 0 && len < kend) kend = len;
+  if (mmode == 0 && len < kend) kend = len;
   const int ntiles = (kend + BKV - 1) / BKV;
   const int kfull = len < a.Tk ? len : a.Tk;
   __bf16* myS = sS + wave * NP * 16 * BKV;
@@ -465,6 +499,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
       gload_tile<BKV, HDP, NP>(stKt, a.kt, ktb, 0, k0 + BKV, tid);
     }
     const bool plain = (bias == nullptr) && (k0 + BKV <= kfull);
+    float bvt[4][4];
+    if (bias) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bvt[mi][r] = 0.f;
+        if (qi < a.Tq) bias4(bvt[mi], bias, qi, k0 + mi * 16 + (lane >> 4) * 4, bias_ld, a);
+      }
+    }
 
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -485,18 +528,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = s[r] * qk_scale;
-        if (!plain) {
-          float bv = 0.f;
-          if (bias && qi < a.Tq && jb + r < a.Tk) bv = bias[(long)qi * a.Tk + jb + r];
-          x = mask_score(x + bv, qi, jb + r, len, a.Tk, a.mode);
-        }
+        if (!plain) x = mask_score(x + (bias ? bvt[mi][r] : 0.f), qi, jb + r, len, a.Tk, mmode);
         const float p = (x == -INFINITY) ? 0.f : fast_exp(x - lse);
         ds[r] = p * (dp[r] - dlt);
         if (F16) ds[r] *= DS_SCALE;
       }
       if (dbias && qi < a.Tq) {
+        if (jb + 4 <= a.Tk) {
+          f4u t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (jb + r < a.Tk) dbias[(long)qi * a.Tk + jb + r] = ds[r] * ds_unscale;
+          for (int r = 0; r < 4; ++r) t.v[r] = ds[r] * ds_unscale;
+          *reinterpret_cast<f4u*>(dbias + (long)qi * a.Tk + jb) = t;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (jb + r < a.Tk) dbias[(long)qi * a.Tk + jb + r] = ds[r] * ds_unscale;
+        }
       }
       bf16x4 pp[3];
       split4s<NP, F16>(ds, pp);
@@ -559,7 +605,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
   const int k0 = kt * BKV;
   const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
   const long row_bh = (long)bh * a.Tq;
-  const float* bias = a.bias ? a.bias + row_bh * a.Tk : nullptr;
+  const int bias_ld = a.mode == 3 ? a.Tq + a.Tk : a.Tk;
+  const float* bias = a.bias ? a.bias + row_bh * bias_ld : nullptr;
+  const int mmode = a.mode == 3 ? 1 : a.mode;
   const __bf16* qnb = a.qn.p + (long)bh * a.qn.batch_stride;
   const __bf16* donb = a.don.p + (long)bh * a.don.batch_stride;
   const __bf16* qtb = a.qt.p + (long)bh * a.qt.batch_stride;
@@ -587,7 +635,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
 #pragma unroll
   for (int i = 0; i < HDP / 16; ++i) { dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const bool tile_dead = (a.mode == 0 && k0 >= len);      // every key of this tile is masked: grads are zero
+  const bool tile_dead = (mmode == 0 && k0 >= len);      // every key of this tile is masked: grads are zero
   const int kfull = len < a.Tk ? len : a.Tk;
   const bool plain = (bias == nullptr) && (k0 + BKV <= kfull);
   const int nq = tile_dead ? 0 : (a.Tq + BQ - 1) / BQ;
@@ -622,6 +670,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
       lse4[r] = qi < a.Tq ? a.lse[row_bh + qi] : 0.f;
       dl4[r] = (qi < a.Tq ? a.delta[row_bh + qi] : 0.f) * dl_scale;
     }
+    float bvt[2][4];
+    if (bias) {
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r, j = k0 + kh * 32 + nj * 16 + (lane & 15);
+          bvt[nj][r] = (qi < a.Tq && j < a.Tk) ? bias_at(bias, qi, j, bias_ld, a) : 0.f;
+        }
+    }
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
       const int ncol = kh * 32 + nj * 16;                  // key offset inside the tile
@@ -646,9 +704,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
         const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r;
         float x = s[r] * qk_scale;
         if (!plain) {
-          float bv = 0.f;
-          if (bias && qi < a.Tq && j < a.Tk) bv = bias[(long)qi * a.Tk + j];
-          x = mask_score(x + bv, qi, j, len, a.Tk, a.mode);
+          x = mask_score(x + (bias ? bvt[nj][r] : 0.f), qi, j, len, a.Tk, mmode);
         }
         p[r] = (qi < a.Tq && x != -INFINITY) ? fast_exp(x - lse4[r]) : 0.f;
         ds[r] = p[r] * (dp[r] - dl4[r]);
@@ -757,7 +813,7 @@ int dispatch(const AttnArgs& a, int precision, bool bwd, hipStream_t s) {
 
 int check_common(int B, int H, int Tq, int Tk, int hd, int mode, int precision) {
   if (B < 0 || H <= 0 || Tq < 0 || Tk < 0 || hd <= 0) return VILCO_ERR_BADARG;
-  if (mode < 0 || mode > 2 || precision < 0 || precision > 3) return VILCO_ERR_BADARG;
+  if (mode < 0 || mode > 3 || precision < 0 || precision > 3) return VILCO_ERR_BADARG;
   if (hd > 64 || (hd % 4) != 0) return VILCO_ERR_UNSUPPORTED;      // head dims 4..64 (P: 64, tests: 8, 16, 32)
   return VILCO_OK;
 }

@@ -539,6 +539,7 @@ def mask_rows_(x, lens):
 
 # ---------------------------------------------------------------------------------------- attention
 MASK_KEYS, MASK_XLNET, MASK_NONE = 0, 1, 2
+MASK_XLNET_REL = 3      # XLNet mask + bias given as UNSHIFTED position scores [B,H,Tq,Tq+Tk] (attn.hip: bias_at)
 use_flash = True     # fused attention kernels when the head dim is supported; False = materialised scores
 
 
@@ -728,22 +729,21 @@ class _FlashRelAttention(torch.autograd.Function):
         bd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
         gemm(qr, kr, bd, T, 2 * T, hd, 1, 1, Cn, Cn, 2 * T, batch=(B, H), sA=(T * Cn, hd), sB=(0, hd),
              sC=(H * T * 2 * T, T * 2 * T))
-        bias = torch.zeros(B, H, T, T, dtype=torch.float32, device=qw.device)
-        _lib.check(lib.vilco_relshift_add(bias.data_ptr(), bd.data_ptr(), scale, B, H, T, _stream()))
-        del bd
-        o, lse = _flash_fwd(qw, k, v, bias, kv_len, H, scale, MASK_XLNET)
+        # the flash kernel reads the unshifted scores in place (mask mode 3): no [T,T] bias tensor, no shift pass
+        o, lse = _flash_fwd(qw, k, v, bd, kv_len, H, scale, MASK_XLNET_REL)
         ctx.H, ctx.scale = H, scale
-        ctx.save_for_backward(qw, qr, k, v, kr, kv_len, bias, o, lse)
+        ctx.save_for_backward(qw, qr, k, v, kr, kv_len, bd, o, lse)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        qw, qr, k, v, kr, kv_len, bias, o, lse = ctx.saved_tensors
+        qw, qr, k, v, kr, kv_len, bd, o, lse = ctx.saved_tensors
         lib = _lib.load()
         H, scale = ctx.H, ctx.scale
         B, T, Cn = qw.shape
         hd = Cn // H
-        dqw, dk, dv, dS = _flash_bwd(qw, k, v, bias, kv_len, o, lse, do.contiguous(), H, scale, MASK_XLNET, True)
+        dqw, dk, dv, dS = _flash_bwd(qw, k, v, bd, kv_len, o, lse, do.contiguous(), H, scale, MASK_XLNET_REL, True)
+        del bd
         dbd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
         _lib.check(lib.vilco_relshift_bwd(dS.data_ptr(), dbd.data_ptr(), scale, B, H, T, _stream()))
         del dS
