@@ -87,6 +87,12 @@ typedef struct vilco_gemm_desc {
   /* (forward, dX = dY W and dW = dY^T X).  Only for tap_operand = NONE and batch 1; A / B may then be NULL.        */
   const void* a_planes;
   const void* b_planes;
+  /* XLNet relative-position band (modeling_xlnet_x.py:204-214, 284-325): with T = bandT only the entries          */
+  /* 0 <= p - T + i < T of the [T, 2T] position-score matrix (row i, column p) are ever used / non-zero.            */
+  /*   band 1: C is that matrix (M = T rows i, N = 2T columns p): output tiles wholly outside the band are skipped  */
+  /*           (left unwritten);  band 2: A is that matrix, k = p (M rows i): K-steps outside a tile's band are     */
+  /*           skipped;  band 3: A is its transpose, M rows p, k = i: likewise.  0: dense.                          */
+  int32_t band, bandT;
 } vilco_gemm_desc;
 
 size_t vilco_gemm_workspace(const vilco_gemm_desc* d);
@@ -109,7 +115,15 @@ typedef struct vilco_pack_item {
   int64_t rows, cols, ld;
   void* planes;
   size_t planes_bytes;
+  /* optional: `nbatch` matrices `batch_stride` floats apart (0 / 1 = one matrix); the planes are then            */
+  /* [part][batch][rows32][cols32] and serve batched vilco_gemm calls whose A / B batches are numbered the same   */
+  int32_t nbatch;
+  int64_t batch_stride;
+  /* relshift = 1: pack XLNet's unshifted view [rows][rows + cols] of src[rows][cols] (element (i,p) =            */
+  /* src[i][p - rows + i] or 0): the adjoint of rel_shift_bnij, so dS feeds the position-term gradients directly  */
+  int32_t relshift;
 } vilco_pack_item;
+size_t vilco_pack_item_bytes(const vilco_pack_item* item, int32_t precision);   /* honours nbatch / relshift */
 int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t precision, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */

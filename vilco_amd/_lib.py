@@ -34,12 +34,14 @@ class GemmDesc(C.Structure):
         ("colscale", c_fp), ("residual", c_fp), ("res_masked", i32),
         ("workspace", c_fp), ("workspace_bytes", sz),
         ("a_planes", c_fp), ("b_planes", c_fp),
+        ("band", i32), ("bandT", i32),
     ]
 
 
 class PackItem(C.Structure):
     """Mirror of `vilco_pack_item`."""
-    _fields_ = [("src", c_fp), ("rows", i64), ("cols", i64), ("ld", i64), ("planes", c_fp), ("planes_bytes", sz)]
+    _fields_ = [("src", c_fp), ("rows", i64), ("cols", i64), ("ld", i64), ("planes", c_fp), ("planes_bytes", sz),
+                ("nbatch", i32), ("batch_stride", i64), ("relshift", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/vilco_hip.h declares
@@ -51,6 +53,7 @@ SIGNATURES = {
     "vilco_gemm_profile_begin": (C.c_int, []),
     "vilco_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vilco_pack_bytes": (sz, [i64, i64, i32]),
+    "vilco_pack_item_bytes": (sz, [C.POINTER(PackItem), i32]),
     "vilco_pack": (C.c_int, [c_fp, i64, i64, i64, i32, c_fp, sz, c_fp]),
     "vilco_pack_many": (C.c_int, [C.POINTER(PackItem), i32, i32, c_fp]),
     "vilco_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp]),

@@ -74,6 +74,7 @@ struct GArgs {
   const float* inv_a;       // fp16 x2 format: {1/s, s} of each operand, left by the pack kernels
   const float* inv_b;
   int vec_out;              // N, ldc, batch strides multiples of 4 and every epilogue pointer 16-byte aligned
+  int band, bandT;          // XLNet relative-position band (vilco_gemm_desc.band)
   Epi e;
 };
 
@@ -427,7 +428,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   int kt1 = kt0 + g.kchunk;
   const int nk_all = g.Kp / BK;
   if (kt1 > nk_all) kt1 = nk_all;
-  const int nk = kt1 - kt0;
+  int kb = kt0;
+  if (g.band) {   // block-uniform: relative-position band of this tile (see vilco_gemm_desc.band)
+    const int T = g.bandT;
+    if (g.band == 1) {                     // C[i][p]: rows m0.., columns n0..
+      if (n0 >= 2 * T - m0 || n0 + BN - 1 < T - (m0 + BM - 1)) return;
+    } else {
+      int lo, hi;                          // non-zero k range of the A rows m0 .. m0+BM-1
+      if (g.band == 2) { lo = T - (m0 + BM - 1); hi = 2 * T - m0; }                  // rows i, k = p
+      else { lo = T - (m0 + BM - 1); hi = 2 * T - m0; if (hi > T) hi = T; }         // rows p, k = i in [T-p, 2T-p) /\ [0,T)
+      if (lo < 0) lo = 0;
+      const int b0 = lo / BK, b1 = (hi + BK - 1) / BK;
+      if (b0 > kb) kb = b0;
+      if (b1 < kt1) kt1 = b1;
+      if (kt1 < kb) kt1 = kb;
+    }
+  }
+  const int kt0b = kb;
+  const int nk = kt1 - kt0b;
 
   bf16x8 stA[NP][RA], stB[NP][RB];
   auto gload = [&](int kt) {
@@ -453,9 +471,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   };
 
   if (nk > 0) {
-    gload(kt0);
+    gload(kt0b);
     lstore(0);
-    if (nk > 1) gload(kt0 + 1);
+    if (nk > 1) gload(kt0b + 1);
   }
   __syncthreads();
   STAMPX(1);
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 #ifdef VILCO_LAB_FINE
     STAMP(1);
 #endif
-    if (t + 2 < nk) gload(kt0 + t + 2);
+    if (t + 2 < nk) gload(kt0b + t + 2);
 #ifdef VILCO_LAB_FINE
     STAMP(2);
 #endif
@@ -645,7 +663,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   p.b_out_rows = d->N;
   long a_batch = (long)d->M * p.Kp, b_batch = (long)d->N * p.Kp;
   // k-major consumption instead of a transposing pack: plain (no tap, unbatched) operands, 16-byte aligned rows
-  const bool km_ok = use_pp() && use_km() && d->tap_operand == VILCO_TAP_NONE && d->batch_outer == 1 && d->batch_inner == 1;
+  const bool km_ok = use_pp() && use_km() && d->tap_operand == VILCO_TAP_NONE;
   p.a_km = km_ok && p.a_tr;
   p.b_km = km_ok && p.b_tr;
   if (p.a_km) { p.a_tr = false; p.a_out_rows = p.Kp; a_batch = (long)p.Kp * align_up(d->M, 32); }
@@ -792,40 +810,54 @@ extern "C" size_t vilco_pack_bytes(int64_t rows, int64_t cols, int32_t precision
   return (size_t)(PACK_HDR + align_up(rows > 0 ? rows : 1, 32) * align_up(cols > 0 ? cols : 1, 32) * 2 * np_of_precision(precision));
 }
 
+static inline long item_cols(const vilco_pack_item& it) { return it.relshift ? it.rows + it.cols : it.cols; }
+
+extern "C" size_t vilco_pack_item_bytes(const vilco_pack_item* it, int32_t precision) {
+  if (!it || it->rows <= 0 || it->cols <= 0) return 0;
+  const long nb = it->nbatch > 1 ? it->nbatch : 1;
+  return (size_t)(PACK_HDR + nb * align_up(it->rows, 32) * align_up(item_cols(*it), 32) * 2 * np_of_precision(precision));
+}
+
 extern "C" int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t precision, void* stream) {
   if (!items || n < 1 || n > 4 || precision < 0 || precision > 3) return VILCO_ERR_BADARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int NP = np_of_precision(precision);
   PackArgs4 pk;
   AmaxArgs am;
+  const int nbatch = items[0].nbatch > 1 ? items[0].nbatch : 1;
   for (int i = 0; i < n; ++i) {
     const vilco_pack_item& it = items[i];
     if (!it.src || !it.planes || it.rows <= 0 || it.cols <= 0 || it.ld < it.cols) return VILCO_ERR_BADARG;
-    if (it.rows > 0x7fffffff || it.cols > 0x7fffffff || !vilco_aligned(it.planes, 256)) return VILCO_ERR_BADARG;
-    if (it.planes_bytes < vilco_pack_bytes(it.rows, it.cols, precision)) return VILCO_ERR_WORKSPACE;
-    const long rows32 = align_up(it.rows, 32), cols32 = align_up(it.cols, 32);
+    if (it.rows > 0x7fffffff || it.cols > 0x3fffffff || !vilco_aligned(it.planes, 256)) return VILCO_ERR_BADARG;
+    if ((it.nbatch > 1 ? it.nbatch : 1) != nbatch) return VILCO_ERR_UNSUPPORTED;      // one launch = one batch count
+    if (it.planes_bytes < vilco_pack_item_bytes(&it, precision)) return VILCO_ERR_WORKSPACE;
+    const long cols = item_cols(it);
+    const long rows32 = align_up(it.rows, 32), cols32 = align_up(cols, 32);
     float* hdr = reinterpret_cast<float*>(it.planes);
     PackArgs& pa = pk.a[i];
     pa.src = it.src; pa.dst = reinterpret_cast<__bf16*>(reinterpret_cast<unsigned char*>(it.planes) + PACK_HDR);
-    pa.ld = it.ld; pa.rows = (int)it.rows; pa.K = (int)it.cols; pa.Kp = (int)cols32;
-    pa.plane_stride = rows32 * cols32; pa.batch_stride = rows32 * cols32; pa.nbi = 1; pa.so = 0; pa.si = 0;
-    pa.tap = 0; pa.tapC = 1; pa.tapT = 1; pa.out_rows = (int)rows32;
-    pa.vec = vilco_aligned(it.src, 16) && (it.ld % 4) == 0;
+    pa.ld = it.ld; pa.rows = (int)it.rows; pa.K = (int)cols; pa.Kp = (int)cols32;
+    pa.plane_stride = rows32 * cols32 * nbatch; pa.batch_stride = rows32 * cols32; pa.nbi = nbatch;
+    pa.so = 0; pa.si = nbatch > 1 ? it.batch_stride : 0;
+    pa.tap = it.relshift ? 4 : 0; pa.tapC = it.relshift ? (int)it.cols : 1; pa.tapT = 1; pa.out_rows = (int)rows32;
+    pa.vec = vilco_aligned(it.src, 16) && (it.ld % 4) == 0 && (it.batch_stride % 4) == 0;
     pa.amax = nullptr; pa.namax = 0; pa.inv_scale = hdr + AMAX_MAX_BLOCKS;
     if (precision == 3) {
-      am.op[i] = amax_view(pa, false, 1, hdr);
+      PackArgs src_view = pa;                     // amax runs over the source matrix itself ([rows][cols])
+      src_view.K = (int)it.cols; src_view.tap = 0;
+      am.op[i] = amax_view(src_view, false, 1, hdr);
       pa.amax = hdr; pa.namax = am.op[i].nblocks;
     }
   }
   if (precision == 3) launch_amax(am, n, s);
-  if (n == 1) dispatch_pack(NP, pk.a[0], false, 1, s);
-  else dispatch_pack_multi(NP, pk, n, s);
+  if (n == 1 && nbatch == 1) dispatch_pack(NP, pk.a[0], false, 1, s);
+  else dispatch_pack_multi(NP, pk, n, s, nbatch);
   return vilco_launch_status();
 }
 
 extern "C" int vilco_pack(const float* src, int64_t rows, int64_t cols, int64_t ld, int32_t precision, void* planes,
                           size_t planes_bytes, void* stream) {
-  const vilco_pack_item it = {src, rows, cols, ld, planes, planes_bytes};
+  const vilco_pack_item it = {src, rows, cols, ld, planes, planes_bytes, 1, 0, 0};
   return vilco_pack_many(&it, 1, precision, stream);
 }
 
@@ -839,13 +871,14 @@ extern "C" size_t vilco_gemm_workspace(const vilco_gemm_desc* d) {
 extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (!d || !d->C || (!d->A && !d->a_planes) || (!d->B && !d->b_planes)) return VILCO_ERR_BADARG;
   if (d->a_planes || d->b_planes) {
-    if (d->tap_operand != VILCO_TAP_NONE || d->batch_outer != 1 || d->batch_inner != 1 || !use_pp() || !use_km()) return VILCO_ERR_UNSUPPORTED;
+    if (d->tap_operand != VILCO_TAP_NONE || !use_pp() || !use_km()) return VILCO_ERR_UNSUPPORTED;
     if (!vilco_aligned(d->a_planes, 256) || !vilco_aligned(d->b_planes, 256)) return VILCO_ERR_BADARG;
   }
   if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch_outer < 1 || d->batch_inner < 1) return VILCO_ERR_BADARG;
   if (d->M == 0 || d->N == 0) return VILCO_OK;
   if (d->precision < 0 || d->precision > 3) return VILCO_ERR_BADARG;
   if (d->act < 0 || d->act > 2) return VILCO_ERR_BADARG;
+  if (d->band < 0 || d->band > 3 || (d->band && d->bandT <= 0)) return VILCO_ERR_BADARG;
   if (d->row_len && d->rowT <= 0) return VILCO_ERR_BADARG;
   if (d->a_kcontig == 0 && d->b_kcontig == 1) return VILCO_ERR_UNSUPPORTED;  // "TT" is never needed
   if (d->tap_operand != VILCO_TAP_NONE) {
@@ -909,15 +942,15 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     const unsigned char* u = reinterpret_cast<const unsigned char*>(d->a_planes);
     planesA = reinterpret_cast<__bf16*>(const_cast<unsigned char*>(u) + PACK_HDR);
     inv_a = reinterpret_cast<const float*>(u) + AMAX_MAX_BLOCKS;
-    p.a_plane = p.a_km ? (long)p.Kp * align_up(d->M, 32) : align_up(d->M, 32) * (long)p.Kp;
-    p.a_batch = p.a_plane;
+    p.a_batch = p.a_km ? (long)p.Kp * align_up(d->M, 32) : align_up(d->M, 32) * (long)p.Kp;
+    p.a_plane = p.a_batch * p.a_nbo * p.a_nbi;       // batched planes: [part][batch][rows32][cols32]
   }
   if (!packB) {
     const unsigned char* u = reinterpret_cast<const unsigned char*>(d->b_planes);
     planesB = reinterpret_cast<__bf16*>(const_cast<unsigned char*>(u) + PACK_HDR);
     inv_b = reinterpret_cast<const float*>(u) + AMAX_MAX_BLOCKS;
-    p.b_plane = p.b_km ? (long)p.Kp * align_up(d->N, 32) : align_up(d->N, 32) * (long)p.Kp;
-    p.b_batch = p.b_plane;
+    p.b_batch = p.b_km ? (long)p.Kp * align_up(d->N, 32) : align_up(d->N, 32) * (long)p.Kp;
+    p.b_plane = p.b_batch * p.b_nbo * p.b_nbi;
   }
 
   // ---- MFMA kernel
@@ -939,6 +972,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   g.ntiles = g.tiles_n * ((d->M + p.BM - 1) / p.BM);
   g.ksplit = p.ksplit; g.kchunk = p.kchunk; g.split_stride = p.split_stride;
   g.inv_a = inv_a; g.inv_b = inv_b;
+  g.band = d->band; g.bandT = d->bandT;
   g.vec_out = (d->N % 4) == 0 && (d->ldc % 4) == 0 && (d->sCo % 4) == 0 && (d->sCi % 4) == 0 && vilco_aligned(d->C, 16) &&
               vilco_aligned(d->bias, 16) && vilco_aligned(d->preact, 16) && vilco_aligned(d->colscale, 16) &&
               vilco_aligned(d->residual, 16);

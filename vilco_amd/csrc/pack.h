@@ -77,6 +77,9 @@ struct PackArgs {
   //                  zero) plus zero slack rows; the GEMM reads 3*tapC-wide overlapped spans from it
   //  2 (kc, expand): output row r = [x[t-1] | x[t] | x[t+1]] explicitly (K = 3*tapC), for tapC % 8 != 0
   //  3 (tr, taps):   output row (j*tapC + c), column tok = x[tok + j - 1][c], zero across sequence ends
+  //  4 (kc, relshift): the logical matrix is XLNet's UNSHIFTED [rows][rows + tapC] view of a [rows][tapC] source:
+  //                  element (i, p) = src[i][p - rows + i] when that column exists, else 0 (the adjoint of
+  //                  rel_shift_bnij, modeling_xlnet_x.py:204-214): dS -> d(bd) without materialising it
   int tap, tapC, tapT;
   int out_rows;        // rows written by the kc kernel
   int vec;             // 16-byte aligned source rows
@@ -108,7 +111,19 @@ __device__ __forceinline__ void pack_kc_body(const PackArgs& a, int z, int bx, i
       srow = seq * a.tapT + tt;
       row_ok = tt >= 0 && tt < a.tapT && srow < a.rows;
     }
-    if (a.tap == 2) {
+    if (a.tap == 4) {
+      const long j0 = (long)k0 - a.rows + orow;       // source column of the chunk's first element
+      if (row_ok && j0 >= 0 && j0 + 8 <= a.tapC) {
+        struct __attribute__((packed, aligned(4))) f4u_ { float v[4]; };
+        const f4u_ t0 = *reinterpret_cast<const f4u_*>(src + orow * a.ld + j0);
+        const f4u_ t1 = *reinterpret_cast<const f4u_*>(src + orow * a.ld + j0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = t0.v[e]; v[4 + e] = t1.v[e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (row_ok && j0 + e >= 0 && j0 + e < a.tapC) ? src[orow * a.ld + j0 + e] : 0.f;
+      }
+    } else if (a.tap == 2) {
       const int t = (int)(orow % a.tapT);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {

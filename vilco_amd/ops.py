@@ -64,7 +64,7 @@ def _ws(nbytes, device):
 def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), sB=(0, 0),
          sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
          bias=None, preact=None, act=ACT_NONE, row_len=None, rowT=0, colscale=None, residual=None,
-         res_masked=0, precision=None, a_planes=None, b_planes=None):
+         res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0):
     """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements.  a_planes / b_planes: operands
     already packed by `pack` (the fp32 tensor may then be None)."""
     lib = _lib.load()
@@ -72,6 +72,7 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     d.A = None if A is None else A.data_ptr() + 4 * offA
     d.B = None if B is None else B.data_ptr() + 4 * offB
     d.a_planes, d.b_planes = _p(a_planes), _p(b_planes)
+    d.band, d.bandT = int(band), int(bandT)
     d.C = Cc.data_ptr() + 4 * offC
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.a_kcontig, d.b_kcontig = int(a_kc), int(b_kc)
@@ -108,16 +109,20 @@ def pack(x, rows, cols, precision=None):
     return buf
 
 
-def pack_many(items, precision=None):
-    """[(x, rows, cols), ...] (at most four) packed by the same two launches -> list of plane buffers."""
+def pack_many(items, precision=None, nbatch=1, relshift=False):
+    """[(x, rows, cols), ...] (at most four) packed by the same two launches -> list of plane buffers.
+    nbatch > 1: every x holds `nbatch` contiguous [rows, cols] matrices (planes for batched GEMMs);
+    relshift: pack XLNet's unshifted [rows, rows + cols] view of each matrix (vilco_pack_item.relshift)."""
     lib = _lib.load()
     prec = _precision if precision is None else int(precision)
     arr = (_lib.PackItem * len(items))()
     bufs = []
     for it, (x, rows, cols) in zip(arr, items):
-        nbytes = lib.vilco_pack_bytes(int(rows), int(cols), prec)
+        it.src, it.rows, it.cols, it.ld = x.data_ptr(), int(rows), int(cols), int(cols)
+        it.nbatch, it.batch_stride, it.relshift = int(nbatch), int(rows) * int(cols), int(bool(relshift))
+        nbytes = lib.vilco_pack_item_bytes(C.byref(it), prec)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        it.src, it.rows, it.cols, it.ld, it.planes, it.planes_bytes = x.data_ptr(), int(rows), int(cols), int(cols), buf.data_ptr(), nbytes
+        it.planes, it.planes_bytes = buf.data_ptr(), nbytes
         bufs.append(buf)
     _lib.check(lib.vilco_pack_many(arr, len(items), prec, _stream()))
     return bufs
@@ -728,7 +733,7 @@ class _FlashRelAttention(torch.autograd.Function):
         hd = Cn // H
         bd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
         gemm(qr, kr, bd, T, 2 * T, hd, 1, 1, Cn, Cn, 2 * T, batch=(B, H), sA=(T * Cn, hd), sB=(0, hd),
-             sC=(H * T * 2 * T, T * 2 * T))
+             sC=(H * T * 2 * T, T * 2 * T), band=1, bandT=T)      # only the band p in [T-i, 2T-i) is ever read
         # the flash kernel reads the unshifted scores in place (mask mode 3): no [T,T] bias tensor, no shift pass
         o, lse = _flash_fwd(qw, k, v, bd, kv_len, H, scale, MASK_XLNET_REL)
         ctx.H, ctx.scale = H, scale
@@ -744,16 +749,28 @@ class _FlashRelAttention(torch.autograd.Function):
         hd = Cn // H
         dqw, dk, dv, dS = _flash_bwd(qw, k, v, bd, kv_len, o, lse, do.contiguous(), H, scale, MASK_XLNET_REL, True)
         del bd
-        dbd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
-        _lib.check(lib.vilco_relshift_bwd(dS.data_ptr(), dbd.data_ptr(), scale, B, H, T, _stream()))
-        del dS
         sX, sB2 = (T * Cn, hd), (H * T * 2 * T, T * 2 * T)
         dqr = torch.empty_like(qr)
-        gemm(dbd, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=(0, hd), sC=sX)
-        dkr = torch.zeros_like(kr)
-        for b in range(B):
-            gemm(dbd, qr, dkr, 2 * T, hd, T, 0, 0, 2 * T, Cn, Cn, batch=(1, H), sA=(0, T * 2 * T),
-                 sB=(0, hd), sC=(0, hd), offA=b * H * T * 2 * T, offB=b * T * Cn, beta=1.0)
+        if _reuse_packs:
+            # d(bd) = scale * unshift(dS) is never materialised: ONE pack of dS in the unshifted [T, 2T] view (per b, h)
+            # feeds dqr = d(bd) kr (k-contiguous) and dkr = sum_b d(bd)^T qr (k-major)
+            (pd,) = pack_many([(dS, T, T)], nbatch=B * H, relshift=True)
+            del dS
+            gemm(None, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=(0, hd), sC=sX,
+                 alpha=scale, a_planes=pd, band=2, bandT=T)
+            dkr_b = torch.empty((B,) + tuple(kr.shape), dtype=torch.float32, device=kr.device)
+            gemm(None, qr, dkr_b, 2 * T, hd, T, 0, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=sX,
+                 sC=(2 * T * Cn, hd), alpha=scale, a_planes=pd, band=3, bandT=T)
+            dkr = dkr_b.sum(0) if B > 1 else dkr_b[0]
+        else:
+            dbd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
+            _lib.check(lib.vilco_relshift_bwd(dS.data_ptr(), dbd.data_ptr(), scale, B, H, T, _stream()))
+            del dS
+            gemm(dbd, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=(0, hd), sC=sX)
+            dkr = torch.zeros_like(kr)
+            for b in range(B):
+                gemm(dbd, qr, dkr, 2 * T, hd, T, 0, 0, 2 * T, Cn, Cn, batch=(1, H), sA=(0, T * 2 * T),
+                     sB=(0, hd), sC=(0, hd), offA=b * H * T * 2 * T, offB=b * T * Cn, beta=1.0)
         return dqw, dqr, dk, dv, dkr, None, None, None
 
 
