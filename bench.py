@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="clips per GPU (mq_vilco.yaml: 2)")
     ap.add_argument("--precision", default="f16x2", choices=["split3", "split", "bf16", "f16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-batch", type=int, default=8,
+                    help="also time a few steps at this many clips per GPU (reported beside the headline; 0 = skip)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -270,6 +272,25 @@ def main():
         out["optimizer_step"] = {"ms": opt_ms, "params_with_grad": n_par, "kind": "fused clip_grad_norm + AdamW",
                                  "hbm_GBps": (32.0 * n_par) / (opt_ms * 1e-3) / 1e9,
                                  "train_step_ms_incl_optimizer": ms + opt_ms}
+        if world == 1 and args.extra_batch and args.extra_batch != args.batch:
+            # not the headline (the reference trains with 2 clips per GPU): shows what is launch-bound at batch 2
+            del opt
+            model.zero_grad(set_to_none=True)
+            big = synth_batch(args.extra_batch, dev, seed=1)
+
+            def big_step():
+                model.zero_grad(set_to_none=True)
+                model(big, is_training=True)['final_loss'].backward()
+            for _ in range(3):
+                big_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                big_step()
+            torch.cuda.synchronize()
+            dtb = (time.perf_counter() - t1) / 5
+            out["larger_batch"] = {"clips_per_gpu": args.extra_batch, "ms_per_step": dtb * 1e3,
+                                   "clips_per_s": args.extra_batch / dtb}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
