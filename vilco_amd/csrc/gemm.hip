@@ -1,22 +1,20 @@
-// MFMA GEMM for gfx950 (v2):  C[m][n] = epilogue(alpha * sum_k A(m,k) * B(k,n)),  fp32 in / fp32 out.
+// MFMA GEMM for gfx950:  C[m][n] = epilogue(alpha * sum_k A(m,k) * B(k,n)),  fp32 in / fp32 out.
 //
 // Two stages per call, both on the caller's stream:
-//   1. pack: each fp32 operand is split ONCE into NP bf16 "planes" (x = p0 + p1 + p2, p0 = bf16(x),
-//      p1 = bf16(x - p0), ...) laid out [part][row][Kp], k contiguous, zero padded to Kp = 32*ceil(K/32).
-//      Operands whose contiguous dim is not k (activations in dW = dY^T X, weights in dX = dY W) are transposed
-//      here through an LDS tile, so the MFMA kernel only ever sees the "NT" form.  k=3 convs keep their
-//      overlapped-row trick: the plane gets one zero row before and after every sequence, and row (b,t) of the
-//      A operand is the contiguous span of rows t-1,t,t+1 (K = 3*Cin, row stride Cin): no im2col.
-//   2. gemm_planes_kernel<BM,NP>: tile BM x 128 x 32 (BM = 256 with 8 waves, or 128 with 4), each wave a 64x64
-//      sub-tile = 4x4 v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Planes stream global -> registers -> LDS
-//      (16-byte chunks, no conversion work in the loop), double buffered, one barrier per K-step.  LDS rows are
-//      64 B with a chunk XOR swizzle that makes every ds_read_b128 fragment read conflict free (swz()).
-//      NP=1: 1, NP=2: 3, NP=3: 6 MFMAs per fragment pair (dropped cross terms <= 2^-9, 2^-17, 2^-26).
-//      Optional split-K (grid.y) writes fp32 partials that a reduce kernel sums and finishes (used when the
-//      tile count cannot fill 256 CUs: dW problems, pyramid levels with <= 288 tokens, the 77-token text side).
+//   1. pack (pack.h): each fp32 operand is split ONCE into NP 16-bit "planes" laid out [part][row][cols32] in the
+//      tensor's natural row-major layout -- or arrives already packed (vilco_pack, a_planes / b_planes) and is shared
+//      by every product the tensor appears in.  k=3 convs keep their overlapped-row trick: the plane gets one zero row
+//      before and after every sequence, and row (b,t) of the A operand is the contiguous span of rows t-1,t,t+1
+//      (K = 3*Cin, row stride Cin): no im2col.
+//   2. gemm_pp_kernel<BM,NP,F16,AKM,BKM>: tile BM x 128 x 32 (BM = 256 or 128), 8 waves in two groups that run one
+//      phase apart (ping-pong), each wave a 64x64 (32x64) sub-tile of v_mfma_f32_16x16x32_{f16,bf16}, fp32 accumulate.
+//      Operands are consumed k-contiguous (ds_read_b128 from XOR-swizzled 64-byte rows) or k-major
+//      (ds_read_b64_tr_b16 from [k][R+16] rows).  NP=1: 1, NP=2: 3, NP=3: 6 MFMAs per fragment pair (dropped cross
+//      terms <= 2^-9, 2^-17 / 2^-22 (fp16), 2^-26).  Optional split-K (grid.y) writes fp32 partials that a reduce
+//      kernel sums and finishes.  Epilogue through LDS: 16-byte row-contiguous stores.
 //
-// precision 0 = NP 2 ("split"), 1 = NP 1 (plain bf16), 2 = NP 3 ("split3": numerically an fp32 GEMM),
-// 3 = two fp16 parts of the per-tensor scaled operands ("f16x2": 22 bits, 3 MFMAs; pack.h).
+// precision 0 = NP 2 bf16 ("split"), 1 = NP 1 (plain bf16), 2 = NP 3 bf16 ("split3": numerically an fp32 GEMM),
+// 3 = two fp16 parts of the per-tensor scaled operands ("f16x2": 22 bits, 3 MFMAs; pack.h; the default).
 // Reference arithmetic replaced: see include/vilco_hip.h (vilco_gemm).
 #include <cstdlib>
 #include <utility>
@@ -125,178 +123,17 @@ __device__ __forceinline__ f32x4 mma(const bf16x8& a, const bf16x8& b, const f32
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int BM, int NP, bool F16>
-__global__ __launch_bounds__(BM * 2) void gemm_planes_kernel(GArgs g) {
-  constexpr int NT = BM * 2;                     // threads
-  constexpr int ROWS = BM + BN;                  // staged rows per part (A rows then B rows)
-  constexpr int TILE = ROWS * 32;                // bf16 elements per part per stage
-  constexpr int RA = BM * 4 / NT;                // 16-byte chunks per thread per part: A rows (= 2)
-  constexpr int RB = BN * 4 / NT;                //                                     B rows (1 or 2)
-  static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0, "chunk split");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);   // [stage 2][part NP][ROWS][32]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  int bid = blockIdx.x;
-  {  // XCD-aware tile order (bijective): blocks b, b+8 share an XCD -> give each XCD a contiguous tile run
-    const int nwg = g.ntiles, q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
-  const int ks = blockIdx.y;
-
-  const __bf16* pa = g.a.p + ((long)(g.a.has_o ? zo : 0) * g.a.nbi + (g.a.has_i ? zi : 0)) * g.a.batch_stride;
-  const __bf16* pb = g.b.p + ((long)(g.b.has_o ? zo : 0) * g.b.nbi + (g.b.has_i ? zi : 0)) * g.b.batch_stride;
-
-  // Everything address-like is fixed over the K loop and kept out of it: per-thread chunk offsets (relative to a
-  // wave-uniform base that advances by BK per step), LDS store offsets, and ONE fragment base per operand
-  // (tile rows are only ever added in multiples of 16, under which the swizzle is invariant).
-  long offA[RA], offB[RB];
-  int ldsA[RA], ldsB[RB];
-  const int crow = tid >> 2, cc = tid & 3;
-#pragma unroll
-  for (int r = 0; r < RA; ++r) {
-    const int row = crow + r * (NT / 4);
-    offA[r] = row_off(g.a, m0 + row) + cc * 8;
-    ldsA[r] = lds_off(row, cc);
-  }
-#pragma unroll
-  for (int r = 0; r < RB; ++r) {
-    const int row = crow + r * (NT / 4);
-    offB[r] = row_off(g.b, n0 + row) + cc * 8;
-    ldsB[r] = lds_off(BM + row, cc);
-  }
-  const int fbA = lds_off(wm * 64 + (lane & 15), lane >> 4);
-  const int fbB = lds_off(BM + wn * 64 + (lane & 15), lane >> 4);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int kt0 = ks * g.kchunk;
-  int kt1 = kt0 + g.kchunk;
-  const int nk_all = g.Kp / BK;
-  if (kt1 > nk_all) kt1 = nk_all;
-
-  bf16x8 stA[NP][RA], stB[NP][RB];
-  auto gload = [&](int kt) {
-    const __bf16* ka = pa + (long)kt * BK;       // wave-uniform bases: scalar arithmetic
-    const __bf16* kb = pb + (long)kt * BK;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-#pragma unroll
-      for (int r = 0; r < RA; ++r) stA[q][r] = *reinterpret_cast<const bf16x8*>(ka + q * g.a.plane_stride + offA[r]);
-#pragma unroll
-      for (int r = 0; r < RB; ++r) stB[q][r] = *reinterpret_cast<const bf16x8*>(kb + q * g.b.plane_stride + offB[r]);
-    }
-  };
-  auto lstore = [&](int st) {
-    __bf16* s = smem + st * NP * TILE;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-#pragma unroll
-      for (int r = 0; r < RA; ++r) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsA[r]) = stA[q][r];
-#pragma unroll
-      for (int r = 0; r < RB; ++r) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsB[r]) = stB[q][r];
-    }
-  };
-
-  if (kt0 < kt1) {
-    gload(kt0);
-    lstore(0);
-  }
-  __syncthreads();
-
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int st = (kt - kt0) & 1;
-    if (kt + 1 < kt1) gload(kt + 1);
-    const __bf16* s = smem + st * NP * TILE;
-    // Part-major order: the part-0 fragments are needed first, so the 16 hi*hi MFMAs can start while the
-    // part-1 / part-2 fragments are still streaming out of LDS (all 8 waves hit the LDS right after the barrier).
-    bf16x8 fa[NP][4], fb[NP][4];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + fbA + i * 16 * 32);
-        fb[q][i] = *reinterpret_cast<const bf16x8*>(s + q * TILE + fbB + i * 16 * 32);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = mma<F16>(fa[0][i], fb[0][j], acc[i][j]);
-    if (NP >= 2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j] = mma<F16>(fa[0][i], fb[1][j], acc[i][j]);
-          acc[i][j] = mma<F16>(fa[1][i], fb[0][j], acc[i][j]);
-        }
-    }
-    if (NP == 3) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j] = mma<F16>(fa[1][i], fb[1][j], acc[i][j]);
-          acc[i][j] = mma<F16>(fa[0][i], fb[2][j], acc[i][j]);
-          acc[i][j] = mma<F16>(fa[2][i], fb[0][j], acc[i][j]);
-        }
-    }
-    if (kt + 1 < kt1) lstore(st ^ 1);
-    __syncthreads();
-  }
-
-  if (F16) {   // undo the two per-tensor power-of-two scales (exact)
-    const float inv = g.inv_a[0] * g.inv_b[0];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] *= inv;
-  }
-
-  // epilogue.  C/D layout of mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg
-  const long coff = zo * g.sCo + zi * g.sCi;
-  const bool partial = g.ksplit > 1;
-  float* cp = g.c + (partial ? (long)ks * g.split_stride : 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + rr;
-      if (m >= g.M) continue;
-      bool valid = true;
-      if (!partial && g.e.row_len) valid = (m % g.e.rowT) < g.e.row_len[m / g.e.rowT];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-        if (n >= g.N) continue;
-        const long idx = coff + (long)m * g.ldc + n;
-        if (partial) cp[idx] = acc[i][j][rr];
-        else store_out(g, idx, n, acc[i][j][rr], valid);
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------ ping-pong kernel
-// Same tiles, planes, LDS image and epilogue as gemm_planes_kernel, different schedule: always 8 waves, split into
-// two groups of four (one wave of each group per SIMD) that run ONE PHASE APART.  A K-step is two phases,
+// Schedule: the 8 waves form two groups of four (one wave of each group per SIMD: wave w and w+4 share a SIMD) that
+// run ONE PHASE APART.  A K-step is two phases,
 //   MEM(t):  ds_write the staged registers (tile t+1), re-issue the global loads for tile t+2 into the same registers,
-//            ds_read this wave's fragments of tile t;           MFMA(t):  the wave's MFMAs on those fragments,
-// each closed by a workgroup barrier.  Group 1 executes one extra barrier before its loop (group 0 one after), so while
-// one wave of a SIMD issues its MFMAs back to back the other one does all its LDS / global traffic: the matrix pipe
-// no longer idles through the write -> barrier -> read chain of the one-phase loop (measured there: ~3000 of the
-// ~4800-6000 cycles per K-step).  Hazards: tile t+1 is written in phases 2t (group 0) and 2t+1 (group 1) into the
-// buffer whose last readers (tile t-1) finished in phase 2t-1, and is first read in phase 2t+2.
+//            ds_read this wave's fragments of tile t;           MFMA(t):  the wave's MFMAs on those fragments.
+// Group 0 runs [MEM(t) MFMA(t)] between workgroup barriers, group 1 [MFMA(t-1) MEM(t)]: while one wave of a SIMD
+// issues its MFMAs back to back the other one does all its LDS / global traffic, so the matrix pipe does not idle
+// through the write -> barrier -> read chain of a one-phase loop (measured there with in-kernel stamps: ~3000 of the
+// ~4800-6000 cycles per K-step; here ~2500 cycles per K-step in total).  ONE barrier per K-step, placed exactly where
+// the hazards are: tile t+1 is written during K-step t (by both groups) into the buffer whose last readers (tile t-1)
+// finished before the previous barrier, and is first read after the next one.
 #ifdef VILCO_LAB   // tools/lab only: in-kernel cycle stamps of block 0, waves 0 and 4 (never compiled into the product)
 __device__ unsigned long long vilco_lab_stamps[2 * 64 * 8];
 #define STAMP(i)                                                                                              \
@@ -627,11 +464,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
 
 // ------------------------------------------------------------------------------------------ host side
 inline long align_up(long x, long a) { return (x + a - 1) / a * a; }
-inline bool use_pp() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("VILCO_GEMM_PP"); v = e ? atoi(e) : 1; }
-  return v != 0;
-}
 inline bool use_km() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("VILCO_GEMM_KM"); v = e ? atoi(e) : 1; }
@@ -663,7 +495,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   p.b_out_rows = d->N;
   long a_batch = (long)d->M * p.Kp, b_batch = (long)d->N * p.Kp;
   // k-major consumption instead of a transposing pack: plain (no tap, unbatched) operands, 16-byte aligned rows
-  const bool km_ok = use_pp() && use_km() && d->tap_operand == VILCO_TAP_NONE;
+  const bool km_ok = use_km() && d->tap_operand == VILCO_TAP_NONE;
   p.a_km = km_ok && p.a_tr;
   p.b_km = km_ok && p.b_tr;
   if (p.a_km) { p.a_tr = false; p.a_out_rows = p.Kp; a_batch = (long)p.Kp * align_up(d->M, 32); }
@@ -726,19 +558,6 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   }
   p.split_stride = out_span;
   p.part_bytes = p.ksplit > 1 ? align_up(out_span * p.ksplit * 4, 256) : 0;
-}
-
-template <int BM, int NP, bool F16 = false>
-void launch_gemm(const GArgs& g, dim3 grid, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * NP * (BM + BN) * 32 * sizeof(__bf16);   // up to 144 KiB
-  static const bool once = [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_kernel<BM, NP, F16>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipGetLastError();
-    return true;
-  }();
-  (void)once;
-  hipLaunchKernelGGL((gemm_planes_kernel<BM, NP, F16>), grid, dim3(BM * 2), lds, s, g);
 }
 
 template <int BM, int NP, bool F16, bool AKM, bool BKM>
@@ -871,7 +690,7 @@ extern "C" size_t vilco_gemm_workspace(const vilco_gemm_desc* d) {
 extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (!d || !d->C || (!d->A && !d->a_planes) || (!d->B && !d->b_planes)) return VILCO_ERR_BADARG;
   if (d->a_planes || d->b_planes) {
-    if (d->tap_operand != VILCO_TAP_NONE || !use_pp() || !use_km()) return VILCO_ERR_UNSUPPORTED;
+    if (d->tap_operand != VILCO_TAP_NONE || !use_km()) return VILCO_ERR_UNSUPPORTED;
     if (!vilco_aligned(d->a_planes, 256) || !vilco_aligned(d->b_planes, 256)) return VILCO_ERR_BADARG;
   }
   if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch_outer < 1 || d->batch_inner < 1) return VILCO_ERR_BADARG;
@@ -984,7 +803,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   dim3 grid(g.ntiles, p.ksplit, nz);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
-  if (use_pp()) {
+  {
     const bool ak = p.a_km, bk = p.b_km;
     if (f16) { if (p.BM == 256) launch_pp<256, 2, true>(g, grid, s, ak, bk); else launch_pp<128, 2, true>(g, grid, s, ak, bk); }
     else if (p.BM == 256) {
@@ -996,17 +815,6 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
       else if (p.NP == 2) launch_pp<128, 2>(g, grid, s, ak, bk);
       else launch_pp<128, 3>(g, grid, s, ak, bk);
     }
-  } else if (f16) {
-    if (p.BM == 256) launch_gemm<256, 2, true>(g, grid, s);
-    else launch_gemm<128, 2, true>(g, grid, s);
-  } else if (p.BM == 256) {
-    if (p.NP == 1) launch_gemm<256, 1>(g, grid, s);
-    else if (p.NP == 2) launch_gemm<256, 2>(g, grid, s);
-    else launch_gemm<256, 3>(g, grid, s);
-  } else {
-    if (p.NP == 1) launch_gemm<128, 1>(g, grid, s);
-    else if (p.NP == 2) launch_gemm<128, 2>(g, grid, s);
-    else launch_gemm<128, 3>(g, grid, s);
   }
   if (ev0) { hipEventRecord(ev1, s); prof().ev.emplace_back(ev0, ev1); }
   if (p.ksplit > 1) {
