@@ -377,7 +377,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
     for (int i = 0; i < HDP / 16; ++i) {
       oacc[i][0] *= alpha; oacc[i][1] *= alpha; oacc[i][2] *= alpha; oacc[i][3] *= alpha;
     }
-    __syncthreads();                                // P visible (only this wave reads it; barrier keeps it simple)
+    // P is written and read by this wave only: the LDS queue of a wave is in order, no workgroup barrier needed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // O^T[d][q] += V^T P^T : m-tiles over d, k-steps over the 64 keys
 #pragma unroll
@@ -550,7 +552,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4*>(myS + q * 16 * BKV + off) = pp[q];
     }
-    __syncthreads();
+    // dS is written and read by this wave only (in-order LDS queue): no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // dQ^T[d][q] += K^T dS^T
 #pragma unroll
