@@ -27,18 +27,24 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GFLOP_PER_CLIP_FWD_BWD = 1917.0      # BASELINE.md section 2, config P (measured with FlopCounterMode)
 PEAK_BF16_TFLOPS = 2500.0            # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
-P_XLNET = dict(d_model=1024, n_head=16, d_head=64, d_inner=2048, n_layer=1, dropout=0.0,
+# MQ/configs/xlnet_config_1024.json (dropout 0.1 included)
+P_XLNET = dict(d_model=1024, n_head=16, d_head=64, d_inner=2048, n_layer=1, dropout=0.1,
                layer_norm_eps=1e-12, vocab_size=32000, initializer_range=0.02, attn_type="bi",
                bi_data=False, clamp_len=-1, ff_activation="gelu")
 
 
-def p_config():
+def p_xlnet(dropout=0.1):
+    return dict(P_XLNET, dropout=dropout)
+
+
+def p_config(dropout=0.1, droppath=0.1):
+    """config P with the reference's training regularisation (mq_vilco.yaml:56-57); the property tests pass 0, 0"""
     from vilco_amd.core.config import make_config
     over = dict(dataset=dict(input_dim=2304, num_classes=22, max_seq_len=2304),
                 model=dict(embd_dim=1024, fpn_dim=1024, head_dim=1024, n_head=16, backbone_arch=(2, 2, 5),
                            use_abs_pe=True, use_cross_modal=True, n_txt_in=768, max_buffer_len_factor=1.0,
                            use_xl=True),
-                train_cfg=dict(init_loss_norm=100, dropout=0.0, droppath=0.0))
+                train_cfg=dict(init_loss_norm=100, dropout=dropout, droppath=droppath))
     return make_config(**over)['model']
 
 
@@ -238,7 +244,8 @@ def main():
                                   "3 MFMAs per product), fp32 accumulate: fp32-equivalent"}[args.precision],
                "data": "synthetic",
                "config": {"workload": "MQ ViLCo backbone config P: T=2304 Cin=2304 D=1024 H=16 arch(2,2,5) XLNet layer "
-                                      "(dropout 0) text L=77x768 22 classes, train mode dropout/droppath 0",
+                                      "text L=77x768 22 classes, train mode with the reference's dropout 0.1 / droppath 0.1 "
+                                      "/ XLNet dropout 0.1 (mq_vilco.yaml, xlnet_config_1024.json)",
                           "clips_per_gpu": args.batch, "global_batch": world * args.batch,
                           "parallelism": "dp%d" % world},
                "clips_per_s_per_gpu": clips_per_s / world,

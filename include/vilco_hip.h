@@ -183,22 +183,25 @@ int vilco_relshift_bwd(const float* ds, float* dbd, float scale, int32_t B, int3
 /* MaskedMHCA / MaskedMHA cores (blocks.py:383-400, 251-265) and, with `bias`, XLNet's             */
 /* rel_attn_core (modeling_xlnet_x.py:270-320; bias = scale * rel_shift(bd)).  Scores stay on chip. */
 /* q [B,Tq,H*hd], k/v [B,Tk,H*hd], bias [B,H,Tq,Tk] or null, lse [B,H,Tq] (saved for backward).     */
-/* mask modes as vilco_softmax_fwd; precision as vilco_gemm.  hd <= 64, hd % 4 == 0.                */
+/* mask modes as vilco_softmax_fwd (+ 3: XLNet mask with the bias given as unshifted position scores [B,H,Tq,Tq+Tk]); */
+/* precision as vilco_gemm.  hd <= 64, hd % 4 == 0.  drop_p > 0: inverted dropout on the attention probabilities      */
+/* (after the softmax, before P V) with the counter-based mask of vilco_dropout: element (bh*Tq + i)*Tk + j of stream   */
+/* drop_seed; forward and backward must be given the same (drop_p, drop_seed).                                         */
 /* ------------------------------------------------------------------------------------------ */
 int vilco_attn_supported(int32_t hd);
 /* workspace = bf16 operand planes (q, k natural; v transposed), built inside the call by the pack kernels */
 size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
-                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, void* workspace,
-                   size_t workspace_bytes, void* stream);
+                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, float drop_p,
+                   uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
 size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 /* dq/dk/dv are overwritten; dbias (optional, [B,H,Tq,Tk]) receives dS.  Deterministic (no atomics). */
 int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, const float* o, const float* lse, const float* dout,
                    float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
-                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, float drop_p,
+                   uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Elementwise / reduction glue of TransformerBlock.forward (blocks.py:561-593).                 */
@@ -214,6 +217,10 @@ int vilco_scale_add_bwd(const float* dout, const float* bval, const float* colsc
                         const float* rowscale, const int32_t* len, int32_t mask_a, float* da,
                         float* db, float* dcolscale, int32_t B, int32_t T, int32_t C,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* Inverted dropout y = keep ? x/(1-p) : 0 with a counter-based mask (element i of the stream `seed` at `offset + i`):   */
+/* the backward pass is the same call on dy.  x = NULL writes the mask factors (0 or 1/(1-p)) -- what the parity tests  */
+/* hand to the oracle.  nn.Dropout in modeling_xlnet_x.py:308,327,486,488,1201,1228,1280 and blocks.py:226,268,349.      */
+int vilco_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream);
 /* out = alpha*a + beta*b (b may be null) */
 int vilco_axpby(float* out, const float* a, const float* b, float alpha, float beta, int64_t n,
                 void* stream);

@@ -144,11 +144,17 @@ def transformer_block(p, pre, x, mask, n_head, stride, t_c_alpha, cross_y=None, 
 
 
 # ------------------------------------------------------------------------------ XLNet layer
-def xlnet_layer(p, pre, x, mask, n_head):
-    """XLNetModel.forward (bi, no mems / segments / target mapping; eval mode) for one layer:
+def xlnet_layer(p, pre, x, mask, n_head, drop=None):
+    """XLNetModel.forward (bi, no mems / segments / target mapping) for one layer:
     modeling_xlnet_x.py:1075-1308, rel_attn :437-461 -> rel_attn_core :270-320, post_attention :322-332,
-    XLNetFeedForward :482-490.  x [B,T,D], mask [B,T] (1 = valid) -> [B,T,D]."""
+    XLNetFeedForward :482-490.  x [B,T,D], mask [B,T] (1 = valid) -> [B,T,D].
+    drop: None (eval / p = 0) or a dict of dropout MASK FACTORS (0 or 1/(1-p)) for the reference's seven nn.Dropout
+    sites, in batch-major layouts: 'xl_input' [B,T,D] (:1201), 'xl_pos_emb' [B,2T,D] (:1228), 'attn_prob' [B,H,T,T]
+    (:308), 'xl_attn_out' [B,T,D] (:327), 'xl_ff_inner' [B,T,d_inner] (:486), 'xl_ff_out' [B,T,D] (:488),
+    'xl_output' [B,T,D] (:1280)."""
     B, T, D = x.shape
+    dm = (lambda k, t: t) if drop is None else (lambda k, t: t * drop[k].to(t.dtype))
+    x = dm('xl_input', x)
     h = x.transpose(0, 1)                                           # [T,B,D]
     att = mask.transpose(0, 1).to(x.dtype)                          # [T,B]
     data_mask = (1.0 - att)[None]                                   # [1,T,B]
@@ -160,6 +166,8 @@ def xlnet_layer(p, pre, x, mask, n_head):
     pos_seq = torch.arange(T, -T, -1.0, dtype=torch.float)
     sinus = torch.einsum("i,d->id", pos_seq, inv_freq)
     pos_emb = torch.cat([torch.sin(sinus), torch.cos(sinus)], dim=-1)[:, None, :].expand(-1, B, -1).to(x.dtype)
+    if drop is not None:
+        pos_emb = pos_emb * drop['xl_pos_emb'].to(x.dtype).transpose(0, 1)
 
     a = pre + 'rel_attn.'
     q = torch.einsum("ibh,hnd->ibnd", h, p[a + 'q'])
@@ -173,15 +181,18 @@ def xlnet_layer(p, pre, x, mask, n_head):
     bd = torch.index_select(bd, 3, torch.arange(T, dtype=torch.long))
     d_head = p[a + 'q'].shape[-1]
     score = (ac + bd) * (1 / (d_head ** 0.5)) - 1e30 * torch.einsum("ijbn->bnij", non_tgt)
-    prob = F.softmax(score, dim=3)
+    prob = dm('attn_prob', F.softmax(score, dim=3))
     vec = torch.einsum("bnij,jbnd->ibnd", prob, v)
-    out = torch.einsum("ibnd,hnd->ibh", vec, p[a + 'o']) + h
+    out = torch.einsum("ibnd,hnd->ibh", vec, p[a + 'o'])
+    out = dm('xl_attn_out', out.transpose(0, 1)).transpose(0, 1) + h
     out = F.layer_norm(out, (D,), p[a + 'layer_norm.weight'], p[a + 'layer_norm.bias'], 1e-12)
     f = pre + 'ff.'
-    y = F.linear(F.gelu(F.linear(out, p[f + 'layer_1.weight'], p[f + 'layer_1.bias'])),
-                 p[f + 'layer_2.weight'], p[f + 'layer_2.bias'])
+    y = F.gelu(F.linear(out, p[f + 'layer_1.weight'], p[f + 'layer_1.bias']))
+    y = dm('xl_ff_inner', y.transpose(0, 1)).transpose(0, 1)
+    y = F.linear(y, p[f + 'layer_2.weight'], p[f + 'layer_2.bias'])
+    y = dm('xl_ff_out', y.transpose(0, 1)).transpose(0, 1)
     y = F.layer_norm(y + out, (D,), p[f + 'layer_norm.weight'], p[f + 'layer_norm.bias'], 1e-12)
-    return y.permute(1, 0, 2).contiguous()
+    return dm('xl_output', y.permute(1, 0, 2).contiguous())
 
 
 # ------------------------------------------------------------------------------ model

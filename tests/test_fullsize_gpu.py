@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 def _model_and_batch(dev):
     import bench
     import vilco_amd.modeling as vm
-    cfg = bench.p_config()
+    cfg = bench.p_config(dropout=0.0, droppath=0.0)      # the properties below need a deterministic step
     torch.manual_seed(0)
-    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.P_XLNET)).to(dev).train()
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet(0.0))).to(dev).train()
     return model, bench.synth_batch(2, dev), cfg
 
 
@@ -97,3 +97,29 @@ def test_nms_full_size_vs_reference_build(dev):
         assert torch.equal(keep, ref.nms(segs, scores, 0.5))
         rdets = torch.zeros(n, 3)
         assert torch.equal(sidx, ref.softnms(segs, scores, rdets, 0.1, 0.75, 0.01, 2))
+
+
+def test_p_config_step_with_reference_dropout(dev):
+    """the benchmark workload itself (dropout 0.1, droppath 0.1, XLNet dropout 0.1 as in mq_vilco.yaml /
+    xlnet_config_1024.json): finite losses and gradients, masks differ between steps, eval mode is deterministic."""
+    import bench
+    import vilco_amd.modeling as vm
+    from vilco_amd import ops
+    cfg = bench.p_config()
+    torch.manual_seed(0)
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet())).to(dev).train()
+    batch = bench.synth_batch(2, dev)
+    vals = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        ops.dropout_log = []
+        try:
+            out = model(batch, is_training=True)
+            out['final_loss'].backward()
+            sites = [e[0] for e in ops.dropout_log]
+        finally:
+            ops.dropout_log = None
+        assert sites.count('attn_prob') >= 1 and 'xl_pos_emb' in sites and 'proj_drop' in sites and 'mlp_drop' in sites
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        vals.append(float(out['final_loss']))
+    assert np.isfinite(vals).all() and vals[0] != vals[1]

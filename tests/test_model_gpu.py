@@ -213,3 +213,52 @@ def test_sync_free_losses_match_gather_losses(dev):
     assert ga.keys() == gb.keys()
     for k in ga:
         assert rel_err(gb[k], ga[k], 1e-6) < 2e-5, k     # floor: analytically-zero key-bias gradients are 1e-12 noise
+
+
+def test_xlnet_dropout_matches_oracle_with_same_masks(dev):
+    """XLNet's seven nn.Dropout sites (p = 0.1 in the reference's xlnet_config_*.json) in training mode: the HIP path
+    draws counter-based masks; the fp64 oracle, given exactly those masks (rebuilt from ops.dropout_log through
+    vilco_dropout), must produce the same output and the same gradients for the input and every parameter."""
+    from vilco_amd import ops
+    from vilco_amd.modeling.modeling_xlnet_x import XLNetConfig, XLNetModel
+    from oracle import mq_oracle as O
+    torch.manual_seed(21)
+    B, T, D, H = 2, 96, 64, 4
+    model = XLNetModel(XLNetConfig(d_model=D, n_head=H, d_inner=128, n_layer=1, dropout=0.1)).to(dev).train()
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.mul_(8.0)                      # initializer_range 0.02 would leave the attention nearly uniform
+    x = torch.randn(B, T, D, device=dev, requires_grad=True)
+    lens = torch.tensor([T, T - 11], dtype=torch.int32, device=dev)
+    wgt = torch.randn(B, T, D, device=dev)
+    ops.dropout_log = []
+    try:
+        out = model.forward_tm(x, lens)
+        (out * wgt).sum().backward()
+        log = list(ops.dropout_log)
+    finally:
+        ops.dropout_log = None
+    assert [e[0] for e in log] == ['xl_input', 'xl_pos_emb', 'attn_prob', 'xl_attn_out', 'xl_ff_inner', 'xl_ff_out',
+                                   'xl_output']
+    masks = {site: ops.dropout_mask(p, seed, shape, dev).double().cpu() for site, p, seed, shape in log}
+    for m in masks.values():                  # inverted dropout: factors are 0 or 1/(1-p), about 10 % zeros
+        assert set(torch.unique(m.float()).tolist()) <= {0.0, float(torch.tensor(1.0 / (1.0 - 0.1), dtype=torch.float32))}
+        assert 0.05 < float((m == 0).double().mean()) < 0.15
+    p64 = {'layer.0.' + k: v.detach().double().cpu().requires_grad_(True) for k, v in model.layer[0].state_dict().items()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    mask = (torch.arange(T)[None, :] < lens.cpu()[:, None]).long()
+    want = O.xlnet_layer(p64, 'layer.0.', x64, mask, H, drop=masks)
+    (want * wgt.double().cpu()).sum().backward()
+    assert rel_err(out, want) < 1e-4
+    assert rel_err(x.grad, x64.grad) < 1e-3
+    for k, v in model.layer[0].named_parameters():
+        if p64['layer.0.' + k].grad is not None:
+            assert rel_err(v.grad, p64['layer.0.' + k].grad, 1e-6) < 1e-3, k
+    # eval mode draws nothing
+    ops.dropout_log = []
+    try:
+        model.eval()
+        model.forward_tm(x.detach(), lens)
+        assert ops.dropout_log == []
+    finally:
+        ops.dropout_log = None

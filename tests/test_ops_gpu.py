@@ -348,3 +348,73 @@ def test_channel_attention(dev):
         o = (att @ q.transpose(-1, -2)).transpose(-1, -2)
         return o.transpose(1, 2).reshape(B, T, C)
     run_pair(lambda qkv: ops.channel_attention(qkv, H, scale), ref, dict(qkv=qkv), dev, TOL_GEMM)
+
+
+def test_dropout_op(dev):
+    from vilco_amd import ops
+    torch.manual_seed(31)
+    x = torch.randn(3, 50, 40, device=dev, requires_grad=True)
+    ops.dropout_log = []
+    try:
+        y = ops.dropout(x, 0.25, True, "t")
+        (site, p, seed, shape), = ops.dropout_log
+    finally:
+        ops.dropout_log = None
+    m = ops.dropout_mask(p, seed, shape, dev)
+    assert torch.equal(y, x * m)
+    assert abs(float((m == 0).float().mean()) - 0.25) < 0.03
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.equal(x.grad, g * m)
+    assert ops.dropout(x, 0.25, False) is x and ops.dropout(x, 0.0, True) is x
+    y2 = ops.dropout(x, 0.25, True)                      # a new call draws a new mask
+    assert not torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("T,hd", [(100, 16), (130, 64)])
+def test_attention_prob_dropout(dev, T, hd):
+    """attention with dropout on the probabilities == reference attention with the same mask (fwd + grads)."""
+    from vilco_amd import ops
+    torch.manual_seed(32)
+    B, H = 2, 2
+    C = H * hd
+    q, k, v = [torch.randn(B, T, C, device=dev, requires_grad=True) for _ in range(3)]
+    lens = torch.tensor([T, T - 9], dtype=torch.int32, device=dev)
+    ops.dropout_log = []
+    try:
+        o = ops.attention(q, k, v, lens, H, 0.3, drop_p=0.2)
+        (site, p, seed, shape), = ops.dropout_log
+    finally:
+        ops.dropout_log = None
+    assert shape == (B, H, T, T)
+    m = ops.dropout_mask(p, seed, shape, dev).double().cpu()
+    g = torch.randn(B, T, C)
+    o.backward(g.to(dev))
+    qd, kd, vd = [t.detach().double().cpu().requires_grad_(True) for t in (q, k, v)]
+    qh, kh, vh = [t.view(B, T, H, hd).transpose(1, 2) for t in (qd, kd, vd)]
+    s = (qh * 0.3) @ kh.transpose(-2, -1)
+    km = (torch.arange(T)[None, :] < lens.cpu()[:, None])[:, None, None, :]
+    pr = torch.softmax(s.masked_fill(~km, float('-inf')), dim=-1) * m
+    want = (pr @ vh).transpose(1, 2).reshape(B, T, C)
+    want.backward(g.double())
+    assert rel(o, want) < TOL_GEMM
+    for a, b in ((q, qd), (k, kd), (v, vd)):
+        assert rel(a.grad, b.grad) < TOL_GEMM
+
+
+def test_attention_zero_upstream_gradient(dev):
+    """dO == 0 for the whole tensor (a clip dropped by stochastic depth): the fp16x2 operand scale of dO is then 2^126;
+    every gradient must come out exactly zero, not inf * 0."""
+    from vilco_amd import ops
+    torch.manual_seed(33)
+    B, T, H, hd = 2, 96, 2, 64
+    q, k, v = [torch.randn(B, T, H * hd, device=dev, requires_grad=True) for _ in range(3)]
+    lens = torch.tensor([T, T - 5], dtype=torch.int32, device=dev)
+    o = ops.attention(q, k, v, lens, H, 0.125)
+    o.backward(torch.zeros_like(o))
+    for t in (q, k, v):
+        assert torch.count_nonzero(t.grad) == 0
+    x, w = torch.zeros(64, 32, device=dev, requires_grad=True), torch.randn(16, 32, device=dev, requires_grad=True)
+    y = ops.linear(x, w)
+    y.backward(torch.zeros_like(y))
+    assert torch.count_nonzero(y) == 0 and torch.count_nonzero(w.grad) == 0 and torch.count_nonzero(x.grad) == 0

@@ -10,7 +10,7 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 cfg = bench.p_config()
 torch.manual_seed(0)
-model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.P_XLNET)).to(dev).train()
+model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet())).to(dev).train()
 batch = bench.synth_batch(2, dev)
 
 def step():

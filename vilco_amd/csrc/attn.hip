@@ -189,6 +189,9 @@ struct AttnArgs {
   // 16-bit planes (natural [tok][HDP] and transposed [d][Tp]) of k, v, q, dout
   Planes kn, vn, kt, vt, qn, don, qt, dot;
   const AttnScales* sc;   // fp16 x2 mode only
+  // dropout on the attention probabilities (modeling_xlnet_x.py:308, blocks.py:226): keep iff hash(seed, (bh*Tq+i)*Tk+j) >= thresh
+  uint32_t drop_thresh, drop_seed;
+  float drop_inv_keep;
 };
 
 // registers holding the B-operand fragments of this wave's 16 query rows (all k-steps, all parts)
@@ -237,6 +240,15 @@ __device__ __forceinline__ void bias4(float (&bv)[4], const float* bias, int i, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = jb + r < a.Tk ? bias_at(bias, i, jb + r, ld, a) : 0.f;
   }
+}
+
+// dropout keep flag (0 or 1) of attention probability (bh, i, j).  The kernels work with the 0/1 flag and apply the
+// 1/(1-p) of inverted dropout to their outputs: O = inv_keep * (P.M) V, dV = inv_keep * dO^T (P.M), and
+// dS = P (inv_keep M dP - delta) = inv_keep * P (M dP - (1-p) delta), so nothing that enters an MFMA grows beyond its
+// undropped bound (the fp16 operand scales of P and dS stay valid for any p).
+__device__ __forceinline__ float drop_keep(const AttnArgs& a, int bh, int i, int j) {
+  const uint64_t idx = ((uint64_t)bh * (uint64_t)a.Tq + (uint64_t)i) * (uint64_t)a.Tk + (uint64_t)j;
+  return vilco_drop_hash(a.drop_seed, idx) >= a.drop_thresh ? 1.f : 0.f;
 }
 
 // score of (query i, key j) after scale + bias: apply the mask
@@ -316,6 +328,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         if (qi < a.Tq) bias4(bvt[mi], bias, qi, k0 + mi * 16 + (lane >> 4) * 4, bias_ld, a);
       }
     }
+    unsigned keep_bits = 0xffffu;          // dropout keep flags of this lane's 16 (mi, r) probabilities
+    if (a.drop_thresh) {
+      keep_bits = 0u;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          keep_bits |= (drop_keep(a, bh, qi, k0 + mi * 16 + (lane >> 4) * 4 + r) != 0.f ? 1u : 0u) << (mi * 4 + r);
+    }
     // S^T[key][q] = K Q^T : 4 m-tiles of 16 keys, this wave's 16 queries
     f32x4 s[4];
 #pragma unroll
@@ -359,7 +380,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         p[r] = dead ? 0.f : fast_exp(s[mi][r] - m_new);
-        psum += p[r];
+        psum += p[r];                                   // the softmax denominator is over the undropped probabilities
+        if (!((keep_bits >> (mi * 4 + r)) & 1u)) p[r] = 0.f;
         if (F16) p[r] *= P_SCALE;
       }
       bf16x4 pp[3];
@@ -399,7 +421,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 
   // finish: lane holds query qi, channels di*16 + 4*(lane>>4) + r
   if (qi < a.Tq) {
-    const float inv = (l_run > 0.f ? 1.f / l_run : 0.f) * (F16 ? P_INV * sc.iv : 1.f);
+    const float inv = (l_run > 0.f ? 1.f / l_run : 0.f) * (F16 ? P_INV * sc.iv : 1.f) * a.drop_inv_keep;
     float* og = a.o + ((long)b * a.Tq + qi) * ld + h * a.hd;
 #pragma unroll
     for (int di = 0; di < HDP / 16; ++di) {
@@ -462,14 +484,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   if (F16) sc = *a.sc;
   const float qk_scale = F16 ? a.scale * sc.iq * sc.ik : a.scale;
   // fp16 x2: dp stays in plane units (dP * sdO * sV), delta is brought there, and dS' = P (dp - delta') * 2^-22
-  const float dl_scale = F16 ? sc.sdo * sc.sv : 1.f;
-  const float ds_unscale = F16 ? DS_INV * sc.ido * sc.iv : 1.f;       // dS = dS' * this
+  const float ds_unscale = (F16 ? DS_INV * sc.ido * sc.iv : 1.f) * a.drop_inv_keep;       // dS = dS' * this
 
   QFrag<HDP, NP> qf, dof;
   load_qfrag<HDP, NP>(qf, a.qn, a.qn.p + (long)bh * a.qn.batch_stride, q0, lane);
   load_qfrag<HDP, NP>(dof, a.don, a.don.p + (long)bh * a.don.batch_stride, q0, lane);
   const float lse = qi < a.Tq ? a.lse[row_bh + qi] : 0.f;
-  const float dlt = (qi < a.Tq ? a.delta[row_bh + qi] : 0.f) * dl_scale;
+  // (1-p) delta in plane units.  Multiplied by the two scales one after the other: their product alone overflows fp32
+  // when both tensors are tiny or zero (a clip dropped by stochastic depth has dO == 0 -> s = 2^126), delta * sdO does not
+  const float dlt = F16 ? ((qi < a.Tq ? a.delta[row_bh + qi] : 0.f) * sc.sdo) * sc.sv / a.drop_inv_keep
+                        : (qi < a.Tq ? a.delta[row_bh + qi] : 0.f) / a.drop_inv_keep;
 
   f32x4 dqacc[HDP / 16];
 #pragma unroll
@@ -510,6 +534,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
         if (qi < a.Tq) bias4(bvt[mi], bias, qi, k0 + mi * 16 + (lane >> 4) * 4, bias_ld, a);
       }
     }
+    unsigned keep_bits = 0xffffu;          // dropout keep flags of this lane's 16 (mi, r) probabilities
+    if (a.drop_thresh) {
+      keep_bits = 0u;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          keep_bits |= (drop_keep(a, bh, qi, k0 + mi * 16 + (lane >> 4) * 4 + r) != 0.f ? 1u : 0u) << (mi * 4 + r);
+    }
 
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -532,7 +565,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
         float x = s[r] * qk_scale;
         if (!plain) x = mask_score(x + (bias ? bvt[mi][r] : 0.f), qi, jb + r, len, a.Tk, mmode);
         const float p = (x == -INFINITY) ? 0.f : fast_exp(x - lse);
-        ds[r] = p * (dp[r] - dlt);
+        const float dpr = ((keep_bits >> (mi * 4 + r)) & 1u) ? dp[r] : 0.f;
+        ds[r] = p * (dpr - dlt);
         if (F16) ds[r] *= DS_SCALE;
       }
       if (dbias && qi < a.Tq) {
@@ -552,9 +586,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4*>(myS + q * 16 * BKV + off) = pp[q];
     }
-    // dS is written and read by this wave only (in-order LDS queue): no workgroup barrier
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
 
     // dQ^T[d][q] += K^T dS^T
 #pragma unroll
@@ -621,8 +653,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
   AttnScales sc = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   if (F16) sc = *a.sc;
   const float qk_scale = F16 ? a.scale * sc.iq * sc.ik : a.scale;
-  const float dl_scale = F16 ? sc.sdo * sc.sv : 1.f;
-  const float ds_unscale = F16 ? DS_INV * sc.ido * sc.iv : 1.f;
+  const float ds_unscale = (F16 ? DS_INV * sc.ido * sc.iv : 1.f) * a.drop_inv_keep;
 
   {
     TileStage<HDP, BKV, NP> st;
@@ -672,7 +703,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
     for (int r = 0; r < 4; ++r) {
       const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r;
       lse4[r] = qi < a.Tq ? a.lse[row_bh + qi] : 0.f;
-      dl4[r] = (qi < a.Tq ? a.delta[row_bh + qi] : 0.f) * dl_scale;
+      const float dl_ = qi < a.Tq ? a.delta[row_bh + qi] : 0.f;
+      dl4[r] = (F16 ? (dl_ * sc.sdo) * sc.sv : dl_) / a.drop_inv_keep;      // see attn_bwd_dq_kernel: never form sdO * sV
     }
     float bvt[2][4];
     if (bias) {
@@ -683,6 +715,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
           const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r, j = k0 + kh * 32 + nj * 16 + (lane & 15);
           bvt[nj][r] = (qi < a.Tq && j < a.Tk) ? bias_at(bias, qi, j, bias_ld, a) : 0.f;
         }
+    }
+    unsigned keep_bits = 0xffu;            // dropout keep flags of this lane's 8 (nj, r) probabilities
+    if (a.drop_thresh) {
+      keep_bits = 0u;
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          keep_bits |= (drop_keep(a, bh, q0 + mq * 16 + (lane >> 4) * 4 + r, k0 + kh * 32 + nj * 16 + (lane & 15)) != 0.f ? 1u : 0u)
+                       << (nj * 4 + r);
     }
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
@@ -711,7 +753,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
           x = mask_score(x + (bias ? bvt[nj][r] : 0.f), qi, j, len, a.Tk, mmode);
         }
         p[r] = (qi < a.Tq && x != -INFINITY) ? fast_exp(x - lse4[r]) : 0.f;
-        ds[r] = p[r] * (dp[r] - dl4[r]);
+        const float mf = ((keep_bits >> (nj * 4 + r)) & 1u) ? 1.f : 0.f;
+        ds[r] = p[r] * (dp[r] * mf - dl4[r]);
+        p[r] *= mf;                                      // dV sees the dropped probabilities
         if (F16) { ds[r] *= DS_SCALE; p[r] *= P_SCALE; }
       }
       bf16x4 pp[3], dd[3];
@@ -759,7 +803,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
       for (int r = 0; r < 4; ++r) {
         if (d + r < a.hd) {
           gk[d + r] = dkacc[di][r] * (a.scale * ds_unscale * sc.iq);
-          gv[d + r] = dvacc[di][r] * (F16 ? P_INV * sc.ido : 1.f);
+          gv[d + r] = dvacc[di][r] * ((F16 ? P_INV * sc.ido : 1.f) * a.drop_inv_keep);
         }
       }
     }
@@ -897,9 +941,10 @@ extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int
 
 extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                               const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
-                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, float drop_p,
+                              uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision);
+  if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
   if (!q || !k || !v || !o || !lse) return VILCO_ERR_BADARG;
   if (mode != 2 && !kv_len) return VILCO_ERR_BADARG;
@@ -911,6 +956,7 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.lse = lse; a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
+  a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
   unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
   ScaleWs sw = {};
   if (precision == 3) {
@@ -941,9 +987,10 @@ extern "C" size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int
 extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* bias,
                               const int32_t* kv_len, const float* o, const float* lse, const float* dout,
                               float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
-                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, float drop_p,
+                              uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision);
+  if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
   if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv) return VILCO_ERR_BADARG;
   if (mode != 2 && !kv_len) return VILCO_ERR_BADARG;
@@ -962,6 +1009,7 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.lse = const_cast<float*>(lse); a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
+  a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
   a.dout = dout; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
   ScaleWs sw = {};
   if (precision == 3) {

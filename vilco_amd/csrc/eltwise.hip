@@ -342,6 +342,23 @@ extern "C" int vilco_scale_add_bwd(const float* dout, const float* bval, const f
   return vilco_launch_status();
 }
 
+// y = keep ? x / (1-p) : 0   (x null: the mask factors themselves, for tests);  in place allowed
+__global__ __launch_bounds__(EW_THREADS) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                             uint32_t thresh, float inv_keep, uint32_t seed, uint64_t offset) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const bool keep = vilco_drop_hash(seed, offset + (uint64_t)i) >= thresh;
+    y[i] = keep ? (x ? x[i] : 1.f) * inv_keep : 0.f;
+  }
+}
+
+extern "C" int vilco_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream) {
+  if (!y || n < 0 || !(p >= 0.f) || p >= 1.f) return VILCO_ERR_BADARG;
+  if (n == 0) return VILCO_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x, y,
+                     (long)n, vilco_drop_threshold_host(p), 1.f / (1.f - p), seed, offset);
+  return vilco_launch_status();
+}
+
 extern "C" int vilco_axpby(float* out, const float* a, const float* b, float alpha, float beta,
                            int64_t n, void* stream) {
   if (!out || !a || n < 0) return VILCO_ERR_BADARG;

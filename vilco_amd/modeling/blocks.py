@@ -158,13 +158,14 @@ class MaskedMHA(nn.Module):
         self.proj = nn.Conv1d(n_embd, n_embd, 1)
 
     def forward_tm(self, x, lens, enc=None, enc_lens=None):
-        _no_dropout(self, self.attn_drop, self.proj_drop)
         src, src_lens = (x, lens) if enc is None else (enc, enc_lens)
         q = ops.linear(x, self.query.weight, self.query.bias)
         k = ops.linear(src, self.key.weight, self.key.bias)
         v = ops.linear(src, self.value.weight, self.value.bias)
-        o = ops.attention(q, k, v, src_lens, self.n_head, self.scale)
-        return ops.linear(o, self.proj.weight, self.proj.bias, ACT_NONE, lens, x.shape[1]), lens
+        o = ops.attention(q, k, v, src_lens, self.n_head, self.scale,
+                          drop_p=self.attn_drop.p if self.training else 0.0)            # attn_drop (blocks.py:253)
+        out = ops.linear(o, self.proj.weight, self.proj.bias, ACT_NONE, lens, x.shape[1])
+        return ops.dropout(out, self.proj_drop.p, self.training, "proj_drop"), lens     # proj_drop (:264)
 
     def forward(self, x, mask, encoder_hidden_states=None, encoder_attention_mask=None):
         lens = mask_to_lens(mask)
@@ -207,7 +208,6 @@ class MaskedMHCA(nn.Module):
         self.proj = nn.Conv1d(n_embd, n_embd, 1)
 
     def forward_tm(self, x, lens):
-        _no_dropout(self, self.attn_drop, self.proj_drop)
         q, q_lens = self.query_conv.forward_tm(x, lens)
         q = self.query_norm.forward_tm(q)
         k, kv_lens = self.key_conv.forward_tm(x, lens)
@@ -217,9 +217,10 @@ class MaskedMHCA(nn.Module):
         q = ops.linear(q, self.query.weight, self.query.bias)
         k = ops.linear(k, self.key.weight, self.key.bias)
         v = ops.linear(v, self.value.weight, self.value.bias)
-        o = ops.attention(q, k, v, kv_lens, self.n_head, self.scale)
+        o = ops.attention(q, k, v, kv_lens, self.n_head, self.scale,
+                          drop_p=self.attn_drop.p if self.training else 0.0)            # attn_drop (blocks.py:394)
         out = ops.linear(o, self.proj.weight, self.proj.bias, ACT_NONE, q_lens, q.shape[1])
-        return out, q_lens
+        return ops.dropout(out, self.proj_drop.p, self.training, "proj_drop"), q_lens   # proj_drop (:405)
 
     def forward(self, x, mask):
         T = x.shape[-1]
@@ -308,12 +309,6 @@ class AffineDropPath(nn.Module):
         return y if rs is None else y * rs.view(-1, 1, 1)
 
 
-def _no_dropout(mod, *drops):
-    for d in drops:
-        if mod.training and d.p > 0.0:
-            raise NotImplementedError("dropout p>0 in training mode is not implemented on the HIP path yet")
-
-
 class TransformerBlock(nn.Module):
     """conv-attention block with optional text cross-attention, MLP and the channel-attention mix
     (blocks.py:468-593).  ln3 and drop_path_attn are shared by the self and cross paths, as in the
@@ -371,7 +366,6 @@ class TransformerBlock(nn.Module):
         return None, None
 
     def forward_tm(self, x, lens, cross_y=None, cross_lens=None):
-        _no_dropout(self, self.mlp[2], self.mlp[4])
         h = self.ln1.forward_tm(x)
         a, out_lens = self.attn.forward_tm(h, lens)
         if self.adapters is not None and "attn" in self.adapters:
@@ -386,7 +380,9 @@ class TransformerBlock(nn.Module):
             out = ops.scale_add(out, c, cs, rs, out_lens, mask_a=True)
         T2 = out.shape[1]
         m = ops.linear(self.ln2.forward_tm(out), self.mlp[0].weight, self.mlp[0].bias, ACT_GELU)
+        m = ops.dropout(m, self.mlp[2].p, self.training, "mlp_drop")                    # blocks.py:533-540
         m = ops.linear(m, self.mlp[3].weight, self.mlp[3].bias, ACT_NONE, out_lens, T2)
+        m = ops.dropout(m, self.mlp[4].p, self.training, "mlp_drop")
         cs, rs = self._dp(self.drop_path_mlp, m)
         out = ops.scale_add(out, m, cs, rs)
         if self.n_ds_strides[0] == 1 and self.n_ds_strides[1] == 1:

@@ -63,10 +63,12 @@ class XLNetRelativeAttention(nn.Module):
         q_r = ops.linear_kn(h, self.q, self.r_r_bias)        # q + r_r_bias (position stream)
         k = ops.linear_kn(h, self.k)
         v = ops.linear_kn(h, self.v)
-        k_r = ops.linear_kn(pos_emb, self.r)                 # [2T, H*hd]
-        vec = ops.rel_attention(q_w, q_r, k, v, k_r, lens, self.n_head, self.scale)
+        k_r = ops.linear_kn(pos_emb, self.r)                 # [2T, H*hd] ([B, 2T, H*hd] under dropout)
+        p = self.dropout.p if self.training else 0.0
+        vec = ops.rel_attention(q_w, q_r, k, v, k_r, lens, self.n_head, self.scale, drop_p=p)   # attn_prob dropout (:308)
         C = self.n_head * self.d_head
         out = ops.linear(vec, self.o.view(self.d_model, C))  # einsum("ibnd,hnd->ibh")
+        out = ops.dropout(out, self.dropout.p, self.training, "xl_attn_out")                      # (:327)
         out = ops.axpby(out, h, 1.0, 1.0)
         return ops.layernorm(out, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
 
@@ -84,7 +86,9 @@ class XLNetFeedForward(nn.Module):
 
     def forward_tm(self, x):
         y = ops.linear(x, self.layer_1.weight, self.layer_1.bias, ACT_GELU)
+        y = ops.dropout(y, self.dropout.p, self.training, "xl_ff_inner")                          # (:486)
         y = ops.linear(y, self.layer_2.weight, self.layer_2.bias)
+        y = ops.dropout(y, self.dropout.p, self.training, "xl_ff_out")                            # (:488)
         y = ops.axpby(y, x, 1.0, 1.0)
         return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
 
@@ -126,15 +130,15 @@ class XLNetModel(nn.Module):
 
     def forward_tm(self, x, lens):
         """inputs_embeds [B,T,D] + attention lengths -> last hidden state [B,T,D]."""
-        if self.training and self.config.dropout > 0.0:
-            raise NotImplementedError(
-                "XLNet dropout>0 in training mode is not implemented on the HIP path yet; "
-                "use a config with dropout 0 (DESIGN.md, 'XLNet dropout')")
         pos_emb = self.relative_positional_encoding(x.shape[1], x.device)
-        h = x
+        p, tr = self.dropout.p, self.training
+        h = ops.dropout(x, p, tr, "xl_input")                                                     # (:1201)
+        if tr and p > 0.0:
+            # the reference drops out the position embedding AFTER expanding it over the batch (:1228): per-clip masks
+            pos_emb = ops.dropout(pos_emb.unsqueeze(0).expand(x.shape[0], -1, -1).contiguous(), p, tr, "xl_pos_emb")
         for layer in self.layer:
             h = layer.forward_tm(h, pos_emb, lens)
-        return h
+        return ops.dropout(h, p, tr, "xl_output")                                                 # (:1280)
 
     def forward(self, inputs_embeds=None, attention_mask=None, **unused):
         lens = attention_mask.to(torch.int32).sum(dim=1, dtype=torch.int32)

@@ -60,6 +60,55 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 4), dtype=torch.uint8, device=device)
 
 
+# ---------------------------------------------------------------------------------------- dropout
+# Counter-based masks (vilco_dropout): a mask is identified by (p, seed); seeds come from torch's seed and a per-process
+# call counter, so a run is reproducible under torch.manual_seed.  `dropout_log` (when a list) records
+# (site, p, seed, shape) of every mask drawn: the parity tests rebuild the masks from it for the oracle.
+_drop_counter = [0]
+dropout_log = None
+
+
+def _new_drop(site, p, shape):
+    if p <= 0.0:
+        return (0.0, 0)
+    _drop_counter[0] += 1
+    seed = (torch.initial_seed() * 0x9E3779B1 + _drop_counter[0] * 0x85EBCA6B) & 0xFFFFFFFF
+    if dropout_log is not None:
+        dropout_log.append((site, float(p), int(seed), tuple(int(x) for x in shape)))
+    return (float(p), int(seed))
+
+
+def dropout_mask(p, seed, shape, device):
+    """the mask factors (0 or 1/(1-p)) of the stream (p, seed), as the kernels apply them"""
+    m = torch.empty(shape, dtype=torch.float32, device=device)
+    _lib.check(_lib.load().vilco_dropout(None, m.data_ptr(), m.numel(), float(p), int(seed), 0, _stream()))
+    return m
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, site):
+        _chk(x)
+        ctx.drop = _new_drop(site, p, x.shape)
+        y = torch.empty_like(x)
+        _lib.check(_lib.load().vilco_dropout(x.data_ptr(), y.data_ptr(), x.numel(), ctx.drop[0], ctx.drop[1], 0, _stream()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.check(_lib.load().vilco_dropout(dy.data_ptr(), dx.data_ptr(), dy.numel(), ctx.drop[0], ctx.drop[1], 0, _stream()))
+        return dx, None, None
+
+
+def dropout(x, p, training, site="dropout"):
+    """nn.Dropout(p) on the HIP path (inverted dropout, fresh counter-based mask per call)."""
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x.contiguous(), float(p), site)
+
+
 # ---------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), sB=(0, 0),
          sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
@@ -605,7 +654,7 @@ def flash_supported(hd):
     return bool(_lib.load().vilco_attn_supported(int(hd)))
 
 
-def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode):
+def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode, drop=(0.0, 0)):
     lib = _lib.load()
     B, Tq, Cn = q.shape
     Tk = k.shape[1]
@@ -614,12 +663,12 @@ def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode):
     nws = lib.vilco_attn_fwd_workspace(B, H, Tq, Tk, Cn // H, _precision)
     ws = _ws(nws, q.device)
     _lib.check(lib.vilco_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
-                                  lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, _precision, ws.data_ptr(), nws,
-                                  _stream()))
+                                  lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, _precision, float(drop[0]),
+                                  int(drop[1]), ws.data_ptr(), nws, _stream()))
     return o, lse
 
 
-def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias):
+def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, drop=(0.0, 0)):
     lib = _lib.load()
     B, Tq, Cn = q.shape
     Tk = k.shape[1]
@@ -629,8 +678,8 @@ def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias):
     ws = _ws(nws, q.device)
     _lib.check(lib.vilco_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
                                   lse.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                  _p(dbias), B, H, Tq, Tk, Cn // H, scale, mode, _precision, ws.data_ptr(), nws,
-                                  _stream()))
+                                  _p(dbias), B, H, Tq, Tk, Cn // H, scale, mode, _precision, float(drop[0]),
+                                  int(drop[1]), ws.data_ptr(), nws, _stream()))
     return dq, dk, dv, dbias
 
 
@@ -639,9 +688,10 @@ class _FlashAttention(torch.autograd.Function):
     from (q, k, lse)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, kv_len, H, scale, mode):
+    def forward(ctx, q, k, v, kv_len, H, scale, mode, drop_p=0.0):
         _chk(q, k, v)
-        o, lse = _flash_fwd(q, k, v, None, kv_len, H, scale, mode)
+        ctx.drop = _new_drop("attn_prob", drop_p, (q.shape[0], H, q.shape[1], k.shape[1]))
+        o, lse = _flash_fwd(q, k, v, None, kv_len, H, scale, mode, ctx.drop)
         ctx.H, ctx.scale, ctx.mode = H, scale, mode
         ctx.save_for_backward(q, k, v, kv_len, o, lse)
         return o
@@ -649,15 +699,20 @@ class _FlashAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do):
         q, k, v, kv_len, o, lse = ctx.saved_tensors
-        dq, dk, dv, _ = _flash_bwd(q, k, v, None, kv_len, o, lse, do.contiguous(), ctx.H, ctx.scale, ctx.mode, False)
-        return dq, dk, dv, None, None, None, None
+        dq, dk, dv, _ = _flash_bwd(q, k, v, None, kv_len, o, lse, do.contiguous(), ctx.H, ctx.scale, ctx.mode, False,
+                                   ctx.drop)
+        return dq, dk, dv, None, None, None, None, None
 
 
-def attention(q, k, v, kv_len, n_head, scale=None, mode=MASK_KEYS):
+def attention(q, k, v, kv_len, n_head, scale=None, mode=MASK_KEYS, drop_p=0.0):
+    """drop_p: dropout on the attention probabilities (training only; the caller passes 0 in eval)."""
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1] // n_head)
-    fn = _FlashAttention if (use_flash and flash_supported(q.shape[-1] // n_head)) else _Attention
-    return fn.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode))
+    if use_flash and flash_supported(q.shape[-1] // n_head):
+        return _FlashAttention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode), float(drop_p))
+    if drop_p > 0.0:
+        raise NotImplementedError("attention dropout needs the fused kernels (head dim <= 64, multiple of 4)")
+    return _Attention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode))
 
 
 class _RelAttention(torch.autograd.Function):
@@ -721,21 +776,23 @@ class _RelAttention(torch.autograd.Function):
 
 
 class _FlashRelAttention(torch.autograd.Function):
-    """XLNet relative attention with the content term fused: the position term bd = qr kr^T is a batched
-    GEMM, shifted (rel_shift_bnij) into an additive bias that the flash kernel consumes; backward returns
-    dS as d(bias)."""
+    """XLNet relative attention (modeling_xlnet_x.py:270-325) with the content term fused: the position scores
+    bd = qr kr^T are one band-limited batched GEMM that the flash kernels read unshifted (mask mode 3); backward
+    gets dS and derives the position-term gradients from one batched pack of it.  kr is [2T, C] (shared by the
+    batch) or [B, 2T, C] (per clip: the reference drops out the expanded position embedding per batch element)."""
 
     @staticmethod
-    def forward(ctx, qw, qr, k, v, kr, kv_len, H, scale):
+    def forward(ctx, qw, qr, k, v, kr, kv_len, H, scale, drop_p=0.0):
         _chk(qw, qr, k, v, kr)
-        lib = _lib.load()
         B, T, Cn = qw.shape
         hd = Cn // H
+        sKr = (2 * T * Cn if kr.dim() == 3 else 0, hd)
         bd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
-        gemm(qr, kr, bd, T, 2 * T, hd, 1, 1, Cn, Cn, 2 * T, batch=(B, H), sA=(T * Cn, hd), sB=(0, hd),
+        gemm(qr, kr, bd, T, 2 * T, hd, 1, 1, Cn, Cn, 2 * T, batch=(B, H), sA=(T * Cn, hd), sB=sKr,
              sC=(H * T * 2 * T, T * 2 * T), band=1, bandT=T)      # only the band p in [T-i, 2T-i) is ever read
+        ctx.drop = _new_drop("attn_prob", drop_p, (B, H, T, T))
         # the flash kernel reads the unshifted scores in place (mask mode 3): no [T,T] bias tensor, no shift pass
-        o, lse = _flash_fwd(qw, k, v, bd, kv_len, H, scale, MASK_XLNET_REL)
+        o, lse = _flash_fwd(qw, k, v, bd, kv_len, H, scale, MASK_XLNET_REL, ctx.drop)
         ctx.H, ctx.scale = H, scale
         ctx.save_for_backward(qw, qr, k, v, kr, kv_len, bd, o, lse)
         return o
@@ -747,36 +804,44 @@ class _FlashRelAttention(torch.autograd.Function):
         H, scale = ctx.H, ctx.scale
         B, T, Cn = qw.shape
         hd = Cn // H
-        dqw, dk, dv, dS = _flash_bwd(qw, k, v, bd, kv_len, o, lse, do.contiguous(), H, scale, MASK_XLNET_REL, True)
+        per_clip = kr.dim() == 3
+        sKr = (2 * T * Cn if per_clip else 0, hd)
+        dqw, dk, dv, dS = _flash_bwd(qw, k, v, bd, kv_len, o, lse, do.contiguous(), H, scale, MASK_XLNET_REL, True,
+                                     ctx.drop)
         del bd
         sX, sB2 = (T * Cn, hd), (H * T * 2 * T, T * 2 * T)
         dqr = torch.empty_like(qr)
         if _reuse_packs:
             # d(bd) = scale * unshift(dS) is never materialised: ONE pack of dS in the unshifted [T, 2T] view (per b, h)
-            # feeds dqr = d(bd) kr (k-contiguous) and dkr = sum_b d(bd)^T qr (k-major)
+            # feeds dqr = d(bd) kr (k-contiguous) and dkr = [sum_b] d(bd)^T qr (k-major)
             (pd,) = pack_many([(dS, T, T)], nbatch=B * H, relshift=True)
             del dS
-            gemm(None, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=(0, hd), sC=sX,
+            gemm(None, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=sKr, sC=sX,
                  alpha=scale, a_planes=pd, band=2, bandT=T)
-            dkr_b = torch.empty((B,) + tuple(kr.shape), dtype=torch.float32, device=kr.device)
+            dkr_b = torch.empty(B, 2 * T, Cn, dtype=torch.float32, device=kr.device)
             gemm(None, qr, dkr_b, 2 * T, hd, T, 0, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=sX,
                  sC=(2 * T * Cn, hd), alpha=scale, a_planes=pd, band=3, bandT=T)
-            dkr = dkr_b.sum(0) if B > 1 else dkr_b[0]
+            dkr = dkr_b if per_clip else (dkr_b.sum(0) if B > 1 else dkr_b[0])
         else:
             dbd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
             _lib.check(lib.vilco_relshift_bwd(dS.data_ptr(), dbd.data_ptr(), scale, B, H, T, _stream()))
             del dS
-            gemm(dbd, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=(0, hd), sC=sX)
+            gemm(dbd, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=sKr, sC=sX)
             dkr = torch.zeros_like(kr)
             for b in range(B):
                 gemm(dbd, qr, dkr, 2 * T, hd, T, 0, 0, 2 * T, Cn, Cn, batch=(1, H), sA=(0, T * 2 * T),
-                     sB=(0, hd), sC=(0, hd), offA=b * H * T * 2 * T, offB=b * T * Cn, beta=1.0)
-        return dqw, dqr, dk, dv, dkr, None, None, None
+                     sB=(0, hd), sC=(0, hd), offA=b * H * T * 2 * T, offB=b * T * Cn,
+                     offC=b * 2 * T * Cn if per_clip else 0, beta=0.0 if per_clip else 1.0)
+        return dqw, dqr, dk, dv, dkr, None, None, None, None
 
 
-def rel_attention(qw, qr, k, v, kr, kv_len, n_head, scale):
-    fn = _FlashRelAttention if (use_flash and flash_supported(qw.shape[-1] // n_head)) else _RelAttention
-    return fn.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale))
+def rel_attention(qw, qr, k, v, kr, kv_len, n_head, scale, drop_p=0.0):
+    """kr [2T, C] or [B, 2T, C]; drop_p: dropout on the attention probabilities (training only)."""
+    if use_flash and flash_supported(qw.shape[-1] // n_head):
+        return _FlashRelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale), float(drop_p))
+    if drop_p > 0.0 or kr.dim() == 3:
+        raise NotImplementedError("XLNet dropout needs the fused attention kernels (head dim <= 64, multiple of 4)")
+    return _RelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale))
 
 
 class _ChannelAttn(torch.autograd.Function):
