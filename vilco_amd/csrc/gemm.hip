@@ -528,10 +528,11 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   const long tn = (d->N + BN - 1) / BN;
   const long tiles128 = ((d->M + 127) / 128) * tn * nbatch;
   const long tiles256 = ((d->M + 255) / 256) * tn * nbatch;
-  // tile / split-K choice, tuned on MI355X with tools/gemm_tune.py (profiles/r01_gemm_tune.txt):
-  // the 8-wave 256-row tile wins whenever M >= 2048; with >= 128 tiles only long K is worth splitting
-  // (>= 32 K-steps per split), with fewer tiles filling the 256 CUs comes first.
-  p.BM = d->M >= 2048 ? 256 : 128;
+  // tile / split-K choice, tuned on MI355X with tools/gemm_tune.py (profiles/r01_gemm_tune.txt).  The 128-row tile
+  // (two blocks per CU) wins whenever all its tiles fit one per CU, or M is small; the 256-row tile for the many-tile
+  // problems.  With >= 128 tiles only long K is worth splitting (>= 32 K-steps per split); with fewer, filling the
+  // 256 CUs comes first, but never below 8 K-steps per split.
+  p.BM = (tiles128 <= 256 || d->M < 2048) ? 128 : 256;
   const long tiles = p.BM == 256 ? tiles256 : tiles128;
   const int nk = p.Kp / BK;
   int ks = 1;
@@ -541,7 +542,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
       if (ks > 3) ks = 3;
     } else {
       ks = (int)((288 + tiles - 1) / tiles);
-      if (ks > nk / 4) ks = nk / 4;
+      if (ks > nk / 8) ks = nk / 8;
       if (ks > 16) ks = 16;
     }
     if (ks < 1) ks = 1;
