@@ -4,6 +4,7 @@ three-part bf16 split mode (both fp32-equivalent), 2e-4 in the two-part bf16 spl
 elementwise 2e-5.  The module runs under the default precision; VILCO_PRECISION=split3 reruns it in that mode."""
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -418,3 +419,64 @@ def test_attention_zero_upstream_gradient(dev):
     y = ops.linear(x, w)
     y.backward(torch.zeros_like(y))
     assert torch.count_nonzero(y) == 0 and torch.count_nonzero(w.grad) == 0 and torch.count_nonzero(x.grad) == 0
+
+
+def test_attention_randomized_shapes(dev):
+    """40 seeded random problems (ragged lengths, every head dim 4..64 that is a multiple of 4, cross-attention shapes,
+    with / without probability dropout, both fp32-equivalent precisions) against an fp64 reference: forward and all
+    three gradients."""
+    from vilco_amd import ops
+    rng = np.random.RandomState(1234)
+    for case in range(40):
+        B, H = int(rng.randint(1, 4)), int(rng.randint(1, 5))
+        hd = int(rng.choice([4, 8, 12, 16, 24, 32, 40, 48, 64]))
+        Tq, Tk = int(rng.randint(1, 300)), int(rng.randint(1, 300))
+        p = float(rng.choice([0.0, 0.0, 0.15, 0.5]))
+        prec = str(rng.choice(["f16x2", "f16x2", "split3"]))
+        torch.manual_seed(1000 + case)
+        C = H * hd
+        q = torch.randn(B, Tq, C, device=dev, requires_grad=True)
+        k, v = [torch.randn(B, Tk, C, device=dev, requires_grad=True) for _ in range(2)]
+        lens = torch.tensor(rng.randint(1, Tk + 1, size=B), dtype=torch.int32, device=dev)
+        scale = float(rng.uniform(0.05, 0.5))
+        ops.set_precision(prec)
+        ops.dropout_log = []
+        try:
+            o = ops.attention(q, k, v, lens, H, scale, drop_p=p)
+            log = list(ops.dropout_log)
+        finally:
+            ops.dropout_log = None
+            ops.set_precision(None)
+        m = ops.dropout_mask(log[0][1], log[0][2], log[0][3], dev).double().cpu() if log else 1.0
+        g = torch.randn(B, Tq, C)
+        o.backward(g.to(dev))
+        qd, kd, vd = [t.detach().double().cpu().requires_grad_(True) for t in (q, k, v)]
+        qh = qd.view(B, Tq, H, hd).transpose(1, 2)
+        kh, vh = [t.view(B, Tk, H, hd).transpose(1, 2) for t in (kd, vd)]
+        sc = (qh * scale) @ kh.transpose(-2, -1)
+        km = (torch.arange(Tk)[None, :] < lens.cpu()[:, None])[:, None, None, :]
+        want = ((torch.softmax(sc.masked_fill(~km, float('-inf')), dim=-1) * m) @ vh).transpose(1, 2).reshape(B, Tq, C)
+        want.backward(g.double())
+        tag = (case, B, H, hd, Tq, Tk, p, prec)
+        assert rel(o, want) < TOL_GEMM, tag
+        for a, b in ((q, qd), (k, kd), (v, vd)):
+            assert rel(a.grad, b.grad) < TOL_GEMM, tag
+
+
+def test_gemm_randomized_shapes(dev):
+    """60 seeded random products in the three orientations the model uses (forward, dX, dW), with and without shared
+    packs, odd sizes included, against fp64."""
+    from vilco_amd import ops
+    rng = np.random.RandomState(4321)
+    for case in range(60):
+        M, N, K = [int(x) for x in rng.randint(1, 700, size=3)]
+        torch.manual_seed(2000 + case)
+        x, w, dy = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.randn(M, N, device=dev)
+        use_planes = bool(rng.randint(0, 2))
+        px, pw, pdy = (ops.pack(x, M, K), ops.pack(w, N, K), ops.pack(dy, M, N)) if use_planes else (None, None, None)
+        y, dx, dw = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev), torch.empty(N, K, device=dev)
+        ops.gemm(x, w, y, M, N, K, 1, 1, K, K, N, a_planes=px, b_planes=pw)
+        ops.gemm(dy, w, dx, M, K, N, 1, 0, N, K, K, a_planes=pdy, b_planes=pw)
+        ops.gemm(dy, x, dw, N, K, M, 0, 0, N, K, K, a_planes=pdy, b_planes=px)
+        for got, want in ((y, x.double() @ w.double().t()), (dx, dy.double() @ w.double()), (dw, dy.double().t() @ x.double())):
+            assert rel(got, want) < 4e-6, (case, M, N, K, use_planes)
