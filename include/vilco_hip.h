@@ -93,6 +93,10 @@ typedef struct vilco_gemm_desc {
   /*           (left unwritten);  band 2: A is that matrix, k = p (M rows i): K-steps outside a tile's band are     */
   /*           skipped;  band 3: A is its transpose, M rows p, k = i: likewise.  0: dense.                          */
   int32_t band, bandT;
+  /* fused inverted dropout on the stored output (after activation, row mask, column scale; before residual / beta):   */
+  /* the mask of vilco_dropout(p, seed) at element index m*N + n.  Needs ldc == N, batch 1.  0: none.                     */
+  float drop_p;
+  uint32_t drop_seed;
 } vilco_gemm_desc;
 
 size_t vilco_gemm_workspace(const vilco_gemm_desc* d);
@@ -224,11 +228,12 @@ int vilco_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, u
 /* out = alpha*a + beta*b (b may be null) */
 int vilco_axpby(float* out, const float* a, const float* b, float alpha, float beta, int64_t n,
                 void* stream);
-/* dz = dy * act'(aux) * rowmask ; aux = pre-activation (gelu) or output (relu); act NONE = mask only.
+/* dz = dropmask(dy) * act'(aux) * rowmask ; aux = pre-activation (gelu) or output (relu); act NONE = mask only;
+ * drop_p > 0: the dropout mask (p, seed) of vilco_gemm's fused epilogue dropout, element index r*C + c.
  * Optional dbias[C] = column sums of dz (needs workspace). */
 int vilco_act_bwd(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
-                  const int32_t* len, int32_t T, int64_t rows, int32_t C, void* workspace,
-                  size_t workspace_bytes, void* stream);
+                  const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p, uint32_t drop_seed,
+                  void* workspace, size_t workspace_bytes, void* stream);
 /* out[c] = sum_r x[r][c] */
 int vilco_colsum(const float* x, float* out, int64_t rows, int32_t C, void* workspace,
                  size_t workspace_bytes, void* stream);

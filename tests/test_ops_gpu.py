@@ -480,3 +480,33 @@ def test_gemm_randomized_shapes(dev):
         ops.gemm(dy, x, dw, N, K, M, 0, 0, N, K, K, a_planes=pdy, b_planes=px)
         for got, want in ((y, x.double() @ w.double().t()), (dx, dy.double() @ w.double()), (dw, dy.double().t() @ x.double())):
             assert rel(got, want) < 4e-6, (case, M, N, K, use_planes)
+
+
+@pytest.mark.parametrize("act", [0, 2])
+@pytest.mark.parametrize("M,N,K", [(150, 72, 64), (700, 130, 96)])
+def test_linear_fused_dropout(dev, act, M, N, K):
+    """nn.Dropout after a linear layer, fused into the GEMM epilogue (forward) and into act_bwd (backward), equals the
+    unfused composition with the same mask."""
+    from vilco_amd import ops
+    torch.manual_seed(41)
+    x = torch.randn(2, M, K, device=dev, requires_grad=True)
+    w = (torch.randn(N, K, device=dev) / 8).requires_grad_(True)
+    b = torch.randn(N, device=dev, requires_grad=True)
+    lens = torch.tensor([M, M - 7], dtype=torch.int32, device=dev)
+    ops.dropout_log = []
+    try:
+        y = ops.linear(x, w, b, act, lens, M, drop_p=0.3, drop_site="t")
+        (site, p, seed, shape), = ops.dropout_log
+    finally:
+        ops.dropout_log = None
+    assert shape == (2, M, N)
+    m = ops.dropout_mask(p, seed, shape, dev)
+    g = torch.randn_like(y)
+    y.backward(g)
+    got = (y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    for t in (x, w, b):
+        t.grad = None
+    y2 = ops.linear(x, w, b, act, lens, M) * m
+    y2.backward(g)
+    for a, c in zip(got, (y2.detach(), x.grad, w.grad, b.grad)):
+        assert rel(a, c) < 2e-6

@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("workspace", c_fp), ("workspace_bytes", sz),
         ("a_planes", c_fp), ("b_planes", c_fp),
         ("band", i32), ("bandT", i32),
+        ("drop_p", f32), ("drop_seed", C.c_uint32),
     ]
 
 
@@ -82,7 +83,7 @@ SIGNATURES = {
                                       c_fp, sz, c_fp]),
     "vilco_dropout": (C.c_int, [c_fp, c_fp, i64, f32, C.c_uint32, C.c_uint64, c_fp]),
     "vilco_axpby": (C.c_int, [c_fp, c_fp, c_fp, f32, f32, i64, c_fp]),
-    "vilco_act_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, c_fp, sz, c_fp]),
+    "vilco_act_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp]),
     "vilco_colsum": (C.c_int, [c_fp, c_fp, i64, i32, c_fp, sz, c_fp]),
     "vilco_mask_rows": (C.c_int, [c_fp, c_fp, i32, i32, i32, c_fp]),
     "vilco_add_pe": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),

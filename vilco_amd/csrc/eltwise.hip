@@ -161,7 +161,7 @@ __global__ __launch_bounds__(EW_THREADS) void axpby_kernel(float* __restrict__ o
 __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ dz,
     float* __restrict__ ws, int act, const int* __restrict__ len, int T, long rows, int C,
-    int rows_per_block) {
+    int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, float drop_inv_keep) {
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
   float acc = 0.f;
   for (long r = r0; r < r1; ++r) {
     float g = dy[r * C + c];
+    if (drop_thresh) g = vilco_drop_hash(drop_seed, (uint64_t)(r * C + c)) >= drop_thresh ? g * drop_inv_keep : 0.f;
     if (len && (int)(r % T) >= len[r / T]) g = 0.f;
     if (act == VILCO_ACT_RELU) g = (aux[r * C + c] > 0.f) ? g : 0.f;
     else if (act == VILCO_ACT_GELU) g *= gelu_grad_f(aux[r * C + c]);
@@ -369,8 +370,9 @@ extern "C" int vilco_axpby(float* out, const float* a, const float* b, float alp
 }
 
 extern "C" int vilco_act_bwd(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
-                             const int32_t* len, int32_t T, int64_t rows, int32_t C, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p,
+                             uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (!dy || !dz || rows < 0 || C <= 0 || act < 0 || act > 2) return VILCO_ERR_BADARG;
   if (act != VILCO_ACT_NONE && !aux) return VILCO_ERR_BADARG;
   if (len && T <= 0) return VILCO_ERR_BADARG;
@@ -381,7 +383,7 @@ extern "C" int vilco_act_bwd(const float* dy, const float* aux, float* dz, float
   const int rpb = (int)((rows + nb - 1) / nb);
   float* ws = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
-                     (long)rows, C, rpb);
+                     (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p));
   if (dbias) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }

@@ -73,6 +73,8 @@ struct GArgs {
   const float* inv_b;
   int vec_out;              // N, ldc, batch strides multiples of 4 and every epilogue pointer 16-byte aligned
   int band, bandT;          // XLNet relative-position band (vilco_gemm_desc.band)
+  uint32_t drop_thresh, drop_seed;   // fused output dropout (vilco_gemm_desc.drop_p): keep iff hash(seed, m*N+n) >= thresh
+  float drop_inv_keep;
   Epi e;
 };
 
@@ -90,6 +92,7 @@ __device__ __forceinline__ void store_out(const GArgs& g, long idx, int n, float
   else if (e.act == VILCO_ACT_GELU) v = gelu_f(v);
   if (!valid) v = 0.f;
   if (e.colscale) v *= e.colscale[n];
+  if (g.drop_thresh) v = vilco_drop_hash(g.drop_seed, (uint64_t)idx) >= g.drop_thresh ? v * g.drop_inv_keep : 0.f;
   if (e.residual && (valid || !e.res_masked)) v += e.residual[idx];
   if (e.beta != 0.f) v += e.beta * g.cfinal[idx];
   g.cfinal[idx] = v;
@@ -110,6 +113,11 @@ __device__ __forceinline__ void store_out4(const GArgs& g, long idx, int n, cons
   }
   if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
   if (e.colscale) v *= *reinterpret_cast<const f32x4*>(e.colscale + n);
+  if (g.drop_thresh) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      v[k] = vilco_drop_hash(g.drop_seed, (uint64_t)(idx + k)) >= g.drop_thresh ? v[k] * g.drop_inv_keep : 0.f;
+  }
   if (e.residual && (valid || !e.res_masked)) v += *reinterpret_cast<const f32x4*>(e.residual + idx);
   if (e.beta != 0.f) v += *reinterpret_cast<const f32x4*>(g.cfinal + idx) * e.beta;
   *reinterpret_cast<f32x4*>(g.cfinal + idx) = v;
@@ -699,6 +707,8 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (d->precision < 0 || d->precision > 3) return VILCO_ERR_BADARG;
   if (d->act < 0 || d->act > 2) return VILCO_ERR_BADARG;
   if (d->band < 0 || d->band > 3 || (d->band && d->bandT <= 0)) return VILCO_ERR_BADARG;
+  if (!(d->drop_p >= 0.f) || d->drop_p >= 1.f) return VILCO_ERR_BADARG;
+  if (d->drop_p > 0.f && (d->ldc != d->N || d->batch_outer != 1 || d->batch_inner != 1)) return VILCO_ERR_UNSUPPORTED;
   if (d->row_len && d->rowT <= 0) return VILCO_ERR_BADARG;
   if (d->a_kcontig == 0 && d->b_kcontig == 1) return VILCO_ERR_UNSUPPORTED;  // "TT" is never needed
   if (d->tap_operand != VILCO_TAP_NONE) {
@@ -793,6 +803,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   g.ksplit = p.ksplit; g.kchunk = p.kchunk; g.split_stride = p.split_stride;
   g.inv_a = inv_a; g.inv_b = inv_b;
   g.band = d->band; g.bandT = d->bandT;
+  g.drop_thresh = vilco_drop_threshold_host(d->drop_p); g.drop_seed = d->drop_seed; g.drop_inv_keep = 1.f / (1.f - d->drop_p);
   g.vec_out = (d->N % 4) == 0 && (d->ldc % 4) == 0 && (d->sCo % 4) == 0 && (d->sCi % 4) == 0 && vilco_aligned(d->C, 16) &&
               vilco_aligned(d->bias, 16) && vilco_aligned(d->preact, 16) && vilco_aligned(d->colscale, 16) &&
               vilco_aligned(d->residual, 16);

@@ -164,8 +164,9 @@ class MaskedMHA(nn.Module):
         v = ops.linear(src, self.value.weight, self.value.bias)
         o = ops.attention(q, k, v, src_lens, self.n_head, self.scale,
                           drop_p=self.attn_drop.p if self.training else 0.0)            # attn_drop (blocks.py:253)
-        out = ops.linear(o, self.proj.weight, self.proj.bias, ACT_NONE, lens, x.shape[1])
-        return ops.dropout(out, self.proj_drop.p, self.training, "proj_drop"), lens     # proj_drop (:264)
+        out = ops.linear(o, self.proj.weight, self.proj.bias, ACT_NONE, lens, x.shape[1],
+                         drop_p=self.proj_drop.p if self.training else 0.0, drop_site="proj_drop")   # proj_drop (:264)
+        return out, lens
 
     def forward(self, x, mask, encoder_hidden_states=None, encoder_attention_mask=None):
         lens = mask_to_lens(mask)
@@ -219,8 +220,9 @@ class MaskedMHCA(nn.Module):
         v = ops.linear(v, self.value.weight, self.value.bias)
         o = ops.attention(q, k, v, kv_lens, self.n_head, self.scale,
                           drop_p=self.attn_drop.p if self.training else 0.0)            # attn_drop (blocks.py:394)
-        out = ops.linear(o, self.proj.weight, self.proj.bias, ACT_NONE, q_lens, q.shape[1])
-        return ops.dropout(out, self.proj_drop.p, self.training, "proj_drop"), q_lens   # proj_drop (:405)
+        out = ops.linear(o, self.proj.weight, self.proj.bias, ACT_NONE, q_lens, q.shape[1],
+                         drop_p=self.proj_drop.p if self.training else 0.0, drop_site="proj_drop")   # proj_drop (:405)
+        return out, q_lens
 
     def forward(self, x, mask):
         T = x.shape[-1]
@@ -379,10 +381,11 @@ class TransformerBlock(nn.Module):
             cs, rs = self._dp(self.drop_path_attn, c)
             out = ops.scale_add(out, c, cs, rs, out_lens, mask_a=True)
         T2 = out.shape[1]
-        m = ops.linear(self.ln2.forward_tm(out), self.mlp[0].weight, self.mlp[0].bias, ACT_GELU)
-        m = ops.dropout(m, self.mlp[2].p, self.training, "mlp_drop")                    # blocks.py:533-540
-        m = ops.linear(m, self.mlp[3].weight, self.mlp[3].bias, ACT_NONE, out_lens, T2)
-        m = ops.dropout(m, self.mlp[4].p, self.training, "mlp_drop")
+        tr = self.training                                                              # mlp dropouts: blocks.py:533-540
+        m = ops.linear(self.ln2.forward_tm(out), self.mlp[0].weight, self.mlp[0].bias, ACT_GELU,
+                       drop_p=self.mlp[2].p if tr else 0.0, drop_site="mlp_drop")
+        m = ops.linear(m, self.mlp[3].weight, self.mlp[3].bias, ACT_NONE, out_lens, T2,
+                       drop_p=self.mlp[4].p if tr else 0.0, drop_site="mlp_drop")
         cs, rs = self._dp(self.drop_path_mlp, m)
         out = ops.scale_add(out, m, cs, rs)
         if self.n_ds_strides[0] == 1 and self.n_ds_strides[1] == 1:

@@ -67,8 +67,7 @@ class XLNetRelativeAttention(nn.Module):
         p = self.dropout.p if self.training else 0.0
         vec = ops.rel_attention(q_w, q_r, k, v, k_r, lens, self.n_head, self.scale, drop_p=p)   # attn_prob dropout (:308)
         C = self.n_head * self.d_head
-        out = ops.linear(vec, self.o.view(self.d_model, C))  # einsum("ibnd,hnd->ibh")
-        out = ops.dropout(out, self.dropout.p, self.training, "xl_attn_out")                      # (:327)
+        out = ops.linear(vec, self.o.view(self.d_model, C), drop_p=p, drop_site="xl_attn_out")   # einsum("ibnd,hnd->ibh") + dropout (:327)
         out = ops.axpby(out, h, 1.0, 1.0)
         return ops.layernorm(out, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
 
@@ -85,10 +84,9 @@ class XLNetFeedForward(nn.Module):
             lin.bias.data.zero_()
 
     def forward_tm(self, x):
-        y = ops.linear(x, self.layer_1.weight, self.layer_1.bias, ACT_GELU)
-        y = ops.dropout(y, self.dropout.p, self.training, "xl_ff_inner")                          # (:486)
-        y = ops.linear(y, self.layer_2.weight, self.layer_2.bias)
-        y = ops.dropout(y, self.dropout.p, self.training, "xl_ff_out")                            # (:488)
+        p = self.dropout.p if self.training else 0.0
+        y = ops.linear(x, self.layer_1.weight, self.layer_1.bias, ACT_GELU, drop_p=p, drop_site="xl_ff_inner")   # (:486)
+        y = ops.linear(y, self.layer_2.weight, self.layer_2.bias, drop_p=p, drop_site="xl_ff_out")              # (:488)
         y = ops.axpby(y, x, 1.0, 1.0)
         return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
 

@@ -113,7 +113,7 @@ def dropout(x, p, training, site="dropout"):
 def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), sB=(0, 0),
          sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
          bias=None, preact=None, act=ACT_NONE, row_len=None, rowT=0, colscale=None, residual=None,
-         res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0):
+         res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0, drop=(0.0, 0)):
     """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements.  a_planes / b_planes: operands
     already packed by `pack` (the fp32 tensor may then be None)."""
     lib = _lib.load()
@@ -122,6 +122,7 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     d.B = None if B is None else B.data_ptr() + 4 * offB
     d.a_planes, d.b_planes = _p(a_planes), _p(b_planes)
     d.band, d.bandT = int(band), int(bandT)
+    d.drop_p, d.drop_seed = float(drop[0]), int(drop[1])
     d.C = Cc.data_ptr() + 4 * offC
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.a_kcontig, d.b_kcontig = int(a_kc), int(b_kc)
@@ -181,15 +182,15 @@ def pack_many(items, precision=None, nbatch=1, relshift=False):
 _reuse_packs = os.environ.get("VILCO_PACK_REUSE", "1") != "0"
 
 
-def _act_bwd(dy, aux, act, lens, T, want_bias):
-    """dz = dy * act'(aux) * rowmask, optional column sums -> (dz, dbias)."""
+def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0)):
+    """dz = dropmask(dy) * act'(aux) * rowmask, optional column sums -> (dz, dbias)."""
     lib = _lib.load()
     rows, Cn = dy.numel() // dy.shape[-1], dy.shape[-1]
     dz = torch.empty_like(dy)
     db = torch.empty(Cn, dtype=torch.float32, device=dy.device) if want_bias else None
     ws = _ws(lib.vilco_colsum_workspace(rows, Cn), dy.device) if want_bias else None
     _lib.check(lib.vilco_act_bwd(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
-                                 int(T or 0), rows, Cn, _p(ws), ws.numel() if ws is not None else 0,
+                                 int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
                                  _stream()))
     return dz, db
 
@@ -208,7 +209,7 @@ class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) * rowmask.  x [..., K] token-major, W [N, K] (conv1x1 / nn.Linear weight)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, lens, T):
+    def forward(ctx, x, w, b, act, lens, T, drop_p=0.0, drop_site="dropout"):
         _chk(x, w, b)
         K = x.shape[-1]
         N = w.shape[0]
@@ -220,8 +221,9 @@ class _Linear(torch.autograd.Function):
         if _reuse_packs:
             ctx.prec = _precision
             px, pw = pack_many([(x, M, K), (w, N, K)])
+        ctx.drop = _new_drop(drop_site, drop_p, y.shape)      # nn.Dropout after the layer, fused into the epilogue
         gemm(x, w, y, M, N, K, 1, 1, K, K, N, bias=b, preact=pre, act=act, row_len=lens,
-             rowT=T or 0, a_planes=px, b_planes=pw)
+             rowT=T or 0, a_planes=px, b_planes=pw, drop=ctx.drop)
         ctx.act, ctx.T = act, T
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, pre if act == ACT_GELU else (y if act == ACT_RELU else None), lens, px, pw)
@@ -234,8 +236,8 @@ class _Linear(torch.autograd.Function):
         K, N = x.shape[-1], w.shape[0]
         M = x.numel() // K
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.act != ACT_NONE or lens is not None:
-            dz, db = _act_bwd(dy, aux, ctx.act, lens, ctx.T, need_db)
+        if ctx.act != ACT_NONE or lens is not None or ctx.drop[0] > 0.0:
+            dz, db = _act_bwd(dy, aux, ctx.act, lens, ctx.T, need_db, ctx.drop)
         else:
             dz, db = dy, (colsum(dy.view(M, N)) if need_db else None)
         dx = dw = pz = None
@@ -249,11 +251,15 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=prec, a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE, lens=None, T=None):
-    return _Linear.apply(x, w, b, act, lens, T)
+def linear(x, w, b=None, act=ACT_NONE, lens=None, T=None, drop_p=0.0, drop_site="dropout"):
+    """drop_p: nn.Dropout(drop_p) applied to the layer's output (pass 0 outside training), fused into the GEMM epilogue.
+    With a ReLU (output saved as the activation witness) the dropout stays a separate op."""
+    if drop_p > 0.0 and act == ACT_RELU:
+        return dropout(_Linear.apply(x, w, b, act, lens, T, 0.0, drop_site), drop_p, True, drop_site)
+    return _Linear.apply(x, w, b, act, lens, T, float(drop_p), drop_site)
 
 
 class _LinearKN(torch.autograd.Function):
