@@ -158,26 +158,38 @@ class _ConvHead(nn.Module):
 class LevelCat:
     """Pyramid levels [B,T_l,C] of every clip concatenated along T with one zero row between levels."""
 
+    _layout = {}     # (T_l ..., device) -> constant index tensors of the concatenated layout
+
+    @classmethod
+    def _get_layout(cls, Ts, dev):
+        key = (tuple(Ts), str(dev))
+        lay = cls._layout.get(key)
+        if lay is None:
+            off, lvl, pos, o = [], [], [], 0
+            for i, T in enumerate(Ts):
+                if i:
+                    lvl.append(i); pos.append(1 << 30); o += 1          # separator row: never valid
+                off.append(o)
+                lvl.extend([i] * T); pos.extend(range(T)); o += T
+            notgap = torch.tensor([0.0 if p_ == (1 << 30) else 1.0 for p_ in pos], dtype=torch.float32, device=dev)
+            lay = (off, o, torch.tensor(lvl, dtype=torch.long, device=dev), torch.tensor(pos, dtype=torch.int32, device=dev),
+                   notgap[None, :, None])
+            cls._layout = {key: lay}
+        return lay
+
     def __init__(self, feats, lens):
         B, dev = feats[0].shape[0], feats[0].device
         self.T = [f.shape[1] for f in feats]
-        self.off, pieces, valid, o = [], [], [], 0
+        self.off, total, lvl, pos, self.notgap = self._get_layout(self.T, dev)
         zero = feats[0].new_zeros(B, 1, feats[0].shape[2])
-        for i, (f, l) in enumerate(zip(feats, lens)):
+        pieces = []
+        for i, f in enumerate(feats):
             if i:
                 pieces.append(zero)
-                valid.append(torch.zeros(B, 1, dtype=torch.bool, device=dev))
-                o += 1
-            self.off.append(o)
             pieces.append(f)
-            valid.append(torch.arange(f.shape[1], device=dev)[None, :] < l[:, None])
-            o += f.shape[1]
         self.x = torch.cat(pieces, dim=1)
-        self.valid = torch.cat(valid, dim=1).to(torch.float32)[:, :, None]          # [B,Tc,1]
-        notgap = torch.ones(o, dtype=torch.float32, device=dev)
-        for t0, T in zip(self.off[1:], self.T[:-1]):
-            notgap[t0 - 1] = 0.0
-        self.notgap = notgap[None, :, None]                                            # [1,Tc,1]
+        lim = torch.stack([l.to(torch.int32) for l in lens], dim=1)[:, lvl]            # [B,Tc] valid length of the row's level
+        self.valid = (pos[None, :] < lim).to(torch.float32)[:, :, None]                 # [B,Tc,1]
 
     def split(self, y):
         return [y[:, o:o + T] for o, T in zip(self.off, self.T)]
