@@ -260,7 +260,7 @@ __device__ __forceinline__ float mask_score(float s, int i, int j, int len, int 
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int HDP, int NP, bool F16>
+template <int HDP, int NP, bool F16, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   constexpr int BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
       }
     }
     unsigned keep_bits = 0xffffu;          // dropout keep flags of this lane's 16 (mi, r) probabilities
-    if (a.drop_thresh) {
+    if (DROP && a.drop_thresh) {
       keep_bits = 0u;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         p[r] = dead ? 0.f : fast_exp(s[mi][r] - m_new);
         psum += p[r];                                   // the softmax denominator is over the undropped probabilities
-        if (!((keep_bits >> (mi * 4 + r)) & 1u)) p[r] = 0.f;
+        if (DROP && !((keep_bits >> (mi * 4 + r)) & 1u)) p[r] = 0.f;
         if (F16) p[r] *= P_SCALE;
       }
       bf16x4 pp[3];
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dBias)
-template <int HDP, int NP, bool F16>
+template <int HDP, int NP, bool F16, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
       }
     }
     unsigned keep_bits = 0xffffu;          // dropout keep flags of this lane's 16 (mi, r) probabilities
-    if (a.drop_thresh) {
+    if (DROP && a.drop_thresh) {
       keep_bits = 0u;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
         float x = s[r] * qk_scale;
         if (!plain) x = mask_score(x + (bias ? bvt[mi][r] : 0.f), qi, jb + r, len, a.Tk, mmode);
         const float p = (x == -INFINITY) ? 0.f : fast_exp(x - lse);
-        const float dpr = ((keep_bits >> (mi * 4 + r)) & 1u) ? dp[r] : 0.f;
+        const float dpr = (!DROP || ((keep_bits >> (mi * 4 + r)) & 1u)) ? dp[r] : 0.f;
         ds[r] = p * (dpr - dlt);
         if (F16) ds[r] *= DS_SCALE;
       }
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // one workgroup per (b, h, 64-key tile); inner loop over 32-query tiles.  S = Q K^T orientation: the C layout
 // gives each lane one key (col) and 4 consecutive queries (rows), so P^T / dS^T go to LDS as packed stores.
-template <int HDP, int NP, bool F16>
+template <int HDP, int NP, bool F16, bool HASB, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) {
   constexpr int BKV = 64, BQ = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
   const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
   const long row_bh = (long)bh * a.Tq;
   const int bias_ld = a.mode == 3 ? a.Tq + a.Tk : a.Tk;
-  const float* bias = a.bias ? a.bias + row_bh * bias_ld : nullptr;
+  const float* bias = (HASB && a.bias) ? a.bias + row_bh * bias_ld : nullptr;
   const int mmode = a.mode == 3 ? 1 : a.mode;
   const __bf16* qnb = a.qn.p + (long)bh * a.qn.batch_stride;
   const __bf16* donb = a.don.p + (long)bh * a.don.batch_stride;
@@ -676,7 +676,26 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
   const int nq = tile_dead ? 0 : (a.Tq + BQ - 1) / BQ;
   TileStage<HDP, BQ, NP> stQ, stdO;
   TileStage<BQ, HDP, NP> stQt, stdOt;
+  // Additive bias of the [32 q][64 keys] tile.  In this kernel's orientation a lane owns one key and four query rows,
+  // so direct loads are single dwords from four rows per instruction (0.7 ms per XLNet pass at P); instead every
+  // thread brings 8 consecutive keys of one query row with the next Q tile (row-contiguous 16-byte loads) and the tile
+  // goes through LDS.  It borrows the P^T buffer (free until this iteration's probabilities are written; exactly
+  // 32 x 64 floats when NP >= 2), at the price of one extra barrier per iteration.
+  constexpr bool BIAS_LDS = HASB && NP >= 2;      // HASB: instantiated separately so the bias-free kernel pays nothing
+  float* sBias = reinterpret_cast<float*>(sPt);
+  float stB[8];
+  const int brow = tid >> 3, bcol = (tid & 7) * 8;
+  auto gload_bias = [&](int q0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (q0 + brow < a.Tq) bias4(v4, bias, q0 + brow, k0 + bcol + 4 * h, bias_ld, a);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) stB[4 * h + e] = v4[e];
+    }
+  };
   if (nq > 0) {
+    if (BIAS_LDS && bias) gload_bias(0);
     gload_tile<HDP, BQ, NP>(stQ, a.qn, qnb, 0, 0, tid);
     gload_tile<HDP, BQ, NP>(stdO, a.don, donb, 0, 0, tid);
     gload_tile<BQ, HDP, NP>(stQt, a.qt, qtb, 0, 0, tid);
@@ -689,8 +708,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
     lstore_tile<HDP, BQ, NP>(stdO, sdO, tid);
     lstore_tile<BQ, HDP, NP>(stQt, sQt, tid);
     lstore_tile<BQ, HDP, NP>(stdOt, sdOt, tid);
+    if (BIAS_LDS && bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sBias[brow * 64 + bcol + e] = stB[e];
+    }
     __syncthreads();
     if (t + 1 < nq) {
+      if (BIAS_LDS && bias) gload_bias(q0 + BQ);
       gload_tile<HDP, BQ, NP>(stQ, a.qn, qnb, q0 + BQ, 0, tid);
       gload_tile<HDP, BQ, NP>(stdO, a.don, donb, q0 + BQ, 0, tid);
       gload_tile<BQ, HDP, NP>(stQt, a.qt, qtb, 0, q0 + BQ, tid);
@@ -708,16 +732,25 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
     }
     float bvt[2][4];
     if (bias) {
+      if (BIAS_LDS) {
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
+        for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r, j = k0 + kh * 32 + nj * 16 + (lane & 15);
-          bvt[nj][r] = (qi < a.Tq && j < a.Tk) ? bias_at(bias, qi, j, bias_ld, a) : 0.f;
-        }
+          for (int r = 0; r < 4; ++r)
+            bvt[nj][r] = sBias[(mq * 16 + (lane >> 4) * 4 + r) * 64 + kh * 32 + nj * 16 + (lane & 15)];
+        __syncthreads();                       // every wave has its bias before anyone writes P^T into the same buffer
+      } else {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r, j = k0 + kh * 32 + nj * 16 + (lane & 15);
+            bvt[nj][r] = (qi < a.Tq && j < a.Tk) ? bias_at(bias, qi, j, bias_ld, a) : 0.f;
+          }
+      }
     }
     unsigned keep_bits = 0xffu;            // dropout keep flags of this lane's 8 (nj, r) probabilities
-    if (a.drop_thresh) {
+    if (DROP && a.drop_thresh) {
       keep_bits = 0u;
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj)
@@ -753,7 +786,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
           x = mask_score(x + (bias ? bvt[nj][r] : 0.f), qi, j, len, a.Tk, mmode);
         }
         p[r] = (qi < a.Tq && x != -INFINITY) ? fast_exp(x - lse4[r]) : 0.f;
-        const float mf = ((keep_bits >> (nj * 4 + r)) & 1u) ? 1.f : 0.f;
+        const float mf = (!DROP || ((keep_bits >> (nj * 4 + r)) & 1u)) ? 1.f : 0.f;
         ds[r] = p[r] * (dp[r] * mf - dl4[r]);
         p[r] *= mf;                                      // dV sees the dropped probabilities
         if (F16) { ds[r] *= DS_SCALE; p[r] *= P_SCALE; }
@@ -826,28 +859,39 @@ void set_lds(K kernel, size_t bytes) {
 template <int HDP, int NP, bool F16 = false>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
   static const bool once = [] {
-    set_lds(&attn_fwd_kernel<HDP, NP, F16>, fwd_lds<HDP, NP>());
+    set_lds(&attn_fwd_kernel<HDP, NP, F16, false>, fwd_lds<HDP, NP>());
+    set_lds(&attn_fwd_kernel<HDP, NP, F16, true>, fwd_lds<HDP, NP>());
     return true;
   }();
   (void)once;
   dim3 grid((a.Tq + 63) / 64, a.H, a.B);
   const size_t lds = fwd_lds<HDP, NP>();
-  hipLaunchKernelGGL((attn_fwd_kernel<HDP, NP, F16>), grid, dim3(ATT_THREADS), lds, s, a);
+  if (a.drop_thresh) hipLaunchKernelGGL((attn_fwd_kernel<HDP, NP, F16, true>), grid, dim3(ATT_THREADS), lds, s, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<HDP, NP, F16, false>), grid, dim3(ATT_THREADS), lds, s, a);
   return vilco_launch_status();
 }
 
 template <int HDP, int NP, bool F16 = false>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
   static const bool once = [] {
-    set_lds(&attn_bwd_dq_kernel<HDP, NP, F16>, dq_lds<HDP, NP>());
-    set_lds(&attn_bwd_dkdv_kernel<HDP, NP, F16>, dkdv_lds<HDP, NP>());
+    set_lds(&attn_bwd_dq_kernel<HDP, NP, F16, false>, dq_lds<HDP, NP>());
+    set_lds(&attn_bwd_dq_kernel<HDP, NP, F16, true>, dq_lds<HDP, NP>());
+    set_lds(&attn_bwd_dkdv_kernel<HDP, NP, F16, false, false>, dkdv_lds<HDP, NP>());
+    set_lds(&attn_bwd_dkdv_kernel<HDP, NP, F16, true, false>, dkdv_lds<HDP, NP>());
+    set_lds(&attn_bwd_dkdv_kernel<HDP, NP, F16, false, true>, dkdv_lds<HDP, NP>());
+    set_lds(&attn_bwd_dkdv_kernel<HDP, NP, F16, true, true>, dkdv_lds<HDP, NP>());
     return true;
   }();
   (void)once;
   dim3 gq((a.Tq + 63) / 64, a.H, a.B), gk((a.Tk + 63) / 64, a.H, a.B);
   const size_t lq = dq_lds<HDP, NP>(), lk = dkdv_lds<HDP, NP>();
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16>), gq, dim3(ATT_THREADS), lq, s, a);
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NP, F16>), gk, dim3(ATT_THREADS), lk, s, a);
+  if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16, true>), gq, dim3(ATT_THREADS), lq, s, a);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16, false>), gq, dim3(ATT_THREADS), lq, s, a);
+  const bool dr = a.drop_thresh != 0;
+  if (a.bias && dr) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NP, F16, true, true>), gk, dim3(ATT_THREADS), lk, s, a);
+  else if (a.bias) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NP, F16, true, false>), gk, dim3(ATT_THREADS), lk, s, a);
+  else if (dr) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NP, F16, false, true>), gk, dim3(ATT_THREADS), lk, s, a);
+  else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NP, F16, false, false>), gk, dim3(ATT_THREADS), lk, s, a);
   return vilco_launch_status();
 }
 
