@@ -212,7 +212,7 @@ def test_sync_free_losses_match_gather_losses(dev):
     assert abs(na - nb) < 1e-4 * max(1.0, abs(na))
     assert ga.keys() == gb.keys()
     for k in ga:
-        assert rel_err(gb[k], ga[k], 1e-6) < 2e-5, k     # floor: analytically-zero key-bias gradients are 1e-12 noise
+        assert rel_err(gb[k], ga[k], 1e-5) < 2e-5, k     # floor: analytically-zero key-bias gradients are 1e-11 noise
 
 
 def test_xlnet_dropout_matches_oracle_with_same_masks(dev):

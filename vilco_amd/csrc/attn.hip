@@ -184,7 +184,8 @@ struct AttnArgs {
   float scale;
   int mode;
   // backward
-  const float* dout; const float* delta;
+  const float* dout; float* delta;     // delta[b,h,i] = dO_i . O_i: written by attn_bwd_dq, read by attn_bwd_dkdv
+  const float* o_in;                   // forward output (backward only)
   float* dq; float* dk; float* dv; float* dbias;
   // 16-bit planes (natural [tok][HDP] and transposed [d][Tp]) of k, v, q, dout
   Planes kn, vn, kt, vt, qn, don, qt, dot;
@@ -437,22 +438,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
-// delta[b,h,i] = sum_d dout[b,i,h,d] * o[b,i,h,d]
-__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ o,
-                                                         float* __restrict__ delta, int B, int H, int T, int hd, int C) {
-  const long total = (long)B * H * T;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int t = (int)(i % T);
-    const long bh = i / T;
-    const int h = (int)(bh % H), b = (int)(bh / H);
-    const float* p = dout + ((long)b * T + t) * C + h * hd;
-    const float* r = o + ((long)b * T + t) * C + h * hd;
-    float s = 0.f;
-    for (int d = 0; d < hd; ++d) s += p[d] * r[d];
-    delta[i] = s;
-  }
-}
-
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dBias)
 template <int HDP, int NP, bool F16, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
@@ -492,8 +477,27 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   const float lse = qi < a.Tq ? a.lse[row_bh + qi] : 0.f;
   // (1-p) delta in plane units.  Multiplied by the two scales one after the other: their product alone overflows fp32
   // when both tensors are tiny or zero (a clip dropped by stochastic depth has dO == 0 -> s = 2^126), delta * sdO does not
-  const float dlt = F16 ? ((qi < a.Tq ? a.delta[row_bh + qi] : 0.f) * sc.sdo) * sc.sv / a.drop_inv_keep
-                        : (qi < a.Tq ? a.delta[row_bh + qi] : 0.f) / a.drop_inv_keep;
+  // delta_i = dO_i . O_i in exact fp32: lane group g covers channels ks*32 + 8g .. +7 of this lane's query, two
+  // shuffles sum the four groups; the result is also left in a.delta for attn_bwd_dkdv (which runs after this kernel)
+  float delta_i = 0.f;
+  if (qi < a.Tq) {
+    const float* po = a.o_in + ((long)b * a.Tq + qi) * ld + h * a.hd;
+    const float* pg = a.dout + ((long)b * a.Tq + qi) * ld + h * a.hd;
+#pragma unroll
+    for (int ks = 0; ks < HDP / 32; ++ks)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int d = ks * 32 + (lane >> 4) * 8 + hh * 4;
+        if (d + 4 <= a.hd) {
+          const float4 x = *reinterpret_cast<const float4*>(po + d), y = *reinterpret_cast<const float4*>(pg + d);
+          delta_i += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+      }
+  }
+  delta_i += __shfl_xor(delta_i, 16, 64);
+  delta_i += __shfl_xor(delta_i, 32, 64);
+  if ((lane >> 4) == 0 && qi < a.Tq) a.delta[row_bh + qi] = delta_i;
+  const float dlt = F16 ? ((delta_i * sc.sdo) * sc.sv) / a.drop_inv_keep : delta_i / a.drop_inv_keep;
 
   f32x4 dqacc[HDP / 16];
 #pragma unroll
@@ -1046,15 +1050,11 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
   float* delta = reinterpret_cast<float*>(wsb);
   wsb += up((long)B * H * Tq * 4, 256);
-  const long rows = (long)B * H * Tq;
-  long blocks = (rows + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((int)blocks), dim3(256), 0, s, dout, o, delta, B, H, Tq, hd, H * hd);
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.lse = const_cast<float*>(lse); a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
   a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
-  a.dout = dout; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
+  a.dout = dout; a.delta = delta; a.o_in = o; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
   ScaleWs sw = {};
   if (precision == 3) {
     const float* const xs[4] = {q, k, v, dout};
