@@ -62,14 +62,17 @@ def synth_batch(B, device, seed=0, T=2304, Cin=2304, L=77):
     return out
 
 
-CPU_THREADS_CAP = 32        # more OpenMP threads than this only adds contention on these op sizes
-
-
 def cpu_baseline_worker():
-    """child process: oracle fwd+bwd of ONE clip of config P on the host cores; prints one JSON line."""
+    """child process: the oracle (CPU restatement of the reference's pure-PyTorch path) on the SAME workload as the
+    GPU leg -- config P, 2 clips, train-mode arithmetic (Bernoulli dropout 0.1 / droppath 0.1 / XLNet dropout 0.1),
+    fp32, 1 warm-up + 3 timed fwd+bwd steps on all host cores.  Prints one JSON line."""
     import vilco_amd.modeling as vm
     from oracle import mq_oracle
-    n = min(os.cpu_count() or 1, CPU_THREADS_CAP)
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
     torch.set_num_threads(n)
     cfg = p_config()
     torch.manual_seed(0)
@@ -77,23 +80,36 @@ def cpu_baseline_worker():
     p = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v)
          for k, v in model.state_dict().items()}
     del model
-    vl = synth_batch(1, "cpu")
+    B = int(os.environ.get("VILCO_CPU_BASELINE_CLIPS", "2"))
+    steps = int(os.environ.get("VILCO_CPU_BASELINE_STEPS", "3"))
+    vl = synth_batch(B, "cpu")
+    mq_oracle.DROP = mq_oracle.DropRandom(dropout=0.1, droppath=0.1, xl=P_XLNET["dropout"], seed=0)
+
+    def step():
+        for v in p.values():
+            if v.is_floating_point():
+                v.grad = None
+        losses, _ = mq_oracle.forward_losses(p, cfg, vl)
+        losses['final_loss'].backward()
+    step()                                            # warm-up (allocator, thread pool)
     t0 = time.time()
-    losses, _ = mq_oracle.forward_losses(p, cfg, vl)
-    losses['final_loss'].backward()
-    dt = time.time() - t0
+    for _ in range(steps):
+        step()
+    dt = (time.time() - t0) / steps
     cpu = ""
     try:
         with open("/proc/cpuinfo") as f:
             cpu = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
     except Exception:
         pass
-    print(json.dumps({"value": 1.0 / dt, "unit": "clips/s", "cores": n, "kind": "port",
-                      "sample": "1 fwd+bwd step of 1 clip (T=2304, C=2304, config P), fp32, oracle/mq_oracle.py "
-                                "(CPU restatement of the reference), %.1f s, %d threads on %s" % (dt, n, cpu)}))
+    print(json.dumps({"value": B / dt, "unit": "clips/s", "cores": n, "kind": "port",
+                      "sample": "1 warm-up + %d timed fwd+bwd steps of %d clips (T=2304, C=2304, config P, train-mode "
+                                "dropout 0.1 / droppath 0.1 / XLNet dropout 0.1), fp32, oracle/mq_oracle.py (CPU "
+                                "restatement of the reference), %.1f s per step, %d threads on %s"
+                                % (steps, B, dt, n, cpu)}))
 
 
-def cpu_baseline(timeout_s=240):
+def cpu_baseline(timeout_s=420):
     """bounded: runs in a child process (no GPU use) and is abandoned after `timeout_s`."""
     import subprocess
     try:
@@ -102,8 +118,8 @@ def cpu_baseline(timeout_s=240):
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:      # timeout / OOM on a small host: report that instead of a number
-        return {"value": None, "unit": "clips/s", "cores": min(os.cpu_count() or 1, CPU_THREADS_CAP), "kind": "port",
-                "sample": "oracle step did not finish within %d s (%s)" % (timeout_s, type(e).__name__)}
+        return {"value": None, "unit": "clips/s", "cores": os.cpu_count() or 1, "kind": "port",
+                "sample": "oracle steps did not finish within %d s (%s)" % (timeout_s, type(e).__name__)}
 
 
 def gemm_profile(step_fn, n=3):
@@ -160,6 +176,19 @@ def pmc_traffic():
         return None
 
 
+def dryrun_parts(dev, rank):
+    """VILCO_BENCH_DRYRUN=1 (tests/test_dist_cpu.py): the rank / collective protocol of this file with a small torch
+    module on CPU + gloo in place of the HIP model, so that `bench.py --gpus N` is known to terminate under torchrun
+    before it ever meets N GPUs."""
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.ReLU(), torch.nn.Linear(64, 4))
+    x = torch.randn(8, 16, generator=torch.Generator().manual_seed(rank))
+
+    def fwd_bwd():
+        model(x).pow(2).mean().backward()
+    return model, fwd_bwd
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,29 +204,39 @@ def main():
     if args.cpu_baseline_worker:
         return cpu_baseline_worker()
 
+    dry = os.environ.get("VILCO_BENCH_DRYRUN", "0") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")            # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend="gloo" if dry else "nccl")            # "nccl" IS RCCL on ROCm
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
-    import vilco_amd
-    import vilco_amd.modeling as vm
-    from vilco_amd import ops
-    vilco_amd._lib.load()                                  # no fallback: fail here if the .so is missing
-    ops.set_precision(args.precision)
+    if dry:
+        model, fwd_bwd = dryrun_parts(dev, rank)
+    else:
+        import vilco_amd
+        import vilco_amd.modeling as vm
+        from vilco_amd import ops
+        vilco_amd._lib.load()                                  # no fallback: fail here if the .so is missing
+        ops.set_precision(args.precision)
+        cfg = p_config()
+        torch.manual_seed(0)                                   # identical replicas ...
+        model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=P_XLNET))
+        model = model.to(dev).train()
+        torch.manual_seed(1000 + rank)                         # ... different dropout / droppath draws and clips per rank
+        batch = synth_batch(args.batch, dev, seed=rank)
 
-    cfg = p_config()
-    torch.manual_seed(0)
-    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=P_XLNET))
-    model = model.to(dev).train()
-    batch = synth_batch(args.batch, dev, seed=rank)
+        def fwd_bwd():
+            model(batch, is_training=True)['final_loss'].backward()
 
     reducer = None
     if distributed:
@@ -208,16 +247,15 @@ def main():
         model.zero_grad(set_to_none=True)
         if reducer is not None:
             reducer.begin()
-        losses = model(batch, is_training=True)
-        losses['final_loss'].backward()
+        fwd_bwd()
         if reducer is not None:
             reducer.finish()
-        return losses
 
     def fence():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -234,6 +272,11 @@ def main():
     ms = dt / args.steps * 1e3
     clips_per_s = world * args.batch * args.steps / dt
 
+    # Everything below is RANK-LOCAL (no collectives): rank 0 measures with the gradient exchange switched off while the
+    # other ranks wait in the final barrier.  (Round 1 ran reducer steps on rank 0 only here, whose all-reduces had
+    # no peer -- ADVICE r1.)
+    if reducer is not None:
+        reducer.enabled = False
     if rank == 0:
         out = {"metric": "clips/sec (fwd+bwd) MQ transformer T=2304 C=2304", "value": clips_per_s,
                "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -248,62 +291,73 @@ def main():
                                       "/ XLNet dropout 0.1 (mq_vilco.yaml, xlnet_config_1024.json)",
                           "clips_per_gpu": args.batch, "global_batch": world * args.batch,
                           "parallelism": "dp%d" % world},
+               "inputs": "resident in HBM before the timed region (the reference's step includes the H2D copy of the "
+                         "42 MB batch, meta_archs.py:1178: ~1 ms on PCIe 5, not part of `value`)",
                "clips_per_s_per_gpu": clips_per_s / world,
                "model_mfma_frac": clips_per_s / world * GFLOP_PER_CLIP_FWD_BWD / 1e3 / PEAK_BF16_TFLOPS}
-        gp = gemm_profile(step)
-        mfma_per_product = {"f16x2": 3, "split3": 6, "split": 3, "bf16": 1}[args.precision]
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp_kernel (all instantiations)", "achieved": gp["tflops"],
-                           "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gp["tflops"] / PEAK_BF16_TFLOPS,
-                           "traffic": pmc_traffic(), "avg_launch_us": gp["avg_launch_us"],
-                           "launches_per_step": gp["launches_per_step"],
-                           "kernel_ms_per_step": gp["kernel_ms_per_step"],
-                           "algorithmic_gflop_per_launch": gp["gflop_per_launch"],
-                           "mfma_per_algorithmic_product": mfma_per_product,
-                           "mfma_issue_frac": gp["tflops"] * mfma_per_product / PEAK_BF16_TFLOPS,
-                           "gemm_calls_ms_per_step_incl_pack_and_reduce": gp["call_ms_per_step"],
-                           "gemm_calls_tflops_incl_pack_and_reduce": gp["call_tflops"]}
-        # the optimizer step is reported separately (BASELINE.json metric = fwd+bwd): fused clip-norm + AdamW
-        from vilco_amd.utils.train_utils import make_optimizer
-        opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-4))
-        step()
-        opt.step(clip_grad_l2norm=1.0)                         # allocates state, builds the chunk plan
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            opt.step(clip_grad_l2norm=1.0)
-        e1.record()
-        torch.cuda.synchronize()
-        n_par = sum(p.numel() for p in model.parameters() if p.grad is not None)
-        opt_ms = e0.elapsed_time(e1) / 3
-        out["optimizer_step"] = {"ms": opt_ms, "params_with_grad": n_par, "kind": "fused clip_grad_norm + AdamW",
-                                 "hbm_GBps": (32.0 * n_par) / (opt_ms * 1e-3) / 1e9,
-                                 "train_step_ms_incl_optimizer": ms + opt_ms}
-        if world == 1 and args.extra_batch and args.extra_batch != args.batch:
-            # not the headline (the reference trains with 2 clips per GPU): shows what is launch-bound at batch 2
-            del opt
-            model.zero_grad(set_to_none=True)
-            big = synth_batch(args.extra_batch, dev, seed=1)
-
-            def big_step():
-                model.zero_grad(set_to_none=True)
-                model(big, is_training=True)['final_loss'].backward()
-            for _ in range(3):
-                big_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                big_step()
-            torch.cuda.synchronize()
-            dtb = (time.perf_counter() - t1) / 5
-            out["larger_batch"] = {"clips_per_gpu": args.extra_batch, "ms_per_step": dtb * 1e3,
-                                   "clips_per_s": args.extra_batch / dtb}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if dry:
+            step()                                               # a rank-local step: must not touch the process group
+            out["dryrun"] = True
+        else:
+            local_sections(out, args, model, step, dev, ms, world)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def local_sections(out, args, model, step, dev, ms, world):
+    """rank-0-only measurements after the timed region: GEMM roofline, optimizer step, larger batch, CPU baseline"""
+    gp = gemm_profile(step)
+    mfma_per_product = {"f16x2": 3, "split3": 6, "split": 3, "bf16": 1}[args.precision]
+    out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp_kernel (all instantiations)", "achieved": gp["tflops"],
+                       "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gp["tflops"] / PEAK_BF16_TFLOPS,
+                       "traffic": pmc_traffic(), "avg_launch_us": gp["avg_launch_us"],
+                       "launches_per_step": gp["launches_per_step"],
+                       "kernel_ms_per_step": gp["kernel_ms_per_step"],
+                       "algorithmic_gflop_per_launch": gp["gflop_per_launch"],
+                       "mfma_per_algorithmic_product": mfma_per_product,
+                       "mfma_issue_frac": gp["tflops"] * mfma_per_product / PEAK_BF16_TFLOPS,
+                       "gemm_calls_ms_per_step_incl_pack_and_reduce": gp["call_ms_per_step"],
+                       "gemm_calls_tflops_incl_pack_and_reduce": gp["call_tflops"]}
+    # the optimizer step is reported separately (BASELINE.json metric = fwd+bwd): fused clip-norm + AdamW
+    from vilco_amd.utils.train_utils import make_optimizer
+    opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-4))
+    step()
+    opt.step(clip_grad_l2norm=1.0)                         # allocates state, builds the chunk plan
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        opt.step(clip_grad_l2norm=1.0)
+    e1.record()
+    torch.cuda.synchronize()
+    n_par = sum(p.numel() for p in model.parameters() if p.grad is not None)
+    opt_ms = e0.elapsed_time(e1) / 3
+    out["optimizer_step"] = {"ms": opt_ms, "params_with_grad": n_par, "kind": "fused clip_grad_norm + AdamW",
+                             "hbm_GBps": (32.0 * n_par) / (opt_ms * 1e-3) / 1e9,
+                             "train_step_ms_incl_optimizer": ms + opt_ms}
+    if world == 1 and args.extra_batch and args.extra_batch != args.batch:
+        # not the headline (the reference trains with 2 clips per GPU): shows what is launch-bound at batch 2
+        del opt
+        model.zero_grad(set_to_none=True)
+        big = synth_batch(args.extra_batch, dev, seed=1)
+
+        def big_step():
+            model.zero_grad(set_to_none=True)
+            model(big, is_training=True)['final_loss'].backward()
+        for _ in range(3):
+            big_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            big_step()
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t1) / 5
+        out["larger_batch"] = {"clips_per_gpu": args.extra_batch, "ms_per_step": dtb * 1e3,
+                               "clips_per_s": args.extra_batch / dtb}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
 
 
 if __name__ == "__main__":

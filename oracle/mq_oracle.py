@@ -21,6 +21,63 @@ import torch
 import torch.nn.functional as F
 
 
+# ------------------------------------------------------------------------------ dropout contexts
+# The reference trains with nn.Dropout / stochastic depth on (mq_vilco.yaml: dropout 0.1, droppath 0.1; XLNet 0.1).
+# DROP = None restates eval-mode arithmetic.  A context object supplies the MASK FACTORS (0 or 1/(1-p)) per site:
+#   DropReplay  -- the factors the HIP path drew (ops.dropout_log), consumed per site in call order (parity tests);
+#   DropRandom  -- fresh Bernoulli masks, i.e. the arithmetic the reference does in train mode (cpu_baseline timing).
+# Sites: 'proj_drop' (blocks.py:264,405), 'mlp_drop' (:533-540, two per block), 'droppath' (per-sample factors [B],
+# :628-641), and XLNet's seven sites (see xlnet_layer).  Factors arrive token-major ([B,T,C]) like the HIP tensors.
+DROP = None
+
+
+class DropReplay:
+    def __init__(self, log, mask_fn):
+        """log: ops.dropout_log entries (site, p, seed, shape) or (site, tensor); mask_fn(p, seed, shape) -> factors"""
+        self.q = {}
+        for e in log:
+            m = e[1] if len(e) == 2 else mask_fn(e[1], e[2], e[3])
+            self.q.setdefault(e[0], []).append(m)
+        self.p = {'droppath': 1.0, 'proj_drop': 1.0, 'mlp_drop': 1.0, 'xl': 1.0}     # > 0: every site is live
+
+    def factor(self, site, shape, dtype):
+        m = self.q[site].pop(0)
+        assert tuple(m.shape) == tuple(shape), (site, tuple(m.shape), tuple(shape))
+        return m.to(dtype).cpu()
+
+    def leftover(self):
+        return {k: len(v) for k, v in self.q.items() if v}
+
+
+class DropRandom:
+    def __init__(self, dropout=0.1, droppath=0.1, xl=0.1, seed=0):
+        self.p = {'droppath': droppath, 'proj_drop': dropout, 'mlp_drop': dropout, 'xl': xl}
+        self.g = torch.Generator().manual_seed(seed)
+
+    def factor(self, site, shape, dtype):
+        p = self.p.get(site, self.p['xl'])
+        return torch.bernoulli(torch.full(tuple(shape), 1.0 - p), generator=self.g).to(dtype) / (1.0 - p)
+
+
+def _live(site):
+    return DROP is not None and DROP.p.get(site, DROP.p['xl']) > 0.0
+
+
+def _drop_cf(site, t):
+    """dropout of a channel-first [B,C,T] tensor with token-major factors"""
+    if not _live(site):
+        return t
+    B, Cn, T = t.shape
+    return t * DROP.factor(site, (B, T, Cn), t.dtype).permute(0, 2, 1)
+
+
+def _drop_path(t):
+    """per-sample stochastic depth (drop_path, blocks.py:628-641) of [B, ...]"""
+    if not _live('droppath'):
+        return t
+    return t * DROP.factor('droppath', (t.shape[0],), t.dtype).view(-1, *([1] * (t.dim() - 1)))
+
+
 # ------------------------------------------------------------------------------ operators
 def masked_conv1d(x, mask, w, b=None, stride=1, groups=1):
     """MaskedConv1D.forward, blocks.py:106-130: conv, mask[::stride] (nearest), multiply."""
@@ -77,7 +134,7 @@ def masked_mhca(p, pre, x, mask, n_head, stride):
     v = ln(p, pre + 'value_norm.', v)
     q, k, v = conv1x1(p, pre + 'query.', q), conv1x1(p, pre + 'key.', k), conv1x1(p, pre + 'value.', v)
     out = _attend(q, k, v, kv_mask[:, 0, :], n_head)
-    return conv1x1(p, pre + 'proj.', out) * qx_mask.to(out.dtype), qx_mask
+    return _drop_cf('proj_drop', conv1x1(p, pre + 'proj.', out)) * qx_mask.to(out.dtype), qx_mask
 
 
 def masked_mha(p, pre, x, mask_float, enc, enc_mask, n_head):
@@ -86,7 +143,7 @@ def masked_mha(p, pre, x, mask_float, enc, enc_mask, n_head):
     k = conv1x1(p, pre + 'key.', enc)
     v = conv1x1(p, pre + 'value.', enc)
     out = _attend(q, k, v, enc_mask.bool(), n_head)
-    return conv1x1(p, pre + 'proj.', out) * mask_float
+    return _drop_cf('proj_drop', conv1x1(p, pre + 'proj.', out)) * mask_float
 
 
 def channel_attention(p, pre, x, n_head):
@@ -102,13 +159,13 @@ def channel_attention(p, pre, x, n_head):
 
 
 def channel_block(p, pre, x, n_head):
-    """ChannelBlock.forward, blocks.py:459-466: norm1 is never applied, no mask, eval-mode drop_path."""
+    """ChannelBlock.forward, blocks.py:459-466: norm1 is never applied, no mask."""
     x = x.permute(0, 2, 1)
-    x = x + channel_attention(p, pre + 'attn.', x, n_head)
+    x = x + _drop_path(channel_attention(p, pre + 'attn.', x, n_head))
     h = F.layer_norm(x, (x.shape[-1],), p[pre + 'norm2.weight'], p[pre + 'norm2.bias'], 1e-5)
     h = F.linear(F.gelu(F.linear(h, p[pre + 'mlp.0.weight'], p[pre + 'mlp.0.bias'])),
                  p[pre + 'mlp.2.weight'], p[pre + 'mlp.2.bias'])
-    return (x + h).permute(0, 2, 1)
+    return (x + _drop_path(h)).permute(0, 2, 1)
 
 
 def adapter(p, pre, x):
@@ -119,10 +176,10 @@ def adapter(p, pre, x):
 
 def transformer_block(p, pre, x, mask, n_head, stride, t_c_alpha, cross_y=None, cross_mask=None,
                       adapter_pre=None):
-    """TransformerBlock.forward, blocks.py:561-593, deterministic (no stochastic depth / dropout)."""
-    def dp(name, v):          # AffineDropPath scale (blocks.py:669-670) or Identity when droppath == 0
+    """TransformerBlock.forward, blocks.py:561-593 (dropout / stochastic depth through the DROP context)."""
+    def dp(name, v):          # AffineDropPath: scale then drop_path (blocks.py:669-670); Identity when droppath == 0
         key = pre + name + '.scale'
-        return p[key] * v if key in p else v
+        return _drop_path(p[key] * v) if key in p else v
 
     h = ln(p, pre + 'ln1.', x)
     out, out_mask = masked_mhca(p, pre + 'attn.', h, mask, n_head, stride)
@@ -135,8 +192,8 @@ def transformer_block(p, pre, x, mask, n_head, stride, t_c_alpha, cross_y=None, 
         c = masked_mha(p, pre + 'cross_attn.', ln(p, pre + 'ln3.', out), mf, ln(p, pre + 'ln3.', cross_y),
                        cross_mask, n_head)
         out = out * mf + dp('drop_path_attn', c)
-    m = F.conv1d(F.gelu(conv1x1(p, pre + 'mlp.0.', ln(p, pre + 'ln2.', out))), p[pre + 'mlp.3.weight'],
-                 p[pre + 'mlp.3.bias'])
+    m = _drop_cf('mlp_drop', F.gelu(conv1x1(p, pre + 'mlp.0.', ln(p, pre + 'ln2.', out))))
+    m = _drop_cf('mlp_drop', F.conv1d(m, p[pre + 'mlp.3.weight'], p[pre + 'mlp.3.bias']))
     out = out + dp('drop_path_mlp', m * mf)
     if stride == 1:
         out = t_c_alpha * out + (1 - t_c_alpha) * channel_block(p, pre + 'channel_attn.', h, n_head)
@@ -153,6 +210,12 @@ def xlnet_layer(p, pre, x, mask, n_head, drop=None):
     (:308), 'xl_attn_out' [B,T,D] (:327), 'xl_ff_inner' [B,T,d_inner] (:486), 'xl_ff_out' [B,T,D] (:488),
     'xl_output' [B,T,D] (:1280)."""
     B, T, D = x.shape
+    if drop is None and _live('xl'):
+        d_inner = p[pre + 'ff.layer_1.weight'].shape[0]
+        shapes = {'xl_input': (B, T, D), 'xl_pos_emb': (B, 2 * T, D), 'attn_prob': (B, n_head, T, T),
+                  'xl_attn_out': (B, T, D), 'xl_ff_inner': (B, T, d_inner), 'xl_ff_out': (B, T, D),
+                  'xl_output': (B, T, D)}
+        drop = {k: DROP.factor(k, sh, x.dtype) for k, sh in shapes.items()}      # forward order of the seven sites
     dm = (lambda k, t: t) if drop is None else (lambda k, t: t * drop[k].to(t.dtype))
     x = dm('xl_input', x)
     h = x.transpose(0, 1)                                           # [T,B,D]

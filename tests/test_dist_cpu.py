@@ -14,8 +14,13 @@ class Tiny(torch.nn.Module):
         self.unused = torch.nn.Linear(16, 16)      # never called: must be pruned from the plan
         self.b = torch.nn.Linear(16, 4)
 
-    def forward(self, x):
-        return self.b(torch.relu(self.a(x)))
+        self.sometimes = torch.nn.Linear(16, 16)   # skipped by rank 1 in step 1: zero-filled, bucket still launched
+
+    def forward(self, x, use_sometimes=True):
+        h = torch.relu(self.a(x))
+        if use_sometimes:
+            h = h + self.sometimes(h)
+        return self.b(h)
 
 
 def _worker(rank, world, port, q):
@@ -30,7 +35,7 @@ def _worker(rank, world, port, q):
         x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 * step + rank))
         model.zero_grad(set_to_none=True)
         red.begin()
-        model(x).pow(2).sum().backward()
+        model(x, use_sometimes=not (rank == 1 and step == 1)).pow(2).sum().backward()
         local = {k: p.grad.clone().numpy() for k, p in model.named_parameters() if p.grad is not None}
         red.finish()
         outs.append((local, {k: p.grad.clone().numpy() for k, p in model.named_parameters() if p.grad is not None}))
@@ -59,6 +64,27 @@ def test_grad_reducer_gloo_world2():
         l1, r1 = res[1][step]
         assert "unused.weight" not in r0
         for k in l0:
-            want = (l0[k] + l1[k]) / 2
+            want = (l0[k] + (l1[k] if k in l1 else 0.0)) / 2       # a rank without a gradient contributes zeros
             assert np.allclose(r0[k], want, atol=1e-6), k
             assert np.allclose(r1[k], want, atol=1e-6), k
+
+
+def test_bench_protocol_two_ranks():
+    """`bench.py --gpus 2` under torch.distributed.run terminates and rank 0 prints ONE JSON line: the rank /
+    collective protocol of bench.py exercised on CPU + gloo (VILCO_BENCH_DRYRUN swaps the HIP model for a small torch
+    module; everything else -- reducer, fences, the rank-local sections after the timed region -- is the real code)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VILCO_BENCH_DRYRUN="1")
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=240,
+                       env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["dryrun"] is True

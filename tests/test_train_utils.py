@@ -85,6 +85,33 @@ def test_fused_optimizer_vs_torch(dev, kind, clip):
 
 
 @pytest.mark.gpu
+def test_fused_optimizer_duplicate_param_uses_clipped_grad(dev):
+    """a parameter listed twice (the `pets.*` adapter aliases, train_utils.py:108-113) is stepped twice per
+    iteration by torch.optim, both times with the gradient clip_grad_norm_ scaled in place"""
+    import warnings
+    from vilco_amd.utils.train_utils import FusedOptimizer
+    torch.manual_seed(1)
+    shapes = [(40, 9), (130,), (7, 3)]
+    ref_p = [torch.randn(s, dtype=torch.float64, requires_grad=True) for s in shapes]
+    hip_p = [p.detach().float().to(dev).requires_grad_(True) for p in ref_p]
+    mk = lambda ps: [{"params": [ps[0], ps[1], ps[1]], "weight_decay": 0.05}, {"params": [ps[2]], "weight_decay": 0.0}]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = torch.optim.AdamW(mk(ref_p), lr=1e-2)
+        hip = FusedOptimizer(mk(hip_p), lr=1e-2, kind="AdamW")
+    for step in range(3):
+        for a, b in zip(ref_p, hip_p):
+            g = 5.0 * torch.randn(a.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(7 * step + a.numel()))
+            a.grad, b.grad = g.clone(), g.float().to(dev)
+        torch.nn.utils.clip_grad_norm_(ref_p, 0.5)
+        ref.step()
+        hip.step(clip_grad_l2norm=0.5)
+        for a, b in zip(ref_p, hip_p):
+            err = (b.detach().cpu().double() - a.detach()).abs().max() / a.detach().abs().max()
+            assert err < 2e-6, (step, tuple(a.shape), float(err))
+
+
+@pytest.mark.gpu
 def test_train_step_runs_and_descends(dev):
     """three iterations of the glue on a golden-size model: loss decreases with a plain AdamW schedule"""
     from parity_util import golden_inputs, load_golden, build_hip_model, golden_cfg

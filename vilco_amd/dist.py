@@ -8,24 +8,48 @@ commented out, train_utils.py:298); its intent -- torchrun + DistributedSampler 
 VQ's `find_unused_parameters=True` DDP (VQ/train_cl.py:112-117) are what this mirrors: 107 of the 465
 tensors never get a gradient at arch (2,2,5), so the bucket plan is pruned statically after the first
 backward instead of searching the graph every step.
+
+Memory traffic: a finished gradient is copied ONCE into its slot of the bucket's flat buffer (the
+collective needs contiguous memory); after the all-reduce `p.grad` is re-pointed at that slot (a view, no
+copy back) and the average is taken by the collective itself (ReduceOp.AVG on RCCL; gloo has no AVG, so
+the CPU test path divides).  Kernels that produce weight gradients can ask `grad_slot(p)` for the slot and
+write there directly, which removes the remaining copy.
+
+Robustness (every rank must issue the same collectives in the same order):
+  * the plan is built from the UNION over ranks of the gradient-bearing parameters (one MAX all-reduce of a
+    bitmask), so rank-local differences cannot produce different bucket layouts;
+  * a planned parameter that got no gradient in some later step is zero-filled and its bucket still
+    launched (in `finish`), instead of one rank asserting while its peers wait in a collective;
+  * `rebuild()` drops the plan (call it when the set of trained parameters changes, e.g. a new task).
 """
 import torch
 import torch.distributed as dist
 
+DEFAULT_BUCKET_MB = 64      # xGMI rings are per-link bound: few large collectives beat many small ones
+
 
 class GradReducer:
-    def __init__(self, model, bucket_mb=64, group=None):
+    def __init__(self, model, bucket_mb=DEFAULT_BUCKET_MB, group=None):
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group)
         self.bucket_bytes = int(bucket_mb * 2 ** 20)
         self.buckets = None          # built after the first backward (static pruning of unused params)
+        self.enabled = True          # False: hooks do nothing (rank-local steps, e.g. profiling on rank 0 only)
+        self._avg = dist.get_backend(group) == "nccl"
         self._hooks = []
         self._pending = []
+        self._slot = {}              # id(param) -> (bucket index, view)
+        self._handed = set()
+        self._next = 0               # index of the next bucket to launch (strict order)
 
     # -- plan -------------------------------------------------------------------------------
     def _build(self):
-        used = [p for p in self.model.parameters() if p.requires_grad and p.grad is not None]
+        cand = [p for p in self.model.parameters() if p.requires_grad]
+        flags = torch.tensor([1 if p.grad is not None else 0 for p in cand], dtype=torch.int32,
+                             device=cand[0].device)
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)      # union over ranks
+        used = [p for p, f in zip(cand, flags.tolist()) if f]
         used.reverse()               # parameters() order is roughly forward order -> reverse ~ backward order
         self.buckets, cur, cur_bytes = [], [], 0
         for p in used:
@@ -37,7 +61,8 @@ class GradReducer:
         if cur:
             self.buckets.append(self._make_bucket(cur))
         for bi, b in enumerate(self.buckets):
-            for p in b["params"]:
+            for p, v in zip(b["params"], b["views"]):
+                self._slot[id(p)] = (bi, v)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
     @staticmethod
@@ -48,42 +73,83 @@ class GradReducer:
         for p in params:
             views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        return {"params": list(params), "flat": flat, "views": views, "left": len(params), "work": None}
+        return {"params": list(params), "flat": flat, "views": views, "left": len(params), "work": None,
+                "done": set()}
+
+    def grad_slot(self, p):
+        """the bucket slot of parameter `p` for a kernel to write its gradient into, or None (no plan yet, `p` not
+        planned, reducer disabled, or the slot was already handed out in this step: a parameter used twice gets its
+        second gradient in ordinary memory and autograd sums the two)."""
+        if not self.enabled or self.buckets is None:
+            return None
+        s = self._slot.get(id(p))
+        if s is None or id(p) in self._handed:
+            return None
+        self._handed.add(id(p))
+        return s[1]
 
     def _make_hook(self, bi):
         def hook(param):
+            if not self.enabled:
+                return
             b = self.buckets[bi]
+            if id(param) in b["done"]:
+                return
+            b["done"].add(id(param))
             b["left"] -= 1
-            if b["left"] == 0:
-                self._launch(b)
+            # collectives must be issued in the same order on every rank: bucket i goes out only after 0..i-1 (a
+            # bucket that is not complete on this rank holds the later ones back until `finish`)
+            while self._next < len(self.buckets) and self.buckets[self._next]["left"] == 0:
+                self._launch(self.buckets[self._next])
+                self._next += 1
         return hook
 
     def _launch(self, b):
-        torch._foreach_copy_(b["views"], [p.grad for p in b["params"]])
-        b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        src, dst = [], []
+        for p, v in zip(b["params"], b["views"]):
+            if p.grad is None:
+                v.zero_()                                   # planned but unused in this step on this rank
+            elif p.grad.data_ptr() != v.data_ptr():         # not produced in place
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         self._pending.append(b)
 
     # -- per step ---------------------------------------------------------------------------
     def begin(self):
+        self._handed = set()
+        self._next = 0
         if self.buckets is not None:
             for b in self.buckets:
-                b["left"], b["work"] = len(b["params"]), None
+                b["left"], b["work"], b["done"] = len(b["params"]), None, set()
             self._pending = []
 
     def finish(self):
-        """wait for the collectives and leave the averaged gradient in every p.grad"""
+        """wait for the collectives and leave the averaged gradient in every planned p.grad (views of the flat
+        buckets: nothing is copied back)"""
+        if not self.enabled:
+            return
         if self.buckets is None:
             self._build()
-            for b in self.buckets:       # first step: nothing was launched from hooks yet
-                self._launch(b)
-        else:
-            for b in self.buckets:       # a bucket whose hook count did not reach 0 would deadlock peers
-                assert b["work"] is not None, "a parameter that had a gradient in step 1 got none now"
-        for b in self._pending:
-            b["work"].wait()
-            b["flat"].div_(self.world)
-            torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
+        for b in self.buckets[self._next:]:      # first step, or buckets held back by an incomplete one
+            self._launch(b)
+        self._next = len(self.buckets)
+        with torch.no_grad():
+            for b in self._pending:
+                b["work"].wait()
+                if not self._avg:
+                    b["flat"].div_(self.world)
+                for p, v in zip(b["params"], b["views"]):
+                    p.grad = v
         self._pending = []
+
+    def rebuild(self):
+        """forget the plan (the set of trained parameters changed); the next `finish` builds a new one"""
+        self.remove()
+        self.buckets, self._slot, self._pending = None, {}, []
 
     def remove(self):
         for h in self._hooks:

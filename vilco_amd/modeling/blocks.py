@@ -55,7 +55,10 @@ def _drop_rowscale(x, drop_prob, training):
         return None
     keep = 1.0 - drop_prob
     m = torch.floor(keep + torch.rand(x.shape[0], dtype=x.dtype, device=x.device))
-    return (m / keep).contiguous()
+    rs = (m / keep).contiguous()
+    if ops.dropout_log is not None:          # parity tests replay the factors into the oracle
+        ops.dropout_log.append(("droppath", rs))
+    return rs
 
 
 # ------------------------------------------------------------------------------ MaskedConv1D

@@ -68,11 +68,17 @@ _drop_counter = [0]
 dropout_log = None
 
 
+def _rank():
+    """data-parallel replicas seeded alike must still draw different masks"""
+    import torch.distributed as dist
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def _new_drop(site, p, shape):
     if p <= 0.0:
         return (0.0, 0)
     _drop_counter[0] += 1
-    seed = (torch.initial_seed() * 0x9E3779B1 + _drop_counter[0] * 0x85EBCA6B) & 0xFFFFFFFF
+    seed = ((torch.initial_seed() + 0x632BE5AB * _rank()) * 0x9E3779B1 + _drop_counter[0] * 0x85EBCA6B) & 0xFFFFFFFF
     if dropout_log is not None:
         dropout_log.append((site, float(p), int(seed), tuple(int(x) for x in shape)))
     return (float(p), int(seed))

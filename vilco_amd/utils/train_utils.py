@@ -112,6 +112,8 @@ class FusedOptimizer(optim.Optimizer):
         lr = (C.c_float * ng)(*[float(g['lr']) for g in self.param_groups])
         wd = (C.c_float * ng)(*[float(g['weight_decay']) for g in self.param_groups])
         g0 = self.param_groups[0]
+        coef = None      # clip coefficient of pass 0, reused by every pass: clip_grad_norm_ scales p.grad in place
+                         # (train_utils.py:343-347), so a parameter listed twice is stepped twice with the CLIPPED gradient
         for k, items in enumerate(passes):
             for p, _ in items:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
@@ -134,7 +136,6 @@ class FusedOptimizer(optim.Optimizer):
                                  [self.state[p]['exp_avg_sq'].data_ptr() if self.kind == "AdamW" else 0 for p, _ in items]],
                                 dtype=torch.int64).to(items[0][0].device, non_blocking=True)
             n = len(items)
-            coef = None
             if k == 0:
                 coef = torch.empty(2, dtype=torch.float32, device=items[0][0].device)
                 _lib.check(lib.vilco_grad_norm(ptrs.data_ptr(), plan['numel'].data_ptr(), plan['chunk_tensor'].data_ptr(),
