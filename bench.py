@@ -62,17 +62,36 @@ def synth_batch(B, device, seed=0, T=2304, Cin=2304, L=77):
     return out
 
 
+CPU_THREADS_CAP = 64        # torch's CPU ops at these sizes stop scaling (and then slow down) beyond ~one socket's cores
+
+
 def cpu_baseline_worker():
     """child process: the oracle (CPU restatement of the reference's pure-PyTorch path) on the SAME workload as the
     GPU leg -- config P, 2 clips, train-mode arithmetic (Bernoulli dropout 0.1 / droppath 0.1 / XLNet dropout 0.1),
-    fp32, 1 warm-up + 3 timed fwd+bwd steps on all host cores.  Prints one JSON line."""
+    fp32, 1 warm-up + up to 3 timed fwd+bwd steps.  Prints one JSON line after EVERY step, so the parent
+    can stop it when its time budget is spent and still report what was measured."""
     import vilco_amd.modeling as vm
     from oracle import mq_oracle
-    n = os.cpu_count() or 1
+    logical = os.cpu_count() or 1
     try:
-        n = len(os.sched_getaffinity(0))
+        logical = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    physical = logical
+    try:      # distinct (physical id, core id) pairs = physical cores
+        cores, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for l in f:
+                if l.startswith("physical id"):
+                    phys = l.split(":")[1].strip()
+                elif l.startswith("core id"):
+                    core = l.split(":")[1].strip()
+                    cores.add((phys, core))
+        if cores:
+            physical = min(len(cores), logical)
+    except Exception:
+        pass
+    n = max(1, min(physical, CPU_THREADS_CAP))
     torch.set_num_threads(n)
     cfg = p_config()
     torch.manual_seed(0)
@@ -84,6 +103,12 @@ def cpu_baseline_worker():
     steps = int(os.environ.get("VILCO_CPU_BASELINE_STEPS", "3"))
     vl = synth_batch(B, "cpu")
     mq_oracle.DROP = mq_oracle.DropRandom(dropout=0.1, droppath=0.1, xl=P_XLNET["dropout"], seed=0)
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
 
     def step():
         for v in p.values():
@@ -91,35 +116,48 @@ def cpu_baseline_worker():
                 v.grad = None
         losses, _ = mq_oracle.forward_losses(p, cfg, vl)
         losses['final_loss'].backward()
-    step()                                            # warm-up (allocator, thread pool)
+
+    def report(dt, what):
+        print(json.dumps({"value": B / dt, "unit": "clips/s", "cores": n, "kind": "port",
+                          "sample": "%s of %d clips (T=2304, C=2304, config P, train-mode dropout 0.1 / droppath 0.1 / "
+                                    "XLNet dropout 0.1), fp32, oracle/mq_oracle.py (CPU restatement of the reference), "
+                                    "%.1f s per step, %d threads (host: %d physical cores / %d logical, %s)"
+                                    % (what, B, dt, n, physical, logical, cpu)}), flush=True)
     t0 = time.time()
-    for _ in range(steps):
+    step()                                            # warm-up (allocator, thread pool)
+    report(time.time() - t0, "the warm-up fwd+bwd step only (timed steps did not fit the budget)")
+    t0 = time.time()
+    for i in range(steps):
         step()
-    dt = (time.time() - t0) / steps
-    cpu = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            cpu = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
-    except Exception:
-        pass
-    print(json.dumps({"value": B / dt, "unit": "clips/s", "cores": n, "kind": "port",
-                      "sample": "1 warm-up + %d timed fwd+bwd steps of %d clips (T=2304, C=2304, config P, train-mode "
-                                "dropout 0.1 / droppath 0.1 / XLNet dropout 0.1), fp32, oracle/mq_oracle.py (CPU "
-                                "restatement of the reference), %.1f s per step, %d threads on %s"
-                                % (steps, B, dt, n, cpu)}))
+        report((time.time() - t0) / (i + 1), "1 warm-up + %d timed fwd+bwd steps" % (i + 1))
 
 
-def cpu_baseline(timeout_s=420):
-    """bounded: runs in a child process (no GPU use) and is abandoned after `timeout_s`."""
+def cpu_baseline(timeout_s=150):
+    """bounded: runs in a child process (no GPU use); after `timeout_s` the child is stopped (its own PID) and the last
+    line it printed is the result."""
     import subprocess
+    import threading
+    lines = []
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"],
-                           capture_output=True, text=True, timeout=timeout_s)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        return json.loads(line)
-    except Exception as e:      # timeout / OOM on a small host: report that instead of a number
-        return {"value": None, "unit": "clips/s", "cores": os.cpu_count() or 1, "kind": "port",
-                "sample": "oracle steps did not finish within %d s (%s)" % (timeout_s, type(e).__name__)}
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+
+        def reader():
+            for l in proc.stdout:
+                if l.startswith("{"):
+                    lines.append(l)
+        th = threading.Thread(target=reader, daemon=True)
+        th.start()
+        try:
+            proc.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.wait()
+        th.join(timeout=5)
+        return json.loads(lines[-1])
+    except Exception as e:      # nothing finished (OOM on a small host, ...): report that instead of a number
+        return {"value": None, "unit": "clips/s", "cores": min(os.cpu_count() or 1, CPU_THREADS_CAP), "kind": "port",
+                "sample": "no oracle step finished within %d s (%s)" % (timeout_s, type(e).__name__)}
 
 
 def gemm_profile(step_fn, n=3):

@@ -267,6 +267,19 @@ int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, co
                      float momentum, const float* tensor_step, const float* norm_coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Continual-learning regularisers of MQ/libs/cl_methods/EWC.py:6-22 (get_regularized_loss) and MAS.py:5-21   */
+/* (get_mas_regularized_loss), called per iteration from train_utils.py:337-344, as ONE multi-tensor launch:    */
+/*   out[0] = lambda * sum_t sum_{i < numel[t]} F_t[i] (opt_t[i] - p_t[i])^2,   grad_t[i] -= 2 lambda F (opt - p) */
+/* ptrs = device int64 [4][n]: parameter, its gradient (accumulated into), importance F (Fisher / |grad|),      */
+/* consolidated value opt; numel[t] = elements of opt_t (a PREFIX of the parameter when the class head has grown */
+/* since the task, EWC.py:19-21).  Same chunk table as the optimizer.  shared_params != 0: some parameter occurs */
+/* in more than one entry (several consolidated tasks) -> gradient accumulated with atomics.                    */
+/* ------------------------------------------------------------------------------------------ */
+int vilco_cl_penalty(const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                     const int64_t* chunk_off, int32_t n, int32_t nchunks, int32_t chunk, float lambda,
+                     int32_t shared_params, float* partial, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* 1-D NMS on the device, replacing nms_1d_cpu (MQ/libs/utils/csrc/nms_cpu.cpp).                 */
 /* Segments of all classes are passed concatenated; seg_off[nseg+1] gives each class's range      */
 /* (batched_nms's per-class loop, nms.py:124-152, becomes one launch: one workgroup per class).   */

@@ -536,3 +536,53 @@ def decode_single_video(cfg, pts, masks, cls_logits, offsets):
         scores.append(prob[ok])
         labels.append(torch.fmod(idx, cfg['num_classes'])[ok])
     return torch.cat(segs), torch.cat(scores), torch.cat(labels)
+
+
+# ------------------------------------------------------------------------------ ViLCo extras
+def ssl_embeddings(p, fpn_feats, fpn_masks, narration, narr_token_mask):
+    """narration / video embeddings of the narration-SSL branch, meta_archs.py:794-811.
+    fpn_feats: list of [B,C,T_l], fpn_masks: list of bool [B,1,T_l]; narration [B,Cn,n], narr_token_mask [B,1,n]."""
+    nf = F.linear(narration.permute(0, 2, 1), p['narration_encoder.weight'], p['narration_encoder.bias']).permute(0, 2, 1)
+    m1 = narr_token_mask.to(nf.dtype)
+    den = m1.sum(dim=2)
+    den = torch.where(den == 0, torch.ones_like(den), den)
+    narr = F.normalize((nf * m1).sum(dim=2) / den, dim=1)
+    pooled = []
+    for f, m in zip(fpn_feats, fpn_masks):
+        mf = m.to(f.dtype)
+        d = mf.sum(dim=2)
+        d = torch.where(d == 0, torch.ones_like(d), d)
+        pooled.append((f * mf).sum(dim=2) / d)
+    video = F.normalize(torch.stack(pooled).mean(dim=0), dim=1)
+    return narr, video
+
+
+def masked_contrastive_loss(text, video, mask, memory, temperature=0.07):
+    """InfoNCE of each modality against the memory bank, positives first (meta_archs.py:1351-1372)."""
+    t, v = text[mask], video[mask]
+    pos = (t * v).sum(dim=1, keepdim=True)
+    lt = torch.cat([pos, t @ memory.T], dim=1) / temperature
+    lv = torch.cat([pos, v @ memory.T], dim=1) / temperature
+    tgt = torch.zeros(t.shape[0], dtype=torch.long)
+    return (F.cross_entropy(lt, tgt) + F.cross_entropy(lv, tgt)) / 2
+
+
+def cl_penalty(named_params, importance_list, optpar_list, lam):
+    """EWC.get_regularized_loss / MAS.get_mas_regularized_loss minus the base loss (EWC.py:6-22, MAS.py:5-21):
+    lam * sum_tasks sum_names['scale' not in name] sum F (opt - p[:len(opt)])^2."""
+    total = 0.0
+    for imp_d, opt_d in zip(importance_list, optpar_list):
+        for name, prm in named_params:
+            if 'scale' not in name and name in imp_d:
+                opt = opt_d[name]
+                total = total + (imp_d[name] * (opt - prm[:opt.size(0)]).pow(2)).sum() * lam
+    return total
+
+
+def bic_correct(logits, splits, alphas, betas):
+    """BiC bias layers on class-range slices of the logits (meta_archs.py:823-836); logits [..., ncls]."""
+    parts, lo = [], 0
+    for hi, a, b in zip(splits, alphas, betas):
+        parts.append(a * logits[..., lo:hi] + b)
+        lo = hi
+    return torch.cat(parts, dim=-1)

@@ -41,3 +41,98 @@ def video_list(T, Cin, Ctxt, L, B=2, seed=0, short=17):
                     'feat_num_frames': 16, 'segmentation_labels': torch.zeros(t, NCLS),
                     'prompt_feature': torch.randn(Ctxt, lb, generator=g)})
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Episode case (BASELINE configs[2] scaled down): 2 query-incremental tasks x 3 iterations of the ViLCo recipe --
+# L2P prompt pool, time adapters (hard-wired to T = 1024 in the reference, meta_archs.py:682) with their EMA,
+# class-head growth between the tasks, a new optimizer per task.  Train mode with dropout = droppath = 0 (and the
+# tiny XLNet JSON's dropout 0) is deterministic, so the imported reference and the HIP path can be compared step by
+# step.  Tensors with more than BIG elements (the adapters' T x 5T Linear layers) are stored as a strided sample.
+EP_T, EP_D, EP_CIN, EP_CTXT, EP_H = 1024, 32, 48, 24, 4
+EP_NCLS0, EP_NEW = 4, 3
+BIG, SAMPLE_STRIDE = 200_000, 997
+
+
+def episode_overrides():
+    o = overrides(D=EP_D, T=EP_T, Cin=EP_CIN, Ctxt=EP_CTXT, H=EP_H, use_xl=True, droppath=0.0, al_loss_weight=0.2,
+                  cl=dict(name='l2p', prompt_pool=True, pool_size=10, topk=4, length=5, embed_dim=EP_CTXT,
+                          use_adapt=True, adapt_blocks=[0, 1], memory_size=8, type_sampling='random'))
+    o['dataset']['num_classes'] = EP_NCLS0
+    o['opt'] = dict(type='AdamW', momentum=0.9, weight_decay=0.05, learning_rate=1e-3, epochs=1, warmup=True,
+                    warmup_epochs=1, schedule_type='cosine', schedule_steps=[], schedule_gamma=0.1)
+    o['train_cfg']['clip_grad_l2norm'] = 1.0
+    return o
+
+
+def episode_clip(idx, labels, T=EP_T, L=9):
+    """clip `idx` with two ground-truth moments of the given class ids"""
+    g = torch.Generator().manual_seed(5000 + idx)
+    t = T - 23 * (idx % 3)
+    segs = torch.tensor([[40.0 + 7 * idx, 150.0 + 11 * idx], [300.5 + 5 * idx, 620.25 - 9 * idx]])
+    return {'video_id': 'ep%d' % idx, 'id': 'ep%d' % idx, 'feats': torch.randn(EP_CIN, t, generator=g), 'segments': segs,
+            'labels': torch.tensor(labels), 'fps': 30.0, 'duration': 400.0, 'feat_stride': 16, 'feat_num_frames': 16,
+            'segmentation_labels': torch.zeros(t, 8), 'prompt_feature': torch.randn(EP_CTXT, L - (idx % 2), generator=g)}
+
+
+def episode_batches(task):
+    """four batches of two clips per task; task 1 replays clips of task 0 next to the new classes 4..6"""
+    if task == 0:
+        return [[episode_clip(0, [0, 1]), episode_clip(1, [2, 3])], [episode_clip(2, [1, 2]), episode_clip(3, [3, 0])],
+                [episode_clip(4, [0, 2]), episode_clip(5, [1, 3])], [episode_clip(10, [3, 1]), episode_clip(11, [2, 0])]]
+    return [[episode_clip(6, [4, 5]), episode_clip(0, [0, 1])], [episode_clip(7, [6, 4]), episode_clip(8, [5, 6])],
+            [episode_clip(9, [4, 6]), episode_clip(2, [1, 2])], [episode_clip(12, [5, 4]), episode_clip(13, [6, 5])]]
+
+
+def seeded_tensor(name, shape, scale):
+    """deterministic stand-in for a tensor too large to store (same bits wherever torch's CPU generator runs)"""
+    g = torch.Generator().manual_seed(sum(ord(c) * (i + 1) for i, c in enumerate(name)) % (2 ** 31))
+    return scale * torch.randn(shape, generator=g)
+
+
+def compact(t):
+    """what a golden keeps of a tensor: everything, or (for > BIG elements) a strided sample + the two norms"""
+    if t.numel() <= BIG:
+        return t.clone()
+    f = t.detach().reshape(-1).double()
+    return {'sample': f[::SAMPLE_STRIDE].float().clone(), 'sum': float(f.sum()), 'l2': float(f.norm()), 'shape': tuple(t.shape)}
+
+
+def perturb_episode_state(model):
+    """shared by the generator (reference model) and the tests (HIP model): the initial weights of the episode case.
+    Small tensors are copied from the golden; the adapters' large Linear weights come from `seeded_tensor` (their
+    reference init has layer.2 = 0, which would carry no signal)."""
+    done = 0
+    with torch.no_grad():
+        for n, p in model.pets.named_parameters():          # (also reachable as backbone.branch.b.adapters.attn.*)
+            if p.numel() > BIG:
+                p.copy_(seeded_tensor('pets.' + n, p.shape, 0.02 if 'layer.0' in n else 0.01).to(p.device))
+                done += 1
+    assert done == 4, done
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# toy module for the EWC / MAS goldens: the regularisers only see named_parameters / reg_params / model(batch)
+class RegToy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.body = torch.nn.Linear(6, 5)
+        self.head = torch.nn.Linear(5, 7)              # "grown" class head: 7 rows now, 4 when task 0 was consolidated
+        self.scale = torch.nn.Parameter(torch.tensor(1.5))          # names containing 'scale' are skipped (EWC.py:15)
+        self.unused = torch.nn.Parameter(torch.zeros(3))            # never gets a gradient: absent from the dictionaries
+        with torch.no_grad():
+            for p in (self.body.weight, self.body.bias, self.head.weight, self.head.bias):
+                p.copy_(torch.randn(p.shape, generator=g))
+        self.reg_params = {}
+
+    def forward(self, x):
+        return {'final_loss': (self.head(torch.tanh(self.body(x))) * self.scale).pow(2).mean()}
+
+
+def reg_toy_loss(model):
+    return model(torch.randn(4, 6, generator=torch.Generator().manual_seed(8)).to(model.scale.device))['final_loss']
+
+
+def reg_toy_loader(device='cpu'):
+    return [torch.randn(4, 6, generator=torch.Generator().manual_seed(20 + i)).to(device) for i in range(3)]

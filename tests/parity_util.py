@@ -86,3 +86,53 @@ def run_smoke():
     assert worst < 1e-3, "smoke: worst gradient rel err %.3e" % worst
     print("smoke ok: final_loss %.6f (oracle %.6f), worst grad rel err %.2e" %
           (float(losses['final_loss']), float(want['final_loss']), worst))
+
+
+# ------------------------------------------------------------------------------------------ episode case
+def load_episode_golden():
+    return torch.load(os.path.join(HERE, "golden", "episode_vilco.pt"), weights_only=False)
+
+
+def episode_full_state(gold_state):
+    """golden snapshot -> full state_dict: small tensors as stored, the adapters' large Linear weights regenerated
+    (cases.seeded_tensor) under every alias (pets.*, backbone.branch.b.adapters.attn.*, pets_emas.0.module.*)."""
+    out = {}
+    for k, v in gold_state.items():
+        if isinstance(v, dict):
+            tail = k.split('layer.')[-1]                                  # '0.weight' / '2.weight'
+            if k.startswith('pets_emas.'):
+                i = k.split('.module.')[1].split('.')[0]
+            elif k.startswith('pets.'):
+                i = k.split('.')[1]
+            else:
+                i = str(cases.episode_overrides()['cl_cfg']['adapt_blocks'].index(int(k.split('.')[2])))
+            name = 'pets.%s.layer.%s' % (i, tail)
+            out[k] = cases.seeded_tensor(name, v['shape'], 0.02 if 'layer.0' in name else 0.01)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def compact_err(got, want):
+    """relative error of a tensor against a golden entry (full tensor or cases.compact sample)"""
+    if isinstance(want, dict):
+        g = got.detach().reshape(-1).double().cpu()
+        return max(rel_err(g[::cases.SAMPLE_STRIDE], want['sample']),
+                   abs(float(g.norm()) - want['l2']) / max(want['l2'], 1e-12))
+    return rel_err(got, want)
+
+
+def delta_err(got_after, init, want_after):
+    """|| (got - init) - (want - init) ||_2 / || want - init ||_2 over the stored elements: the error of the UPDATE a
+    training phase made to a tensor (robust to single near-zero-gradient elements, where Adam's m / sqrt(v) is a
+    coin flip in any arithmetic)."""
+    if isinstance(want_after, dict):
+        g = got_after.detach().reshape(-1).double().cpu()[::cases.SAMPLE_STRIDE]
+        i = init.detach().reshape(-1).double().cpu()[::cases.SAMPLE_STRIDE]
+        w = want_after['sample'].double()
+    else:
+        g, i, w = got_after.detach().double().cpu(), init.detach().double().cpu(), want_after.double()
+    ref = (w - i).norm().item()
+    if ref < 1e-9:
+        return (g - i).norm().item()
+    return ((g - i) - (w - i)).norm().item() / ref

@@ -1,0 +1,182 @@
+"""BASELINE configs[2] as a tested config: the episode path (adapters + their EMA + L2P prompts + replay memory +
+class-head growth + a new optimizer per task) against golden vectors recorded from the imported reference driving
+its own train_one_epoch / augment_classification (tests/golden/make_golden_episode.py).
+
+CPU part: the oracle and the host-side logic (memory sampling, head growth, the in-memory task stream).
+GPU part: the HIP model + FusedOptimizer + train_one_epoch reproduce the reference's loss / LR sequences, parameter
+updates, EMA adapters, post-augment tensors and the EMA-ensemble inference output."""
+import os
+import random
+
+import pytest
+import torch
+
+from parity_util import (GRAD_FLOOR, cases, compact_err, delta_err, episode_full_state, load_episode_golden, rel_err)
+
+
+def _cfg(gold):
+    from vilco_amd.core.config import make_config
+    return make_config(**gold['overrides'])
+
+
+def _xl(cfg):
+    from ref_import import xlnet_json
+    return xlnet_json(cfg['model']['embd_dim'], cases.EP_H)
+
+
+def _task_data(task):
+    data = {}
+    for b in cases.episode_batches(task):
+        for v in b:
+            for c in v['labels'].tolist():
+                if (task == 0 and c < cases.EP_NCLS0) or (task == 1 and c >= cases.EP_NCLS0):
+                    data.setdefault(c, []).append(v)
+    return data
+
+
+def test_oracle_matches_reference_first_iteration():
+    """the oracle (with time adapters and prompts) on the episode case's initial state = the reference's first loss"""
+    from oracle import mq_oracle
+    gold = load_episode_golden()
+    cfg = _cfg(gold)['model']
+    p = {k: v.double() if v.is_floating_point() else v for k, v in episode_full_state(gold['init_state']).items()}
+    vl = [{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()}
+          for d in cases.episode_batches(0)[0]]
+    losses, ln = mq_oracle.forward_losses(p, cfg, vl, task_id=0, n_known=0)
+    want = gold['tasks'][0]['losses'][0]
+    for k in ('cls_loss', 'reg_loss', 'al_loss', 'final_loss'):
+        assert abs(float(losses[k]) - want[k]) <= 2e-5 * max(abs(want[k]), 1e-3), (k, float(losses[k]), want[k])
+
+
+def test_memory_sampling_and_head_growth_match_reference():
+    """add_samples_to_mem (random replay sampling, m per class) and augment_classification on the CPU: host logic"""
+    import vilco_amd.modeling as vm
+    gold = load_episode_golden()
+    cfg = _cfg(gold)
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg['model'], xlnet_config=_xl(cfg)))
+    state = episode_full_state(gold['tasks'][0]['state'])
+    model.load_state_dict(state, strict=True)                 # reference keys, incl. the adapter aliases and the EMA
+    random.seed(0)
+    n_cls = model.cls_head.cls_head.conv.out_channels
+    assert n_cls == cases.EP_NCLS0
+    from vilco_amd.train_cl import memory_quota
+    model.add_samples_to_mem(None, _task_data(0), memory_quota(cfg['cl_cfg']['memory_size'], n_cls))
+    assert {c: [v['video_id'] for v in vs] for c, vs in model.memory.items()} == gold['tasks'][0]['memory_ids']
+    torch.manual_seed(99)
+    model.augment_classification(cases.EP_NEW, 'cpu')
+    sd = model.state_dict()
+    for k, want in gold['tasks'][0]['post_augment'].items():
+        assert sd[k].shape == want.shape and torch.equal(sd[k], want), k
+    assert model.num_classes == cases.EP_NCLS0 + cases.EP_NEW
+
+
+def test_in_memory_stream_contract():
+    from vilco_amd.utils.cl_stream import InMemoryQILStream
+    s = InMemoryQILStream([_task_data(0), _task_data(1)], batch_size=2, seed=3)
+    it = iter(s)
+    d0, l0, nxt = next(it)
+    assert nxt == cases.EP_NEW and sorted(d0) == [0, 1, 2, 3] and len(l0) == 4
+    ids0 = sorted(v['video_id'] for b in l0 for v in b)
+    assert ids0 == sorted({v['video_id'] for vs in d0.values() for v in vs})       # every clip once per epoch
+    order0 = [v['video_id'] for b in l0 for v in b]
+    l0.sampler.set_epoch(1)
+    assert sorted(v['video_id'] for b in l0 for v in b) == ids0 and [v['video_id'] for b in l0 for v in b] != order0
+    s.memory = {0: d0[0][:1]}
+    d1, l1, nxt = next(it)
+    assert nxt is None
+    assert [v['is_memory'] for v in l1.items] == [True] + [False] * (len(l1.items) - 1)    # replayed clips first
+    assert len(l1) == len(l1.items) // 2                                                   # drop_last, as the reference's loader
+    # two ranks see disjoint halves of the same permutation
+    a = InMemoryQILStream([_task_data(0)], 2, seed=3, rank=0, world=2).__next__()[1]
+    b = InMemoryQILStream([_task_data(0)], 2, seed=3, rank=1, world=2).__next__()[1]
+    ia, ib = {v['video_id'] for x in a for v in x}, {v['video_id'] for x in b for v in x}
+    assert len(a) == len(b) == 2 and not (ia & ib)
+
+
+# ------------------------------------------------------------------------------------------------------- GPU
+def _build(gold, dev):
+    import vilco_amd.modeling as vm
+    cfg = _cfg(gold)
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg['model'], xlnet_config=_xl(cfg)))
+    model.load_state_dict(episode_full_state(gold['init_state']), strict=True)
+    model = model.to(dev)
+    model.loss_normalizer = cfg['model']['train_cfg']['init_loss_norm']
+    return cfg, model
+
+
+@pytest.mark.gpu
+def test_episode_reproduces_reference(dev):
+    """two tasks x four iterations through vilco_amd.utils.train_utils.train_one_epoch on the HIP path"""
+    from vilco_amd.utils.train_utils import make_optimizer, make_scheduler, train_one_epoch
+    gold = load_episode_golden()
+    cfg, model = _build(gold, dev)
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    opt = make_optimizer(model, cfg['opt'])
+    sch = make_scheduler(opt, cfg['opt'], len(cases.episode_batches(0)))
+    for task in range(2):
+        want = gold['tasks'][task]
+        lrs = []
+        step0 = sch.step
+
+        def rec_step(*a, **k):
+            lrs.append(opt.param_groups[0]['lr'])
+            return step0(*a, **k)
+        sch.step = rec_step
+        model.pre_train_epoch(task_id=task, current_epoch=0)
+        hist = train_one_epoch(cases.episode_batches(task), model, opt, sch, 0, 1,
+                               clip_grad_l2norm=cfg['train_cfg']['clip_grad_l2norm'], cl_name=cfg['cl_cfg']['name'],
+                               reg_lambda=cfg['cl_cfg']['reg_lambda'], prev_out_cls_logits_dict={}, current_task_id=task)
+        assert len(hist) == len(want['losses'])
+        for i, (h, w) in enumerate(zip(hist, want['losses'])):
+            for k in w:
+                assert abs(float(h[k]) - w[k]) <= 1e-3 * max(abs(w[k]), 1e-3), (task, i, k, float(h[k]), w[k])
+        assert all(abs(a - b) <= 1e-12 + 1e-9 * abs(b) for a, b in zip(lrs, want['lrs'])), (lrs, want['lrs'])
+        assert abs(model.loss_normalizer - want['loss_normalizer']) <= 1e-4 * want['loss_normalizer']
+        # parameter updates, adapter EMA included (pets_emas.* keys)
+        sd = model.state_dict()
+        worst = ("", 0.0)
+        for k, w in want['state'].items():
+            if not (sd[k].is_floating_point()):
+                continue
+            base = init[k] if init[k].shape == sd[k].shape else None
+            e = delta_err(sd[k], base, w) if base is not None else compact_err(sd[k], w)
+            if e > worst[1]:
+                worst = (k, e)
+        assert worst[1] < 2e-2, "task %d: update of %s differs from the reference's by %.3e" % (task, worst[0], worst[1])
+        ema_keys = [k for k in want['state'] if k.startswith('pets_emas.')]
+        assert ema_keys and max(compact_err(sd[k], want['state'][k]) for k in ema_keys) < 1e-5
+
+        # eval: EMA-ensemble forward (meta_archs.py:854-881), decode, soft-NMS
+        model.eval()
+        clip = cases.episode_batches(task)[0][0]
+        with torch.no_grad():
+            raw = model([clip], task_id=task, is_training=False, get_emb=True)
+            res = model([clip], task_id=task, is_training=False)[0]
+        for a, b in zip(raw[0], want['eval_cls_logits']):
+            assert rel_err(a, b) < 1e-3
+        for a, b in zip(raw[1], want['eval_offsets']):
+            assert rel_err(a, b) < 1e-3
+        wi = want['inference']
+        assert res['segments'].shape == wi['segments'].shape
+        assert rel_err(res['scores'], wi['scores']) < 1e-3
+        agree = (res['labels'] == wi['labels']).float().mean().item()
+        assert agree >= 0.98, agree          # near-tied scores may swap neighbours at 1e-3 arithmetic
+
+        # between the tasks: memory, n_known, head growth, NEW optimizer + scheduler (train_cl.py:343-389)
+        random.seed(0)
+        model.add_samples_to_mem(None, _task_data(task), cfg['cl_cfg']['memory_size'] // model.cls_head.cls_head.conv.out_channels)
+        model.n_known = len(model.memory)
+        assert model.n_known == want['n_known']
+        if task == 0:
+            torch.manual_seed(99)
+            model.augment_classification(cases.EP_NEW, dev)
+            sd = model.state_dict()
+            for k, w in want['post_augment'].items():
+                assert sd[k].shape == w.shape
+                n_old = cases.EP_NCLS0
+                assert rel_err(sd[k][:n_old], w[:n_old]) < 2e-2 if 'cls_head' in k else True     # trained rows
+                assert torch.equal(sd[k][n_old:].cpu(), w[n_old:]), k                            # fresh rows: same init stream
+            init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            opt = make_optimizer(model, cfg['opt'])
+            sch = make_scheduler(opt, cfg['opt'], len(cases.episode_batches(1)))
+            model.train()

@@ -1,8 +1,9 @@
 """The HIP path (vilco_amd.modeling through libvilco_hip.so) vs the golden vectors generated from the
 imported reference and vs the float64 oracle, on the same seeded inputs.  Tolerance: 1e-3 relative
 (BASELINE.json north_star; max abs error / max abs reference per tensor) on losses, logits and every
-parameter gradient, in the default GEMM precision (three-part split bf16 MFMA = fp32-equivalent).
-The faster two-part split mode is checked separately with the statistics it actually achieves."""
+parameter gradient, in the default GEMM precision (f16x2: fp16 MFMA on two-part splits of power-of-two
+scaled operands, 22 significant bits).  The narrower modes are checked separately with the statistics
+they actually achieve.  Train-mode (dropout / stochastic depth on) parity: test_train_mode_vs_oracle_*."""
 import numpy as np
 import pytest
 import torch
@@ -262,3 +263,55 @@ def test_xlnet_dropout_matches_oracle_with_same_masks(dev):
         assert ops.dropout_log == []
     finally:
         ops.dropout_log = None
+
+
+def test_train_mode_vs_oracle_with_replayed_masks(dev):
+    """The whole model in TRAIN mode with the reference's regularisation on -- dropout 0.1 (proj / MLP dropouts fused
+    into the GEMM epilogues), stochastic depth 0.1 (AffineDropPath and the ChannelBlock drop paths), XLNet dropout 0.1
+    (seven sites incl. the attention probabilities inside the flash kernels): the fp64 oracle, handed exactly the
+    factors the HIP path drew (ops.dropout_log -> oracle DropReplay), must give the same losses and the same gradient
+    for every parameter."""
+    from oracle import mq_oracle
+    from vilco_amd import ops
+    import vilco_amd.modeling as vm
+    from vilco_amd.core.config import make_config
+    gold = load_golden("xl")
+    over = dict(gold['overrides'])
+    over['train_cfg'] = dict(over['train_cfg'], dropout=0.1, droppath=0.1)
+    cfg = make_config(**over)['model']
+    torch.manual_seed(5)
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=xlnet_json(cfg['embd_dim'], 4, dropout=0.1)))
+    model.load_state_dict(gold['state_dict'])
+    model = model.to(dev).train()
+    model.loss_normalizer = cfg['train_cfg']['init_loss_norm']
+    vl = golden_inputs(gold)
+    ops.dropout_log = []
+    try:
+        losses = model(vl, task_id=gold['task_id'], is_training=True)
+        losses['final_loss'].backward()
+        log = list(ops.dropout_log)
+    finally:
+        ops.dropout_log = None
+    sites = [e[0] for e in log]
+    for s_ in ('proj_drop', 'mlp_drop', 'droppath', 'attn_prob', 'xl_input', 'xl_output'):
+        assert s_ in sites, (s_, sorted(set(sites)))
+    p = {k: (v.double() if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point())
+         for k, v in gold['state_dict'].items()}
+    vl64 = [{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()} for d in vl]
+    ctx = mq_oracle.DropReplay(log, lambda pr, seed, shape: ops.dropout_mask(pr, seed, shape, dev).cpu())
+    mq_oracle.DROP = ctx
+    try:
+        want, _ = mq_oracle.forward_losses(p, cfg, vl64, task_id=gold['task_id'], n_known=gold['n_known'])
+        want['final_loss'].backward()
+    finally:
+        mq_oracle.DROP = None
+    assert ctx.leftover() == {}, ctx.leftover()          # every mask the HIP path drew was consumed, in order
+    for k in ('cls_loss', 'reg_loss', 'final_loss'):
+        assert rel_err(losses[k], want[k]) < TOL, (k, float(losses[k]), float(want[k]))
+    worst = ("", 0.0)
+    for k, q in model.named_parameters():
+        if p[k].grad is not None and q.grad is not None:
+            e = rel_err(q.grad, p[k].grad, GRAD_FLOOR)
+            if e > worst[1]:
+                worst = (k, e)
+    assert worst[1] < TOL, worst

@@ -299,8 +299,8 @@ def test_attention_precision_modes(dev, mode, tol):
         ops.set_precision(None)
 
 
-@pytest.mark.parametrize("flash", [True, False])
-@pytest.mark.parametrize("T,hd", [(48, 16), (100, 64)])
+@pytest.mark.parametrize("flash,T,hd", [(True, 48, 16), (False, 48, 16), (True, 100, 64), (False, 100, 64),
+                                         (True, 576, 64)])     # 576: several key tiles, band GEMM + relshift pack
 def test_rel_attention(dev, flash, T, hd):
     """XLNet core vs the published formula incl. rel_shift_bnij (modeling_xlnet_x.py:256-320)."""
     from vilco_amd import ops

@@ -92,6 +92,7 @@ SIGNATURES = {
     "vilco_grad_norm": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, f32, c_fp, c_fp, c_fp]),
     "vilco_optim_step": (C.c_int, [i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), i32,
                                    f32, f32, f32, f32, c_fp, c_fp, c_fp]),
+    "vilco_cl_penalty": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, f32, i32, c_fp, c_fp, c_fp]),
     "vilco_nms_workspace": (sz, [i64, i32]),
     "vilco_nms_1d": (C.c_int, [c_fp, c_fp, c_fp, i32, i64, f32, c_fp, c_fp, c_fp, sz, c_fp]),
     "vilco_softnms_1d": (C.c_int, [c_fp, c_fp, c_fp, i32, i64, f32, f32, f32, i32, i64, c_fp, c_fp, c_fp,

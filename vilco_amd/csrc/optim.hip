@@ -113,7 +113,91 @@ __global__ __launch_bounds__(OPT_THREADS) void sgd_kernel(MultiArgs a, Hyper h, 
   }
 }
 
+// EWC / MAS penalty (MQ/libs/cl_methods/EWC.py:6-22, MAS.py:5-21) over a chunk table of (parameter, importance,
+// consolidated value) triples: partial[chunk] = sum F (opt - p)^2 ; grad += -2 lambda F (opt - p).
+// ptrs = [4][n]: param, grad, importance, optpar; numel[t] = optpar's element count (a prefix of the parameter when the
+// class head has grown since the task was consolidated).
+__global__ __launch_bounds__(OPT_THREADS) void cl_penalty_kernel(MultiArgs a, float lambda, float* __restrict__ partial) {
+  __shared__ float red[OPT_THREADS / 64];
+  const int t = a.chunk_tensor[blockIdx.x];
+  const long off = a.chunk_off[blockIdx.x];
+  const float* p = reinterpret_cast<const float*>(a.ptrs[t]) + off;
+  float* g = reinterpret_cast<float*>(a.ptrs[(long)a.n + t]) + off;
+  const float* f = reinterpret_cast<const float*>(a.ptrs[2L * a.n + t]) + off;
+  const float* o = reinterpret_cast<const float*>(a.ptrs[3L * a.n + t]) + off;
+  long cnt = a.numel[t] - off;
+  if (cnt > a.chunk) cnt = a.chunk;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < cnt; i += OPT_THREADS) {
+    const float d = o[i] - p[i];
+    const float fd = f[i] * d;
+    s += fd * d;
+    g[i] -= 2.f * lambda * fd;      // every parameter occurs once: plain read-modify-write
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// the same, for a parameter that appears in more than one task's dictionary: gradient accumulated with atomics
+__global__ __launch_bounds__(OPT_THREADS) void cl_penalty_atomic_kernel(MultiArgs a, float lambda,
+                                                                        float* __restrict__ partial) {
+  __shared__ float red[OPT_THREADS / 64];
+  const int t = a.chunk_tensor[blockIdx.x];
+  const long off = a.chunk_off[blockIdx.x];
+  const float* p = reinterpret_cast<const float*>(a.ptrs[t]) + off;
+  float* g = reinterpret_cast<float*>(a.ptrs[(long)a.n + t]) + off;
+  const float* f = reinterpret_cast<const float*>(a.ptrs[2L * a.n + t]) + off;
+  const float* o = reinterpret_cast<const float*>(a.ptrs[3L * a.n + t]) + off;
+  long cnt = a.numel[t] - off;
+  if (cnt > a.chunk) cnt = a.chunk;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < cnt; i += OPT_THREADS) {
+    const float d = o[i] - p[i];
+    const float fd = f[i] * d;
+    s += fd * d;
+    atomicAdd(&g[i], -2.f * lambda * fd);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void scaled_sum_kernel(const float* __restrict__ partial, int n, float scale,
+                                                                 float* __restrict__ out) {
+  __shared__ double red[OPT_THREADS];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += OPT_THREADS) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = OPT_THREADS / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
+}
+
 }  // namespace
+
+extern "C" int vilco_cl_penalty(const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                                const int64_t* chunk_off, int32_t n, int32_t nchunks, int32_t chunk, float lambda,
+                                int32_t shared_params, float* partial, float* out, void* stream) {
+  if (!ptrs || !numel || !chunk_tensor || !chunk_off || !partial || !out || n < 0 || nchunks < 0 || chunk <= 0)
+    return VILCO_ERR_BADARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  MultiArgs a{reinterpret_cast<const long*>(ptrs), reinterpret_cast<const long*>(numel), chunk_tensor,
+              reinterpret_cast<const long*>(chunk_off), nullptr, n, chunk};
+  if (nchunks > 0) {
+    if (shared_params)
+      hipLaunchKernelGGL(cl_penalty_atomic_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, s, a, lambda, partial);
+    else
+      hipLaunchKernelGGL(cl_penalty_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, s, a, lambda, partial);
+  }
+  hipLaunchKernelGGL(scaled_sum_kernel, dim3(1), dim3(OPT_THREADS), 0, s, partial, nchunks, lambda, out);
+  return vilco_launch_status();
+}
 
 extern "C" int vilco_grad_norm(const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
                                const int64_t* chunk_off, int32_t n, int32_t nchunks, int32_t chunk, float max_norm,

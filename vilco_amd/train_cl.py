@@ -1,0 +1,133 @@
+"""Episode (task) loop of query-incremental continual learning on the HIP path -- our counterpart of the
+reference driver MQ/train_cl.py:206-389 (+ load_best_checkpoint :31-40), written around the drop-in model:
+
+  for every task j of the stream:
+      validate the incoming model                                   (train_cl.py:209-219)
+      [type_sampling 'icarl': cache sigmoid(logits) of the task's clips, :226-235]
+      for every epoch: sampler.set_epoch, pre_train_epoch (adapters), train_one_epoch, validate after the first
+          third of the epochs, keep the best checkpoint             (:237-316)
+      replay memory: m = memory_size // #classes per class, add_samples_to_mem, n_known = len(memory), memory
+          pickle                                                    (:343-361)
+      reload the task's best checkpoint, final validation           (:363-365)
+      if another task follows: augment_classification(num_next_classes), EWC / MAS consolidation, NEW optimizer
+          and scheduler                                             (:373-389)
+
+What is ours rather than the reference's: the stream is any iterable with QILSetTask's contract
+(`(data, loader, num_next_classes)` per task, a `.memory` attribute; utils/cl_stream.py has an in-memory one --
+the Ego4D readers are outside the hot path), validation is a callable (the evaluator is outside the hot path;
+`train_utils.collect_results` produces its input format), gradients of data-parallel replicas go through
+`dist.GradReducer`, and the per-iteration work is `train_utils.train_one_epoch` (fused clip + AdamW, no host sync).
+Checkpoints keep the reference's keys: task, epoch, state_dict, scheduler, optimizer, reg_params (:300-307).
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .cl_methods import regularizers
+from .utils.train_utils import make_optimizer, make_scheduler, save_checkpoint, train_one_epoch
+
+
+def load_best_checkpoint(model, file_folder, file_name, current_task, gpu_id):
+    """train_cl.py:31-40: restore state_dict + reg_params when the file exists; the model is returned either way."""
+    path = os.path.join(file_folder, file_name)
+    if os.path.exists(path):
+        ck = torch.load(path, map_location=lambda storage, loc: storage.cuda(gpu_id), weights_only=False)
+        model.load_state_dict(ck['state_dict'])
+        model.reg_params = ck['reg_params']
+        model = model.cuda(gpu_id)
+    return model
+
+
+def memory_quota(memory_size, n_classes):
+    """videos kept per class after a task (train_cl.py:343-349)"""
+    return 'ALL' if memory_size == 'ALL' else memory_size // n_classes
+
+
+@torch.no_grad()
+def cache_prev_logits(model, loader, task_id):
+    """{video_id: [sigmoid(cls logits) per pyramid level as numpy]} of the incoming model (train_cl.py:226-235)"""
+    out = {}
+    for video_list in loader:
+        cls_logits, _, _ = model(video_list, task_id=task_id, get_emb=True)
+        for i, v in enumerate(video_list):
+            out[v['video_id']] = [np.array(torch.sigmoid(lvl[i]).cpu().numpy()) for lvl in cls_logits]
+    return out
+
+
+def run_episodes(cfg, model, train_stream, validate=None, ckpt_folder=None, gpu_id=0, start_task=0, start_epoch=0,
+                 combine_train=False, reducer=None, logger=None, print_freq=20, on_step_history=None):
+    """cfg: the merged config dict (opt / train_cfg / cl_cfg as in libs/core/config.py).
+    validate(model, epoch, task) -> mAP-like float (higher is better), or None to skip validation (every epoch's
+    state then counts as "best", so the last epoch is what gets reloaded).
+    Returns (model, optimizer, scheduler, log) with log = list of per-task dicts."""
+    is_main = int(os.environ.get("LOCAL_RANK", "0")) == 0
+    optimizer = make_optimizer(model, cfg['opt'])
+    it = iter(train_stream)
+    num_tasks = train_stream.num_tasks
+    data, loader, num_next = next(it)
+    iters_per_epoch = len(loader)
+    scheduler = make_scheduler(optimizer, cfg['opt'], iters_per_epoch)
+    max_epochs = cfg['opt'].get('early_stop_epochs', cfg['opt']['epochs'] + cfg['opt']['warmup_epochs'])
+    memory_size = cfg['cl_cfg']['memory_size']
+    log = []
+    for j in range(start_task, num_tasks):
+        if j != 0:
+            data, loader, num_next = next(it)
+        entry = {'task': j, 'init_metric': None, 'best_metric': None, 'best_epoch': -1, 'history': []}
+        if validate is not None:
+            entry['init_metric'] = validate(model, 0, j)
+        best, best_epoch = -10000.0, -1
+        prev_logits = cache_prev_logits(model, loader, j) if model.type_sampling == 'icarl' else {}
+        ck_name = 'best_task_{:03d}_performance.pth.tar'.format(j)
+        for epoch in range(start_epoch, max_epochs):
+            sampler = getattr(loader, 'sampler', None)
+            if sampler is not None and hasattr(sampler, 'set_epoch'):
+                sampler.set_epoch(epoch)
+            if model.use_adapt:
+                model.pre_train_epoch(task_id=j, current_epoch=epoch)
+            hist = train_one_epoch(loader, model, optimizer, scheduler, epoch, 1, model_ema=None,
+                                   clip_grad_l2norm=cfg['train_cfg']['clip_grad_l2norm'], print_freq=print_freq,
+                                   logger=logger, cl_name=cfg['cl_cfg']['name'], reg_lambda=cfg['cl_cfg']['reg_lambda'],
+                                   prev_out_cls_logits_dict=prev_logits, current_task_id=j, reducer=reducer)
+            entry['history'].append(hist)
+            if on_step_history is not None:
+                on_step_history(j, epoch, hist)
+            if not (is_main and not combine_train) or epoch < max_epochs // 3:
+                continue
+            metric = validate(model, epoch, j) if validate is not None else float(epoch)
+            if metric > best:
+                best, best_epoch = metric, epoch
+                if ckpt_folder is not None:
+                    save_checkpoint({'task': j, 'epoch': epoch, 'state_dict': model.state_dict(),
+                                     'scheduler': scheduler.state_dict(), 'optimizer': optimizer.state_dict(),
+                                     'reg_params': model.reg_params}, file_folder=ckpt_folder, file_name=ck_name)
+        entry['best_metric'], entry['best_epoch'] = best, best_epoch
+
+        # replay memory for the next task (train_cl.py:343-361)
+        n_cls = model.cls_head.cls_head.conv.out_channels
+        if memory_size != 0:
+            model.add_samples_to_mem(None, data, memory_quota(memory_size, n_cls))
+        train_stream.memory = model.memory
+        model.n_known = len(model.memory)
+        if ckpt_folder is not None and is_main:
+            os.makedirs(ckpt_folder, exist_ok=True)
+            with open(os.path.join(ckpt_folder, cfg['cl_cfg']['path_memory']), 'wb') as h:
+                pickle.dump(model.memory, h)
+            model = load_best_checkpoint(model, ckpt_folder, ck_name, j, gpu_id)
+        if validate is not None:
+            entry['final_metric'] = validate(model, max_epochs - 1, j)
+        log.append(entry)
+
+        if num_next is not None:
+            model.augment_classification(num_next, torch.device('cuda', gpu_id))
+            if cfg['cl_cfg']['name'] == 'ewc':
+                model.reg_params = regularizers.on_task_update(loader, gpu_id, optimizer, model, kind='ewc')
+            elif cfg['cl_cfg']['name'] == 'mas':
+                model.reg_params = regularizers.on_task_update(loader, gpu_id, optimizer, model, kind='mas')
+            optimizer = make_optimizer(model, cfg['opt'])
+            scheduler = make_scheduler(optimizer, cfg['opt'], iters_per_epoch)
+            if reducer is not None:
+                reducer.rebuild()          # the class head and the gaussian parameters are new tensors
+    return model, optimizer, scheduler, log

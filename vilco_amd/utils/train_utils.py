@@ -216,3 +216,98 @@ def train_step(model, optimizer, scheduler, video_list, task_id=0, prev_out_cls_
     if getattr(model, "use_adapt", False):
         model.post_train_step()
     return losses
+
+
+class AverageMeter(object):
+    """running value / average (train_utils.py:216-244)"""
+
+    def __init__(self):
+        self.initialized, self.val, self.avg, self.sum, self.count = False, None, None, None, None
+
+    def update(self, val, n=1):
+        if not self.initialized:
+            self.val, self.avg, self.sum, self.count, self.initialized = val, val, val * n, n, True
+        else:
+            self.val = val
+            self.sum += val * n
+            self.count += n
+            self.avg = self.sum / self.count
+
+
+def train_one_epoch(train_loader, model, optimizer, scheduler, curr_epoch, n_gpu=1, model_ema=None,
+                    clip_grad_l2norm=-1, tb_writer=None, print_freq=20, logger=None, cl_name=None, reg_lambda=0.0,
+                    prev_out_cls_logits_dict=None, current_task_id=0, reducer=None):
+    """One epoch of the continual-learning training loop (train_utils.py:278-423), same arguments.  Per iteration:
+    zero_grad, forward with `task_id` and the cached iCaRL/BiC logits of the batch's videos, backward of
+    final_loss (+ the EWC / MAS penalty of cl_name, applied as one multi-tensor kernel that adds its gradient to
+    p.grad), [gradient all-reduce], fused clip + optimizer step, scheduler step, adapter EMA (`post_train_step`).
+    Nothing in the loop reads a device value unless a log line is due (every `print_freq` iterations).
+    Returns the list of per-iteration loss dicts (device tensors), which the reference does not -- harmless."""
+    from ..cl_methods import regularizers
+    model.train()
+    model.compute_means = model.cl_name == 'icarl'
+    tracker, history = {}, []
+    for iter_idx, video_list in enumerate(train_loader, 0):
+        optimizer.zero_grad(set_to_none=True)
+        prev = []
+        for v in video_list:
+            if prev_out_cls_logits_dict is not None and v['video_id'] in prev_out_cls_logits_dict:
+                prev.append(prev_out_cls_logits_dict[v['video_id']])
+        if reducer is not None:
+            reducer.begin()
+        losses = model(video_list, task_id=current_task_id, prev_out_cls_logits=prev)
+        losses['final_loss'].backward()
+        if reducer is not None:
+            reducer.finish()
+        if cl_name in ('ewc', 'mas'):
+            # loss + lambda * sum_i sum_p F_i (theta*_i - theta)^2 (EWC.py:6-22 / MAS.py:5-21): value added to the
+            # reported loss, gradient added straight into p.grad.  The penalty is the same on every rank, so adding it
+            # after the gradient average equals averaging it.
+            pen = regularizers.apply_penalty(model, reg_lambda, kind=cl_name)
+            if pen is not None:
+                losses['final_loss'] = losses['final_loss'].detach() + pen
+        optimizer.step(clip_grad_l2norm=clip_grad_l2norm)
+        scheduler.step()
+        if model.use_adapt:
+            model.post_train_step()
+        history.append({k: v.detach() for k, v in losses.items()})
+        if iter_idx != 0 and iter_idx % print_freq == 0 and logger is not None:
+            for k, v in losses.items():
+                tracker.setdefault(k, AverageMeter()).update(float(v))
+            logger.info('Epoch: [{:03d}][{:05d}/{:05d}]\tLoss {:.2f} ({:.2f})'.format(
+                curr_epoch, iter_idx, len(train_loader), tracker['final_loss'].val, tracker['final_loss'].avg))
+    if logger is not None:
+        logger.info("[Train]: Epoch {:d} finished with lr={:.8f}\n".format(curr_epoch, scheduler.get_last_lr()[0]))
+    return history
+
+
+@torch.no_grad()
+def collect_results(val_loader, model, task_id=0):
+    """the evaluator's input format (train_utils.py:1049-1098 / 749-752): a dict of flat per-segment columns
+    {'video-id': [...], 't-start', 't-end', 'label', 'score': numpy arrays}, from eval-mode forwards (batch size 1)."""
+    was_training = model.training
+    model.eval()
+    res = {'video-id': [], 't-start': [], 't-end': [], 'label': [], 'score': []}
+    for video_list in val_loader:
+        for out in model(video_list, task_id=task_id, is_training=False):
+            n = out['segments'].shape[0]
+            if n > 0:
+                res['video-id'].extend([out['video_id']] * n)
+                res['t-start'].append(out['segments'][:, 0])
+                res['t-end'].append(out['segments'][:, 1])
+                res['label'].append(out['labels'])
+                res['score'].append(out['scores'])
+    for k, dt in (('t-start', torch.float32), ('t-end', torch.float32), ('label', torch.int64), ('score', torch.float32)):
+        res[k] = torch.cat(res[k]).numpy() if res[k] else torch.zeros(0, dtype=dt).numpy()
+    model.train(was_training)
+    return res
+
+
+def results_to_anet_json(results, version="vilco_amd"):
+    """the ActivityNet-style submission dict the reference dumps with `output_file` (train_utils.py:771-774 via
+    libs/utils/postprocessing): {"version", "results": {video_id: [{"label", "score", "segment": [s, e]}]}, ...}"""
+    out = {}
+    for vid, s, e, l, sc in zip(results['video-id'], results['t-start'], results['t-end'], results['label'],
+                                results['score']):
+        out.setdefault(vid, []).append({"label": int(l), "score": float(sc), "segment": [float(s), float(e)]})
+    return {"version": version, "results": out, "external_data": {}}
