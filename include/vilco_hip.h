@@ -267,6 +267,41 @@ int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, co
                      float momentum, const float* tensor_step, const float* norm_coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Point labelling + losses of the heads in two launches each way: label_points_single_video                    */
+/* (MQ/libs/modeling/meta_archs.py:1253-1344), losses (:1374-1447: focal on valid points x gaussian weights,      */
+/* DIoU on positives, "al" loss, loss_normalizer EMA :1407-1410), sigmoid_focal_loss / ctr_diou_loss_1d           */
+/* (losses.py:5-52, 109-168) and the regression head's last two layers relu(Scale_l(x)) (meta_archs.py:344-346).   */
+/* Rows r of a clip are the pyramid points of all levels laid end to end, optionally with separator rows           */
+/* (points[r].stride <= 0).  gt = float [B][3*Nmax + 1]: Nmax (start, end) pairs, Nmax class ids, the count.        */
+/* gauss = [6][C]: mu, sigma, mu_reg_left, sigma_reg_left, mu_reg_right, sigma_reg_right.                          */
+/* loss_norm (device float[1]) is read and updated in place.  almax_state: device uint64 [B*C], zero before the    */
+/* first call and left zero by every call.  out = {cls_loss, reg_loss, al_loss, cls + loss_weight*reg +            */
+/* al_weight*al}; saved[0] = the normaliser used.  center_radius <= 0: center_sample 'none'.                       */
+/* bwd: g_cls / g_reg / g_al / g_final = device scalars, the upstream gradients of the four outputs (NULL = 0).  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct vilco_loss_desc {
+  const float* logits;       /* [B][R][C] */
+  const float* offsets;      /* [B][R][2] raw head output when level_scale != NULL, else already relu(scale * x) */
+  const float* level_scale;  /* [L] or NULL */
+  const float* points;       /* [R][4] = (t, reg_lo, reg_hi, stride) */
+  const int32_t* row_level;  /* [R] */
+  const int32_t* row_pos;    /* [R] position of the row inside its level */
+  const int32_t* level_len;  /* [B][L] valid length of every level */
+  const float* gt;           /* [B][3*Nmax + 1] */
+  const float* gauss;        /* [6][C] */
+  float* loss_norm;          /* [1] */
+  int32_t B, R, C, L, Nmax;
+  float center_radius, label_smoothing, momentum, loss_weight, al_weight;
+  int32_t use_al;
+} vilco_loss_desc;
+size_t vilco_mq_loss_workspace(int32_t B, int32_t R, int32_t C);
+int vilco_mq_loss_fwd(const vilco_loss_desc* d, float* out, float* saved, void* almax_state, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int vilco_mq_loss_bwd(const vilco_loss_desc* d, const float* g_cls, const float* g_reg, const float* g_al,
+                      const float* g_final, const float* saved, const void* workspace, float* d_logits,
+                      float* d_offsets, float* d_level_scale, float* d_gauss, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Continual-learning regularisers of MQ/libs/cl_methods/EWC.py:6-22 (get_regularized_loss) and MAS.py:5-21   */
 /* (get_mas_regularized_loss), called per iteration from train_utils.py:337-344, as ONE multi-tensor launch:    */
 /*   out[0] = lambda * sum_t sum_{i < numel[t]} F_t[i] (opt_t[i] - p_t[i])^2,   grad_t[i] -= 2 lambda F (opt - p) */

@@ -122,17 +122,77 @@ def compact_err(got, want):
     return rel_err(got, want)
 
 
-def delta_err(got_after, init, want_after):
-    """|| (got - init) - (want - init) ||_2 / || want - init ||_2 over the stored elements: the error of the UPDATE a
-    training phase made to a tensor (robust to single near-zero-gradient elements, where Adam's m / sqrt(v) is a
-    coin flip in any arithmetic)."""
-    if isinstance(want_after, dict):
-        g = got_after.detach().reshape(-1).double().cpu()[::cases.SAMPLE_STRIDE]
-        i = init.detach().reshape(-1).double().cpu()[::cases.SAMPLE_STRIDE]
-        w = want_after['sample'].double()
-    else:
-        g, i, w = got_after.detach().double().cpu(), init.detach().double().cpu(), want_after.double()
-    ref = (w - i).norm().item()
+def delta_err(got_after, got_init, want_after, want_init):
+    """|| (got_after - got_init) - (want_after - want_init) ||_2 / || want_after - want_init ||_2 over the stored
+    elements: the error of the UPDATE a training phase made to a tensor (robust to single near-zero-gradient elements,
+    where Adam's m / sqrt(v) is a coin flip in any arithmetic)."""
+    def vec(t):
+        if isinstance(t, dict):
+            return t['sample'].double()
+        return t.detach().reshape(-1).double().cpu()
+    big = isinstance(want_after, dict)
+    g, gi = vec(got_after), vec(got_init)
+    if big:
+        g, gi = g[::cases.SAMPLE_STRIDE], gi[::cases.SAMPLE_STRIDE]
+    w, wi = vec(want_after), vec(want_init)
+    ref = (w - wi).norm().item()
     if ref < 1e-9:
-        return (g - i).norm().item()
-    return ((g - i) - (w - i)).norm().item() / ref
+        return (g - gi).norm().item()
+    return ((g - gi) - (w - wi)).norm().item() / ref
+
+
+def oracle_episode_trajectory(gold, dtype=torch.float64):
+    """The episode case stepped by the ORACLE (CPU) under torch.optim.AdamW + clip_grad_norm_ + the reference's parameter
+    groups (incl. the duplicated adapter aliases) and scheduler: returns per task (loss list, state after the task,
+    state before it).  In float32 this reproduces the reference golden bit for bit; in float64 it is the exact-arithmetic
+    trajectory the HIP path is held to (Adam turns single fp32 rounding events of the reference into visible update
+    differences on a few tensors, which fp64 and the HIP path do not share)."""
+    import warnings
+    import vilco_amd.modeling as vm
+    from oracle import mq_oracle
+    from vilco_amd.core.config import make_config
+    from vilco_amd.utils.train_utils import make_scheduler, param_groups
+    cfg = make_config(**gold['overrides'])
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg['model'], xlnet_config=xlnet_json(cfg['model']['embd_dim'], cases.EP_H)))
+    model.load_state_dict(episode_full_state(gold['init_state']))
+    model = model.to(dtype)
+    norm = float(cfg['model']['train_cfg']['init_loss_norm'])
+
+    def mkopt():
+        decay, no_decay, remain = param_groups(model)
+        pd = dict(model.named_parameters())
+        for mn, m in model.named_modules():
+            for pn, p in m.named_parameters():
+                full = '%s.%s' % (mn, pn) if mn else pn
+                if 'pets' in full:
+                    pd[full] = p
+        wd = cfg['opt']['weight_decay']
+        groups = [{"params": [pd[n] for n in decay], "weight_decay": wd}, {"params": [pd[n] for n in no_decay], "weight_decay": 0.0},
+                  {"params": [pd[n] for n in remain], "weight_decay": wd}]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return torch.optim.AdamW(groups, lr=cfg['opt']['learning_rate'])
+    out = []
+    for task in range(2):
+        opt = mkopt()
+        sch = make_scheduler(opt, cfg['opt'], len(cases.episode_batches(task)))
+        before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        mcfg = dict(cfg['model'], num_classes=model.num_classes)
+        losses = []
+        for vl in cases.episode_batches(task):
+            opt.zero_grad(set_to_none=True)
+            vlt = [{k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()} for d in vl]
+            ls, norm = mq_oracle.forward_losses(dict(model.state_dict(keep_vars=True)), mcfg, vlt, loss_normalizer=norm,
+                                                task_id=task, n_known=model.n_known)
+            ls['final_loss'].backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), cfg['train_cfg']['clip_grad_l2norm'])
+            opt.step()
+            sch.step()
+            losses.append({k: float(v.detach().sum()) for k, v in ls.items()})
+        out.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, before))
+        if task == 0:
+            model.n_known = gold['tasks'][0]['n_known']
+            torch.manual_seed(99)
+            model.augment_classification(cases.EP_NEW, 'cpu')
+            model = model.to(dtype)
+    return out

@@ -39,6 +39,15 @@ class GemmDesc(C.Structure):
     ]
 
 
+class LossDesc(C.Structure):
+    """Mirror of `vilco_loss_desc`."""
+    _fields_ = [("logits", c_fp), ("offsets", c_fp), ("level_scale", c_fp), ("points", c_fp), ("row_level", c_fp),
+                ("row_pos", c_fp), ("level_len", c_fp), ("gt", c_fp), ("gauss", c_fp), ("loss_norm", c_fp),
+                ("B", i32), ("R", i32), ("C", i32), ("L", i32), ("Nmax", i32),
+                ("center_radius", f32), ("label_smoothing", f32), ("momentum", f32), ("loss_weight", f32),
+                ("al_weight", f32), ("use_al", i32)]
+
+
 class PackItem(C.Structure):
     """Mirror of `vilco_pack_item`."""
     _fields_ = [("src", c_fp), ("rows", i64), ("cols", i64), ("ld", i64), ("planes", c_fp), ("planes_bytes", sz),
@@ -92,6 +101,10 @@ SIGNATURES = {
     "vilco_grad_norm": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, f32, c_fp, c_fp, c_fp]),
     "vilco_optim_step": (C.c_int, [i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), i32,
                                    f32, f32, f32, f32, c_fp, c_fp, c_fp]),
+    "vilco_mq_loss_workspace": (sz, [i32, i32, i32]),
+    "vilco_mq_loss_fwd": (C.c_int, [C.POINTER(LossDesc), c_fp, c_fp, c_fp, c_fp, sz, c_fp]),
+    "vilco_mq_loss_bwd": (C.c_int, [C.POINTER(LossDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                    c_fp]),
     "vilco_cl_penalty": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, f32, i32, c_fp, c_fp, c_fp]),
     "vilco_nms_workspace": (sz, [i64, i32]),
     "vilco_nms_1d": (C.c_int, [c_fp, c_fp, c_fp, i32, i64, f32, c_fp, c_fp, c_fp, sz, c_fp]),

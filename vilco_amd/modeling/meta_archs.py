@@ -217,7 +217,8 @@ class PtTransformerClsHead(_ConvHead):
         """-> list of logits [B, T_l, ncls] (already the permuted layout of meta_archs.py:848)."""
         if cat is not None and self.can_cat(list(self.head) + [self.cls_head]):
             x = self._trunk_cat(cat.x.detach() if self.detach_feat else cat.x, cat)
-            return cat.split(self._conv_cat(self.cls_head, x, cat))
+            cat.cls_logits = self._conv_cat(self.cls_head, x, cat)       # [B, Tc, ncls]: the fused loss reads it whole
+            return cat.split(cat.cls_logits)
         out = []
         for x, l in zip(feats, lens):
             x = self._trunk(x.detach() if self.detach_feat else x, l)
@@ -241,10 +242,15 @@ class PtTransformerRegHead(_ConvHead):
                                         padding=kernel_size // 2)
         self.reg_params = {}
 
-    def forward_tm(self, feats, lens, cat=None):
+    def forward_tm(self, feats, lens, cat=None, raw=False):
+        """raw=True (training with the fused loss kernel, which applies relu(Scale_l(x)) itself): only `cat.raw_offsets`
+        [B, Tc, 2] is produced and None returned."""
         assert len(feats) == self.fpn_levels
         if cat is not None and self.can_cat(list(self.head) + [self.offset_head]):
-            off = cat.split(self._conv_cat(self.offset_head, self._trunk_cat(cat.x, cat), cat))
+            cat.raw_offsets = self._conv_cat(self.offset_head, self._trunk_cat(cat.x, cat), cat)
+            if raw:
+                return None
+            off = cat.split(cat.raw_offsets)
             return [F.relu(self.scale[l](o)) for l, o in enumerate(off)]
         out = []
         for l, (x, ln) in enumerate(zip(feats, lens)):
@@ -346,6 +352,7 @@ class PtTransformer(nn.Module):
 
         self.loss_normalizer = t['init_loss_norm']     # EMA, not checkpointed (:611); a device scalar in the sync-free path
         self.sync_free_loss = os.environ.get("VILCO_SYNC_FREE_LOSS", "1") != "0"
+        self.fused_loss = os.environ.get("VILCO_FUSED_LOSS", "1") != "0"      # ops.mq_loss (0: tensor expressions)
         self.loss_normalizer_momentum = 0.9
         self.reg_params = {}
 
@@ -473,11 +480,12 @@ class PtTransformer(nn.Module):
         return ops.transpose(batched), lens, narr
 
     # ------------------------------------------------------------------ forward
-    def _run_network(self, x_tm, lens, text_tm, text_lens):
+    def _run_network(self, x_tm, lens, text_tm, text_lens, raw_offsets=False):
         feats, all_lens = self.backbone.forward_tm(x_tm, lens, text_tm, text_lens)
         fpn_feats, fpn_lens = self.neck.forward_tm(feats, all_lens)
         cat = LevelCat(fpn_feats, fpn_lens) if (self.level_cat and len(fpn_feats) > 1) else None
-        out_offsets = self.reg_head.forward_tm(fpn_feats, fpn_lens, cat)
+        self._cat = cat
+        out_offsets = self.reg_head.forward_tm(fpn_feats, fpn_lens, cat, raw=raw_offsets and cat is not None)
         out_cls_logits = self.cls_head.forward_tm(fpn_feats, fpn_lens, cat)
         return fpn_feats, fpn_lens, out_cls_logits, out_offsets
 
@@ -502,7 +510,12 @@ class PtTransformer(nn.Module):
             text_tm = res['prompted_embedding'].contiguous()
             reduce_sim = res['reduce_sim']
 
-        fpn_feats, fpn_lens, out_cls_logits, out_offsets = self._run_network(x_tm, lens, text_tm, text_lens)
+        # training with fixed loss weights: labels + losses are ONE fused kernel pair (ops.mq_loss) that also applies the
+        # regression head's relu(Scale_l(x)); everything else (BiC, dynamic loss weight, get_emb, eval) keeps the lists
+        fused = (is_training and not get_emb and self.fused_loss and self.sync_free_loss and self.train_loss_weight > 0
+                 and not (self.n_known > 0 and self.cl_name == 'bic') and self.num_classes <= 128)
+        fpn_feats, fpn_lens, out_cls_logits, out_offsets = self._run_network(x_tm, lens, text_tm, text_lens,
+                                                                            raw_offsets=fused)
 
         if self.training and self.narration_ssl:
             narration_feats, video_feats = self._ssl_embeddings(fpn_feats, fpn_lens, narr)
@@ -531,12 +544,16 @@ class PtTransformer(nn.Module):
             assert video_list[0]['segments'] is not None, "GT action labels does not exist"
             assert video_list[0]['labels'] is not None, "GT action labels does not exist"
             dev = self.device
-            gt_segments = [x['segments'].to(dev) for x in video_list if len(x['labels']) > 0]
-            gt_labels = [x['labels'].to(dev) for x in video_list if len(x['labels']) > 0]
-            gt_cls, gt_off, np_cls, np_reg = self.label_points(points, gt_segments, gt_labels)
-            losses = self.losses(fpn_masks, out_cls_logits, out_offsets, gt_cls, gt_off, label_list=gt_labels,
-                                 normal_probs_cls=np_cls, normal_probs_reg=np_reg,
-                                 prev_out_cls_logits=prev_out_cls_logits, reduce_sim=reduce_sim)
+            if fused:
+                losses = self._fused_losses(video_list, points, fpn_lens, out_cls_logits, out_offsets,
+                                            prev_out_cls_logits, reduce_sim)
+            else:
+                gt_segments = [x['segments'].to(dev) for x in video_list if len(x['labels']) > 0]
+                gt_labels = [x['labels'].to(dev) for x in video_list if len(x['labels']) > 0]
+                gt_cls, gt_off, np_cls, np_reg = self.label_points(points, gt_segments, gt_labels)
+                losses = self.losses(fpn_masks, out_cls_logits, out_offsets, gt_cls, gt_off, label_list=gt_labels,
+                                     normal_probs_cls=np_cls, normal_probs_reg=np_reg,
+                                     prev_out_cls_logits=prev_out_cls_logits, reduce_sim=reduce_sim)
             if self.narration_ssl and narr[1].sum() > 0:
                 m0 = narr[1].to(torch.bool)
                 self.memory_bank.update(narration_feats[m0])
@@ -638,6 +655,60 @@ class PtTransformer(nn.Module):
         return cls_targets, reg_targets, (p_cls[rows, min_len_inds], p_left[rows, min_len_inds],
                                           p_right[rows, min_len_inds])
 
+    # ------------------------------------------------------------------ fused labels + losses
+    def _loss_tables(self, points, cat, dev):
+        """(points [R,4], row_level [R], row_pos [R]) of the row layout the loss kernel walks: the LevelCat layout with
+        separator rows (stride 0) or the plain concatenation of the levels.  Cached per layout."""
+        key = (tuple(p.shape[0] for p in points), cat is not None, str(dev))
+        tab = getattr(self, "_loss_tab", None)
+        if tab is None or tab[0] != key:
+            rows, lvl, pos = [], [], []
+            for i, p in enumerate(points):
+                if i and cat is not None:
+                    rows.append(p.new_zeros(1, 4))
+                    lvl.append(i)
+                    pos.append(1 << 30)
+                rows.append(p)
+                lvl.extend([i] * p.shape[0])
+                pos.extend(range(p.shape[0]))
+            tab = (key, (torch.cat(rows).contiguous().to(dev), torch.tensor(lvl, dtype=torch.int32, device=dev),
+                         torch.tensor(pos, dtype=torch.int32, device=dev)))
+            self._loss_tab = tab
+        return tab[1]
+
+    def _fused_losses(self, video_list, points, fpn_lens, out_cls_logits, out_offsets, prev_out_cls_logits, reduce_sim):
+        """meta_archs.py:1253-1344 + 1374-1447 through ops.mq_loss; the CL terms (:1478-1519) are added on top."""
+        cat = self._cat
+        dev = self.device
+        vids = [x for x in video_list if len(x['labels']) > 0]
+        nmax = max(int(x['labels'].shape[0]) for x in vids)
+        gt = torch.zeros(len(vids), 3 * nmax + 1, dtype=torch.float32)
+        for b, x in enumerate(vids):
+            n = int(x['labels'].shape[0])
+            gt[b, :2 * n] = x['segments'].reshape(-1).float().cpu()
+            gt[b, 2 * nmax:2 * nmax + n] = x['labels'].float().cpu()
+            gt[b, 3 * nmax] = n
+        gt = gt.to(dev, non_blocking=True)
+        if cat is not None and getattr(cat, "raw_offsets", None) is not None and out_offsets is None:
+            logits, offsets = cat.cls_logits, cat.raw_offsets
+            scale = torch.stack([s.scale for s in self.reg_head.scale])
+        else:
+            logits, offsets, scale, cat = torch.cat(out_cls_logits, dim=1), torch.cat(out_offsets, dim=1), None, None
+        tables = self._loss_tables(points, cat, dev)
+        level_len = torch.stack([l.to(torch.int32) for l in fpn_lens], dim=1).contiguous()
+        gauss = torch.cat([self.mu, self.sigma, self.mu_reg_left, self.sigma_reg_left, self.mu_reg_right,
+                           self.sigma_reg_right], dim=1).t().contiguous()                         # [6, ncls]
+        norm = self._loss_norm
+        if not (torch.is_tensor(norm) and norm.dim() == 1):
+            norm = torch.full((1,), float(norm), dtype=torch.float32, device=dev)
+            self._loss_norm = norm
+        radius = self.train_center_sample_radius if self.train_center_sample == 'radius' else 0.0
+        cls_loss, reg_loss, al_loss, final_loss = ops.mq_loss(
+            logits, offsets, scale, gauss, tables, level_len, gt, norm, radius, self.train_label_smoothing,
+            self.loss_normalizer_momentum, self.train_loss_weight, self.al_loss_weight, logits.shape[-1] != 1)
+        return self._cl_terms({'cls_loss': cls_loss, 'reg_loss': reg_loss, 'al_loss': al_loss}, final_loss,
+                              out_cls_logits, prev_out_cls_logits, reduce_sim)
+
     # ------------------------------------------------------------------ losses
     @property
     def loss_normalizer(self):
@@ -651,7 +722,7 @@ class PtTransformer(nn.Module):
 
     def _loss_norm_tensor(self, device):
         v = self._loss_norm
-        return v if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float32, device=device)
+        return v.reshape(()) if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float32, device=device)
 
     def losses(self, fpn_masks, out_cls_logits, out_offsets, gt_cls_labels, gt_offsets, label_list=None,
                normal_probs_cls=None, normal_probs_reg=None, out_importances=None, out_start=None,
@@ -718,9 +789,13 @@ class PtTransformer(nn.Module):
             loss_weight = cls_loss.detach() / max(reg_loss.item(), 0.01)
         final_loss = cls_loss + reg_loss * loss_weight + al_loss * self.al_loss_weight
 
+        return self._cl_terms({'cls_loss': cls_loss, 'reg_loss': reg_loss, 'al_loss': al_loss}, final_loss, out_cls_logits,
+                              prev_out_cls_logits, reduce_sim)
+
+    def _cl_terms(self, out, final_loss, out_cls_logits, prev_out_cls_logits, reduce_sim):
+        """continual-learning terms on top of the detection loss (meta_archs.py:1478-1519)"""
         if self.n_known > 0 and self.cl_name == 'l2p':
             final_loss = final_loss - 0.1 * reduce_sim
-        out = {'cls_loss': cls_loss, 'reg_loss': reg_loss, 'al_loss': al_loss}
         if self.n_known > 0 and self.cl_name == 'bic':
             n_classes = self.cls_head.cls_head.conv.out_channels
             alpha, temp, dist_loss = self.n_known / n_classes, 2, 0

@@ -908,3 +908,63 @@ class _ChannelAttn(torch.autograd.Function):
 
 def channel_attention(qkv, n_head, scale):
     return _ChannelAttn.apply(qkv, int(n_head), float(scale))
+
+
+# ---------------------------------------------------------------------------------------- labels + losses
+_almax_state = {}
+
+
+class _MQLoss(torch.autograd.Function):
+    """label_points + losses of the heads (meta_archs.py:1253-1344, 1374-1447) as two launches each way
+    (vilco_mq_loss_fwd / _bwd).  Returns (cls_loss, reg_loss, al_loss, final_loss); `loss_norm` (device float[1]) is the
+    loss_normalizer EMA, updated in place."""
+
+    @staticmethod
+    def forward(ctx, logits, offsets, level_scale, gauss, tables, level_len, gt, loss_norm, cfg):
+        _chk(logits, offsets, level_scale, gauss)
+        lib = _lib.load()
+        B, R, Cn = logits.shape
+        points, row_level, row_pos = tables
+        d = _lib.LossDesc()
+        d.logits, d.offsets, d.level_scale = logits.data_ptr(), offsets.data_ptr(), _p(level_scale)
+        d.points, d.row_level, d.row_pos = points.data_ptr(), row_level.data_ptr(), row_pos.data_ptr()
+        d.level_len, d.gt, d.gauss, d.loss_norm = level_len.data_ptr(), gt.data_ptr(), gauss.data_ptr(), loss_norm.data_ptr()
+        d.B, d.R, d.C, d.L, d.Nmax = B, R, Cn, level_len.shape[1], (gt.shape[1] - 1) // 3
+        d.center_radius, d.label_smoothing, d.momentum = cfg['radius'], cfg['smoothing'], cfg['momentum']
+        d.loss_weight, d.al_weight, d.use_al = cfg['loss_weight'], cfg['al_weight'], int(cfg['use_al'])
+        key = (logits.device.index, B * Cn)
+        st = _almax_state.get(key)
+        if st is None:
+            st = _almax_state[key] = torch.zeros(B * Cn, dtype=torch.int64, device=logits.device)
+        nws = lib.vilco_mq_loss_workspace(B, R, Cn)
+        ws = _ws(nws, logits.device)
+        out = torch.empty(4, dtype=torch.float32, device=logits.device)
+        saved = torch.empty(1, dtype=torch.float32, device=logits.device)
+        _lib.check(lib.vilco_mq_loss_fwd(C.byref(d), out.data_ptr(), saved.data_ptr(), st.data_ptr(), ws.data_ptr(), nws,
+                                         _stream()))
+        ctx.desc, ctx.keep = d, (points, row_level, row_pos, level_len, gt, loss_norm)
+        ctx.save_for_backward(logits, offsets, level_scale, gauss, saved, ws)
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg, g_al, g_final):
+        logits, offsets, level_scale, gauss, saved, ws = ctx.saved_tensors
+        lib = _lib.load()
+        d = ctx.desc
+        dl, do = torch.empty_like(logits), torch.empty_like(offsets)
+        dsc = torch.empty_like(level_scale) if level_scale is not None else None
+        dg = torch.empty_like(gauss)
+        gs = [None if g is None else g.contiguous().float() for g in (g_cls, g_reg, g_al, g_final)]
+        _lib.check(lib.vilco_mq_loss_bwd(C.byref(d), _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(gs[3]), saved.data_ptr(),
+                                         ws.data_ptr(), dl.data_ptr(), do.data_ptr(), _p(dsc), dg.data_ptr(), _stream()))
+        return dl, do, dsc, dg, None, None, None, None, None
+
+
+def mq_loss(logits, offsets, level_scale, gauss, tables, level_len, gt, loss_norm, radius, smoothing, momentum, loss_weight,
+            al_weight, use_al):
+    """logits [B,R,C], offsets [B,R,2] (raw when level_scale [L] is given), gauss [6,C], tables = (points [R,4],
+    row_level [R] int32, row_pos [R] int32), level_len [B,L] int32, gt float [B, 3*Nmax+1] (include/vilco_hip.h)."""
+    cfg = dict(radius=float(radius), smoothing=float(smoothing), momentum=float(momentum), loss_weight=float(loss_weight),
+               al_weight=float(al_weight), use_al=bool(use_al))
+    return _MQLoss.apply(logits.contiguous(), offsets.contiguous(), level_scale, gauss.contiguous(), tables, level_len, gt,
+                         loss_norm, cfg)
