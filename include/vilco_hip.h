@@ -36,6 +36,10 @@ enum vilco_status {
 const char* vilco_status_str(int status);
 /* library / target identification: "vilco_hip <ver> gfx950" */
 const char* vilco_version(void);
+/* With VILCO_GRID_SYNC=1 in the environment two-stage reductions (column sums, amax -> pack) finish inside one      */
+/* launch through a grid-wide barrier whose spin is bounded; this returns how many barriers gave up since the library */
+/* was loaded (0 in a healthy process).  Synchronises the device.  Default: the two-launch forms (measured faster).   */
+int vilco_sync_timeouts_read(void);
 
 /* ------------------------------------------------------------------------------------------ */
 /* GEMM family: every 1x1 conv, k=3 conv, nn.Linear, einsum projection and (round 1) the        */
@@ -84,7 +88,8 @@ typedef struct vilco_gemm_desc {
   /* optional operands already packed by vilco_pack (NULL: the call packs A / B itself).  The packed tensor is the  */
   /* row-major matrix the operand lives in: [M][K] (a_kcontig = 1) or [K][M] (a_kcontig = 0), likewise [N][K] /    */
   /* [K][N] for B -- ONE pack of an activation, a weight or an output gradient serves every product it appears in  */
-  /* (forward, dX = dY W and dW = dY^T X).  Only for tap_operand = NONE and batch 1; A / B may then be NULL.        */
+  /* (forward, dX = dY W and dW = dY^T X).  For tap_operand = NONE and batch 1 (A / B may then be NULL), and for    */
+  /* the weight operand B ([N][3*tapC], k-contiguous) of a conv whose taps are on A (tap_operand = TAP_A).          */
   const void* a_planes;
   const void* b_planes;
   /* XLNet relative-position band (modeling_xlnet_x.py:204-214, 284-325): with T = bandT only the entries          */

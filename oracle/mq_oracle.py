@@ -462,6 +462,23 @@ def prompt_forward(p, cfg, text_tm, prompt_idx):
     return torch.cat([batched, text_tm], dim=1), reduce_sim
 
 
+def prompt_select(p, cfg, text_tm):
+    """Prompt.forward's own selection (prompt_mask = None: inference, and training once the task window runs past the
+    pool): top-k keys per sample by cosine similarity, then -- batchwise_prompt -- the top_k most frequent ids of the
+    batch for every sample (prompt.py:66-82)."""
+    def l2n(v):
+        return v * torch.rsqrt(torch.maximum((v ** 2).sum(1, keepdim=True), torch.tensor(1e-12, dtype=v.dtype)))
+    k, pool = cfg['cl_cfg']['topk'], cfg['cl_cfg']['pool_size']
+    sim = l2n(text_tm.mean(dim=1)) @ l2n(p['prompt.prompt_key']).t()
+    _, idx = torch.topk(sim, k=k, dim=1)
+    ids, counts = torch.unique(idx, return_counts=True, sorted=True)
+    if ids.shape[0] < pool:
+        ids = torch.cat([ids, torch.full((pool - ids.shape[0],), int(idx.min()), dtype=ids.dtype)])
+        counts = torch.cat([counts, torch.zeros(pool - counts.shape[0], dtype=counts.dtype)])
+    _, major = torch.topk(counts, k=k)
+    return ids[major].expand(text_tm.shape[0], -1)
+
+
 def batch_inputs(cfg, video_list, training, dtype=torch.float32):
     """preprocessing + query_preprocessing, meta_archs.py:1134-1221 (padding to max_seq_len)."""
     feats = [v['feats'] for v in video_list if len(v['labels']) > 0]
@@ -495,7 +512,10 @@ def forward_network(p, cfg, video_list, training=True, task_id=-1):
     adapter_blocks = tuple(cfg['cl_cfg']['adapt_blocks']) if cfg['cl_cfg'].get('use_adapt') else ()
     if 'prompt.prompt' in p:
         k = cfg['cl_cfg']['topk']
-        idx = torch.arange(task_id * k, (task_id + 1) * k).unsqueeze(0).expand(text.shape[0], -1)
+        if training and (task_id + 1) * k <= cfg['cl_cfg']['pool_size']:
+            idx = torch.arange(task_id * k, (task_id + 1) * k).unsqueeze(0).expand(text.shape[0], -1)
+        else:
+            idx = prompt_select(p, cfg, text.permute(0, 2, 1))                 # meta_archs.py:766-769
         ttm, reduce_sim = prompt_forward(p, cfg, text.permute(0, 2, 1), idx)
         text = ttm.permute(0, 2, 1)
         tl = torch.as_tensor([v['prompt_feature'].shape[-1] for v in video_list])

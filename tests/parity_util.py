@@ -173,6 +173,7 @@ def oracle_episode_trajectory(gold, dtype=torch.float64):
             warnings.simplefilter("ignore")
             return torch.optim.AdamW(groups, lr=cfg['opt']['learning_rate'])
     out = []
+    ema = {k: v.detach().clone() for k, v in model.pets.state_dict().items()}      # adapter EMA (meta_archs.py:702-707)
     for task in range(2):
         opt = mkopt()
         sch = make_scheduler(opt, cfg['opt'], len(cases.episode_batches(task)))
@@ -188,8 +189,21 @@ def oracle_episode_trajectory(gold, dtype=torch.float64):
             torch.nn.utils.clip_grad_norm_(model.parameters(), cfg['train_cfg']['clip_grad_l2norm'])
             opt.step()
             sch.step()
+            for k, v in model.pets.state_dict().items():
+                ema[k] = 0.999 * ema[k] + 0.001 * v.detach()
             losses.append({k: float(v.detach().sum()) for k, v in ls.items()})
-        out.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, before))
+        # eval-mode forward of the task's first clip with the adapter-EMA ensemble (meta_archs.py:854-881)
+        clip = cases.episode_batches(task)[0][0]
+        clip = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in clip.items()}
+        with torch.no_grad():
+            sd = dict(model.state_dict())
+            _, _, cls_a, off_a, _ = mq_oracle.forward_network(sd, mcfg, [clip], training=False, task_id=task)
+            sd_e = dict(sd)
+            for k, v in ema.items():
+                sd_e['pets.' + k] = v
+            _, _, cls_b, off_b, _ = mq_oracle.forward_network(sd_e, mcfg, [clip], training=False, task_id=task)
+        evals = ([(a + b) / 2 for a, b in zip(cls_a, cls_b)], [(a + b) / 2 for a, b in zip(off_a, off_b)])
+        out.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, before, evals))
         if task == 0:
             model.n_known = gold['tasks'][0]['n_known']
             torch.manual_seed(99)

@@ -58,6 +58,7 @@ class PackItem(C.Structure):
 SIGNATURES = {
     "vilco_status_str": (C.c_char_p, [C.c_int]),
     "vilco_version": (C.c_char_p, []),
+    "vilco_sync_timeouts_read": (C.c_int, []),
     "vilco_gemm_workspace": (sz, [C.POINTER(GemmDesc)]),
     "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "vilco_gemm_profile_begin": (C.c_int, []),

@@ -935,7 +935,10 @@ PlaneSpec spec_tr(int B, int H, int T, int hd) {
 // natural (kc) packs queued here go out together in ONE launch (flush_packs)
 struct PackQueue { PackArgs4 a; int n = 0; PackArgs4 t; int nt = 0; };
 
-Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, int B, int H, int T, int hd, int HDP,
+// optnone: hipcc 7.2's -O3 HOST code for this function queues pack descriptors whose amax pointer is not the one
+// passed in (non-fp16 modes then packed fp16 planes; found by bisection with per-function optnone, r02) -- it is a
+// dozen scalar assignments per call, so nothing is lost
+__attribute__((optnone)) Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, int B, int H, int T, int hd, int HDP,
                     int NP, hipStream_t s, const float* amax = nullptr, int namax = 0, float* inv_scale = nullptr,
                     PackQueue* queue = nullptr) {
   PackArgs pa;
@@ -958,23 +961,60 @@ Planes pack_operand(const float* x, __bf16*& dst, const PlaneSpec& sp, bool tr, 
 
 long planes_bytes(const PlaneSpec& sp, int NP) { return up(sp.elems_per_part * NP, 128) * 2; }
 
-// fp16 x2: one amax launch over the [B*T][C] operands (q, k, v[, dO]); returns the partial counts
-struct ScaleWs { float* parts[4]; int n[4]; float* out; };
-ScaleWs run_amax(unsigned char* region, const float* const (&x)[4], const int (&T)[4], int nops, int B, int C, hipStream_t s) {
+// fp16 x2: amax over the [B*T][C] operands (q, k, v[, dO]): the views are planned here and run either inside the fused
+// kc-pack launch (flush_packs) or by one amax launch
+struct ScaleWs {
+  float* parts[4] = {nullptr, nullptr, nullptr, nullptr};
+  int n[4] = {0, 0, 0, 0};
+  float* out = nullptr;
+  AmaxArgs am;
+  int nops = 0;
+};
+ScaleWs plan_amax(unsigned char* region, const float* const (&x)[4], const int (&T)[4], int nops, int B, int C) {
   ScaleWs w;
   float* f = reinterpret_cast<float*>(region);
   w.out = f + 4 * AMAX_MAX_BLOCKS;
-  AmaxArgs am;
+  w.nops = nops;
   for (int i = 0; i < nops; ++i) {
     PackArgs pa = {};
     pa.src = x[i]; pa.ld = C; pa.rows = B * T[i]; pa.K = C; pa.nbi = 1; pa.so = 0; pa.si = 0; pa.tap = 0;
     pa.vec = vilco_aligned(x[i], 16) && (C % 4) == 0;
     w.parts[i] = f + i * AMAX_MAX_BLOCKS;
-    am.op[i] = amax_view(pa, false, 1, w.parts[i]);
-    w.n[i] = am.op[i].nblocks;
+    w.am.op[i] = amax_view(pa, false, 1, w.parts[i]);
+    w.n[i] = w.am.op[i].nblocks;
   }
-  launch_amax(am, nops, s);
   return w;
+}
+
+// all queued packs of one attention call: [amax +] natural packs in one launch, transposing packs in another
+void flush_packs(PackQueue& pq, ScaleWs& sw, bool f16, int NP, int nbatch, hipStream_t s) {
+  if (f16) {
+    PackArgs fa[4];
+    AmaxOp fm[4];
+    int nf = 0;
+    bool covered[4] = {false, false, false, false};
+    for (int i = 0; i < pq.n; ++i)
+      for (int j = 0; j < sw.nops; ++j)
+        if (pq.a.a[i].amax == sw.parts[j]) { fa[nf] = pq.a.a[i]; fm[nf] = sw.am.op[j]; covered[j] = true; ++nf; break; }
+    bool ok = nf == pq.n;
+    for (int j = 0; j < sw.nops && ok; ++j) {
+      if (covered[j]) continue;
+      if (nf == 4) { ok = false; break; }
+      PackArgs d = {};                          // amax only: a pack of zero rows that still leaves {1/s, s}
+      d.Kp = 8; d.nbi = 1; d.tapC = 1; d.tapT = 1; d.out_rows = 0;
+      d.amax = sw.parts[j]; d.inv_scale = sw.out + 2 * j;
+      fa[nf] = d; fm[nf] = sw.am.op[j]; ++nf;
+    }
+    if (ok && dispatch_pack_fused(NP, fa, fm, nf, nbatch, s, VILCO_SITE_ATTNPACK)) {
+      for (int i = 0; i < pq.nt; ++i) pq.t.a[i].namax = fa[0].namax;      // every operand got gx * nbatch partials
+    } else {
+      launch_amax(sw.am, sw.nops, s);
+      if (pq.n) dispatch_pack_multi(NP, pq.a, pq.n, s, nbatch);
+    }
+  } else if (pq.n) {
+    dispatch_pack_multi(NP, pq.a, pq.n, s, nbatch);
+  }
+  if (pq.nt) dispatch_pack_tr_multi(NP, pq.t, pq.nt, s, nbatch);
 }
 
 }  // namespace
@@ -1006,11 +1046,11 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
   a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
   unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
-  ScaleWs sw = {};
+  ScaleWs sw;
   if (precision == 3) {
     const float* const xs[4] = {q, k, v, nullptr};
     const int Ts[4] = {Tq, Tk, Tk, 0};
-    sw = run_amax(wsb, xs, Ts, 3, B, H * hd, s);
+    sw = plan_amax(wsb, xs, Ts, 3, B, H * hd);
     a.sc = reinterpret_cast<const AttnScales*>(sw.out);
   }
   float* so = sw.out;
@@ -1019,8 +1059,7 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
   a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
   a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
-  dispatch_pack_multi(NP, pq.a, pq.n, s, B * H);
-  dispatch_pack_tr_multi(NP, pq.t, pq.nt, s, B * H);
+  flush_packs(pq, sw, precision == 3, NP, B * H, s);
   return hd <= 32 ? dispatch<32>(a, precision, false, s) : dispatch<64>(a, precision, false, s);
 }
 
@@ -1055,11 +1094,11 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
   a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
   a.dout = dout; a.delta = delta; a.o_in = o; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
-  ScaleWs sw = {};
+  ScaleWs sw;
   if (precision == 3) {
     const float* const xs[4] = {q, k, v, dout};
     const int Ts[4] = {Tq, Tk, Tk, Tq};
-    sw = run_amax(wsb, xs, Ts, 4, B, H * hd, s);
+    sw = plan_amax(wsb, xs, Ts, 4, B, H * hd);
     a.sc = reinterpret_cast<const AttnScales*>(sw.out);
   }
   float* so = sw.out;
@@ -1072,7 +1111,6 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
   a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
   a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
-  dispatch_pack_multi(NP, pq.a, pq.n, s, B * H);
-  dispatch_pack_tr_multi(NP, pq.t, pq.nt, s, B * H);
+  flush_packs(pq, sw, precision == 3, NP, B * H, s);
   return hd <= 32 ? dispatch<32>(a, precision, true, s) : dispatch<64>(a, precision, true, s);
 }

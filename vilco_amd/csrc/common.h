@@ -50,3 +50,96 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// In-launch grid barrier + "finish the column reduction in the same launch".
+// Two-stage reductions (per-block partial sums -> final sums; per-block partial maxima -> scale -> pack) used to be two
+// launches each; ~5 us of launch latency plus ~1.5 us of dependency gap per extra kernel made them cost more than the
+// work.  Here every block arrives at a counter, the last one flips a generation word, everybody leaves: ~2-3 us.
+// Requirements, enforced by the host code that sizes the grids: all blocks of the launch are co-resident
+// (<= VILCO_SYNC_MAX_BLOCKS blocks of <= 256 threads: 4 per CU), and one launch at a time per counter pair -- counters
+// are per (stream slot, call site), streams get their slot from vilco_sync_slot() (sync.hip).
+// The spin is bounded: a barrier that does not complete counts a timeout (vilco_sync_timeouts_read) instead of hanging.
+constexpr int VILCO_SYNC_MAX_BLOCKS = 1024;
+constexpr int VILCO_SYNC_SITES = 16;        // barrier states per stream slot
+constexpr int VILCO_SYNC_SLOTS = 8;
+constexpr int VILCO_SYNC_GROUPS = 32;       // arrival groups (one 64-byte line each) below the top-level counter
+constexpr int VILCO_SYNC_WORDS = 16 * (1 + VILCO_SYNC_GROUPS);   // words per barrier state
+enum { VILCO_SITE_PACK = 0, VILCO_SITE_LN = 1, VILCO_SITE_COLSUM = 2, VILCO_SITE_DWCONV = 3, VILCO_SITE_GEMMPACK = 4,
+       VILCO_SITE_ATTNPACK = 5 };
+
+// device address of the site's barrier state (sync.hip), or null: use the two-launch form
+unsigned* vilco_sync_counter(hipStream_t s, int site);
+
+// Device-scope atomics on MI355X execute at the memory side (the per-XCD L2s are not coherent with each other), ~40 ns
+// apiece on one address: 1024 blocks arriving at ONE counter cost ~40 us (measured, r02).  So arrival is two-level:
+// block b arrives at group b % G (G lines in different channels, in parallel), the last arriver of a group arrives at the
+// top line, the last of those flips every group's generation word; blocks poll only their own group's line.
+// state layout (words): line 0 = {top arrive, -, timeouts}; line 1 + g = {arrive, generation}.
+//
+// Memory: an agent-scope release / acquire fence on this multi-XCD part writes back / invalidates the XCD's whole L2
+// (measured: ~20 us per barrier after a kernel has dirtied megabytes).  The barrier therefore carries NO fence: the few
+// words that cross it (partial sums, partial maxima) must be written with vilco_st_agent and read with vilco_ld_agent
+// (write-through / cache-bypassing accesses at device scope); each thread waits for its own stores to be acknowledged
+// before the block arrives.
+__device__ __forceinline__ void vilco_st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float vilco_ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void vilco_grid_barrier(unsigned* ctr, unsigned nblocks, unsigned bid) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // my write-through stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    const unsigned G = nblocks < (unsigned)VILCO_SYNC_GROUPS ? nblocks : (unsigned)VILCO_SYNC_GROUPS;
+    const unsigned grp = bid % G;
+    const unsigned gsize = (nblocks - grp + G - 1) / G;
+    unsigned* g = ctr + 16 * (1 + grp);
+    const unsigned gen = __hip_atomic_load(&g[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // before arriving
+    if (__hip_atomic_fetch_add(&g[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+      __hip_atomic_store(&g[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) {
+        __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the counter resets land before anybody is released
+        for (unsigned j = 0; j < G; ++j)
+          __hip_atomic_fetch_add(&ctr[16 * (1 + j) + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    long spins = 0;
+    while (__hip_atomic_load(&g[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1L << 21)) {            // ~seconds: co-residency assumption violated
+        atomicAdd(&ctr[2], 1u);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// out[j] = sum_r ws[r][j] (j < ncols; j >= split goes to out1[j - split] when out1 != null), by ALL blocks of the launch
+// after a grid barrier: block `bid` of `nblocks` takes 64-column groups bid, bid + nblocks, ...; 4 row slices per group
+// combined through LDS.  blockDim must be 256 (1-D).
+__device__ __forceinline__ void vilco_finish_colsum(const float* __restrict__ ws, float* __restrict__ out0,
+                                                    float* __restrict__ out1, int nrows, int ncols, int split,
+                                                    unsigned* ctr, unsigned bid, unsigned nblocks) {
+  __shared__ float vilco_fc_part[4][64];
+  vilco_grid_barrier(ctr, nblocks, bid);
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  for (int g = (int)bid; g * 64 < ncols; g += (int)nblocks) {
+    const int j = g * 64 + lane;
+    float s = 0.f;
+    if (j < ncols)
+      for (int r = slice; r < nrows; r += 4) s += vilco_ld_agent(ws + (long)r * ncols + j);
+    __syncthreads();
+    vilco_fc_part[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && j < ncols) {
+      s = (vilco_fc_part[0][lane] + vilco_fc_part[1][lane]) + (vilco_fc_part[2][lane] + vilco_fc_part[3][lane]);
+      if (out1 && j >= split) out1[j - split] = s;
+      else out0[j] = s;
+    }
+  }
+}

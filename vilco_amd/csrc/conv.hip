@@ -86,7 +86,8 @@ __global__ __launch_bounds__(EW_THREADS) void dwconv3_bwd_dx_kernel(
 // partial dw: block handles a slab of output rows; thread = 4 channels; ws[block][C*3]
 __global__ __launch_bounds__(EW_THREADS) void dwconv3_bwd_dw_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const int* __restrict__ in_len,
-    float* __restrict__ ws, int B, int Tin, int Tout, int C, int stride, int rows_per_block) {
+    float* __restrict__ ws, int B, int Tin, int Tout, int C, int stride, int rows_per_block, float* __restrict__ dw,
+    unsigned* sync) {
   const int C4 = C >> 2;
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
@@ -112,10 +113,10 @@ __global__ __launch_bounds__(EW_THREADS) void dwconv3_bwd_dw_kernel(
       acc[9] += g.w * xm.w; acc[10] += g.w * x0.w; acc[11] += g.w * xp.w;
     }
     float* o = ws + (long)blockIdx.x * C * 3 + c * 3;
-    st4(o, make_float4(acc[0], acc[1], acc[2], acc[3]));
-    st4(o + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
-    st4(o + 8, make_float4(acc[8], acc[9], acc[10], acc[11]));
+#pragma unroll
+    for (int k = 0; k < 12; ++k) vilco_st_agent(o + k, acc[k]);      // crosses the in-launch barrier: write-through
   }
+  if (sync) vilco_finish_colsum(ws, dw, nullptr, (int)gridDim.x, C * 3, C * 3, sync, blockIdx.x, gridDim.x);
 }
 
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
@@ -230,9 +231,10 @@ extern "C" int vilco_dwconv3_bwd(const float* dy, const float* x, const float* w
     const int nb = dw_blocks(rows);
     const int rpb = (int)((rows + nb - 1) / nb);
     float* ws = reinterpret_cast<float*>(workspace);
+    unsigned* sync = vilco_sync_counter(s, VILCO_SITE_DWCONV);          // nb <= 512 blocks: co-resident
     hipLaunchKernelGGL(dwconv3_bwd_dw_kernel, dim3(nb), dim3(EW_THREADS), 0, s, dy, x, in_len, ws, B, Tin,
-                       Tout, C, stride, rpb);
-    vilco_reduce_rows(ws, dw, nullptr, nb, C * 3, C * 3, s);
+                       Tout, C, stride, rpb, dw, sync);
+    if (!sync) vilco_reduce_rows(ws, dw, nullptr, nb, C * 3, C * 3, s);
   }
   return vilco_launch_status();
 }

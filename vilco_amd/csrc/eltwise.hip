@@ -128,25 +128,29 @@ __global__ __launch_bounds__(EW_THREADS) void scale_add_fwd_kernel(
 __global__ __launch_bounds__(EW_THREADS) void scale_add_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ bval, const float* __restrict__ colscale,
     const float* __restrict__ rowscale, const int* __restrict__ len, int mask_a, float* __restrict__ da,
-    float* __restrict__ db, float* __restrict__ ws, int B, int T, int C, int rows_per_block) {
+    float* __restrict__ db, float* __restrict__ ws, int B, int T, int C, int rows_per_block,
+    float* __restrict__ dcolscale, unsigned* sync) {
   const long R = (long)B * T;
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > R) r1 = R;
   const int c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float cs = colscale ? colscale[c] : 1.f;
-  float acc = 0.f;
-  for (long r = r0; r < r1; ++r) {
-    const int t = (int)(r % T), b = (int)(r / T);
-    const float am = (mask_a && len && t >= len[b]) ? 0.f : 1.f;
-    const float rs = rowscale ? rowscale[b] : 1.f;
-    const float g = dout[r * C + c];
-    if (da) da[r * C + c] = g * am;
-    if (db) db[r * C + c] = g * cs * rs;
-    if (ws) acc += g * bval[r * C + c] * rs;
+  if (c < C) {
+    const float cs = colscale ? colscale[c] : 1.f;
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const int t = (int)(r % T), b = (int)(r / T);
+      const float am = (mask_a && len && t >= len[b]) ? 0.f : 1.f;
+      const float rs = rowscale ? rowscale[b] : 1.f;
+      const float g = dout[r * C + c];
+      if (da) da[r * C + c] = g * am;
+      if (db) db[r * C + c] = g * cs * rs;
+      if (ws) acc += g * bval[r * C + c] * rs;
+    }
+    if (ws) vilco_st_agent(ws + (long)blockIdx.x * C + c, acc);
   }
-  if (ws) ws[(long)blockIdx.x * C + c] = acc;
+  if (sync) vilco_finish_colsum(ws, dcolscale, nullptr, (int)gridDim.x, C, C, sync, blockIdx.y * gridDim.x + blockIdx.x,
+                                gridDim.x * gridDim.y);
 }
 
 __global__ __launch_bounds__(EW_THREADS) void axpby_kernel(float* __restrict__ out,
@@ -161,36 +165,44 @@ __global__ __launch_bounds__(EW_THREADS) void axpby_kernel(float* __restrict__ o
 __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ dz,
     float* __restrict__ ws, int act, const int* __restrict__ len, int T, long rows, int C,
-    int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, float drop_inv_keep) {
+    int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, float drop_inv_keep, float* __restrict__ dbias,
+    unsigned* sync) {
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
   const int c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float acc = 0.f;
-  for (long r = r0; r < r1; ++r) {
-    float g = dy[r * C + c];
-    if (drop_thresh) g = vilco_drop_hash(drop_seed, (uint64_t)(r * C + c)) >= drop_thresh ? g * drop_inv_keep : 0.f;
-    if (len && (int)(r % T) >= len[r / T]) g = 0.f;
-    if (act == VILCO_ACT_RELU) g = (aux[r * C + c] > 0.f) ? g : 0.f;
-    else if (act == VILCO_ACT_GELU) g *= gelu_grad_f(aux[r * C + c]);
-    dz[r * C + c] = g;
-    acc += g;
+  if (c < C) {
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      float g = dy[r * C + c];
+      if (drop_thresh) g = vilco_drop_hash(drop_seed, (uint64_t)(r * C + c)) >= drop_thresh ? g * drop_inv_keep : 0.f;
+      if (len && (int)(r % T) >= len[r / T]) g = 0.f;
+      if (act == VILCO_ACT_RELU) g = (aux[r * C + c] > 0.f) ? g : 0.f;
+      else if (act == VILCO_ACT_GELU) g *= gelu_grad_f(aux[r * C + c]);
+      dz[r * C + c] = g;
+      acc += g;
+    }
+    if (ws) vilco_st_agent(ws + (long)blockIdx.x * C + c, acc);
   }
-  if (ws) ws[(long)blockIdx.x * C + c] = acc;
+  if (sync) vilco_finish_colsum(ws, dbias, nullptr, (int)gridDim.x, C, C, sync, blockIdx.y * gridDim.x + blockIdx.x,
+                                gridDim.x * gridDim.y);
 }
 
 __global__ __launch_bounds__(EW_THREADS) void colsum_partial_kernel(const float* __restrict__ x,
                                                                     float* __restrict__ ws, long rows,
-                                                                    int C, int rows_per_block) {
+                                                                    int C, int rows_per_block, float* __restrict__ out,
+                                                                    unsigned* sync) {
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
   const int c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float acc = 0.f;
-  for (long r = r0; r < r1; ++r) acc += x[r * C + c];
-  ws[(long)blockIdx.x * C + c] = acc;
+  if (c < C) {
+    float acc = 0.f;
+    for (long r = r0; r < r1; ++r) acc += x[r * C + c];
+    vilco_st_agent(ws + (long)blockIdx.x * C + c, acc);
+  }
+  if (sync) vilco_finish_colsum(ws, out, nullptr, (int)gridDim.x, C, C, sync, blockIdx.y * gridDim.x + blockIdx.x,
+                                gridDim.x * gridDim.y);
 }
 
 __global__ __launch_bounds__(EW_THREADS) void mask_rows_kernel(float* __restrict__ x,
@@ -256,6 +268,15 @@ int col_blocks(long rows) {
   if (b > 128) b = 128;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+// row blocks of the 2-D (row chunk, 256-column group) reductions: as col_blocks, but never more than
+// VILCO_SYNC_MAX_BLOCKS blocks in total, so that the in-launch finish (grid barrier) is safe
+int col_blocks_sync(long rows, int C) {
+  const int gy = (C + EW_THREADS - 1) / EW_THREADS;
+  int nb = col_blocks(rows);
+  if ((long)nb * gy > VILCO_SYNC_MAX_BLOCKS) nb = VILCO_SYNC_MAX_BLOCKS / gy;
+  return nb < 1 ? 1 : nb;
 }
 
 }  // namespace
@@ -334,12 +355,13 @@ extern "C" int vilco_scale_add_bwd(const float* dout, const float* bval, const f
   if (rows == 0) return VILCO_OK;
   if (dcolscale && (!workspace || workspace_bytes < vilco_colsum_workspace(rows, C))) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nb = col_blocks(rows);
+  const int nb = col_blocks_sync(rows, C);
   const int rpb = (int)((rows + nb - 1) / nb);
   float* ws = dcolscale ? reinterpret_cast<float*>(workspace) : nullptr;
+  unsigned* sync = (dcolscale && C <= 256 * VILCO_SYNC_MAX_BLOCKS) ? vilco_sync_counter(s, VILCO_SITE_COLSUM) : nullptr;
   hipLaunchKernelGGL(scale_add_bwd_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dout, bval, colscale, rowscale,
-                     len, mask_a, da, db, ws, B, T, C, rpb);
-  if (dcolscale) vilco_reduce_rows(ws, dcolscale, nullptr, nb, C, C, s);
+                     len, mask_a, da, db, ws, B, T, C, rpb, dcolscale, sync);
+  if (dcolscale && !sync) vilco_reduce_rows(ws, dcolscale, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }
 
@@ -379,12 +401,13 @@ extern "C" int vilco_act_bwd(const float* dy, const float* aux, float* dz, float
   if (rows == 0) return VILCO_OK;
   if (dbias && (!workspace || workspace_bytes < vilco_colsum_workspace(rows, C))) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nb = col_blocks(rows);
+  const int nb = col_blocks_sync(rows, C);
   const int rpb = (int)((rows + nb - 1) / nb);
   float* ws = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
+  unsigned* sync = (dbias && C <= 256 * VILCO_SYNC_MAX_BLOCKS) ? vilco_sync_counter(s, VILCO_SITE_COLSUM) : nullptr;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
-                     (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p));
-  if (dbias) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
+                     (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync);
+  if (dbias && !sync) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }
 
@@ -393,11 +416,14 @@ extern "C" int vilco_colsum(const float* x, float* out, int64_t rows, int32_t C,
   if (!x || !out || rows < 0 || C <= 0) return VILCO_ERR_BADARG;
   if (!workspace || workspace_bytes < vilco_colsum_workspace(rows, C)) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nb = col_blocks(rows);
+  if (rows == 0) return hipMemsetAsync(out, 0, sizeof(float) * C, s) == hipSuccess ? VILCO_OK : VILCO_ERR_LAUNCH;
+  const int nb = col_blocks_sync(rows, C);
   const int rpb = (int)((rows + nb - 1) / nb);
   float* ws = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, x, ws, (long)rows, C, rpb);
-  vilco_reduce_rows(ws, out, nullptr, nb, C, C, s);
+  unsigned* sync = C <= 256 * VILCO_SYNC_MAX_BLOCKS ? vilco_sync_counter(s, VILCO_SITE_COLSUM) : nullptr;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, x, ws, (long)rows, C, rpb,
+                     out, sync);
+  if (!sync) vilco_reduce_rows(ws, out, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }
 

@@ -184,11 +184,14 @@ template <int BM, int NP, bool F16, bool AKM, bool BKM>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   constexpr int NT = 512;
   constexpr int MI = BM / 64;                    // 16-row A fragments per wave (wave tile = 16*MI x 64)
-  constexpr int RSA = BM + 16, RSB = BN + 16;    // k-major LDS row strides (elements)
+  // k-major LDS row strides (elements): 16 mod 128, so that a row is 8 dwords mod 64 banks (the 192-row tile borrows
+  // the 256-row stride: its columns 128..191 land on 192..255 under the bit-6 flip)
+  constexpr int RSA = (BM == 192 ? 256 : BM) + 16, RSB = BN + 16;
   constexpr int A_EL = AKM ? 32 * RSA : BM * 32; // elements per part per stage
   constexpr int B_EL = BKM ? 32 * RSB : BN * 32;
   constexpr int TILE = A_EL + B_EL;
-  constexpr int RA = BM * 4 / NT;                // 16-byte chunks per thread per part: 2 or 1
+  constexpr int RA = (BM * 4 + NT - 1) / NT;     // 16-byte chunks per thread per part: 2 or 1 (192 rows: 1.5 -> the
+  constexpr bool RA_TAIL = (BM * 4) % NT != 0;   //  second round is taken by the first half of the threads only)
   constexpr int RB = BN * 4 / NT;                // 1
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* smem = reinterpret_cast<__bf16*>(smem_raw);   // [stage 2][part NP][A tile | B tile]
@@ -217,17 +220,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   long offA[RA], offB[RB];
   int ldsA[RA], ldsB[RB];
   const int crow = tid >> 2, cc = tid & 3;
+  const bool tailA = !RA_TAIL || tid < (BM * 4) % NT;     // does this thread take part in the last A round?
 #pragma unroll
   for (int r = 0; r < RA; ++r) {
     if (AKM) {
       constexpr int CPR = BM / 8;                // chunks per k-row
-      const int id = tid + r * NT, k = id / CPR, c = id % CPR;
+      int id = tid + r * NT;
+      if (id >= 32 * CPR) id = 0;                // (unused slot of the tail round)
+      const int k = id / CPR, c = id % CPR;
       int col = m0 + c * 8;
       if (col > g.a.cols - 8) col = g.a.cols - 8;
       offA[r] = (long)k * g.a.row_stride + col;
       ldsA[r] = k * RSA + ((c * 8) ^ (((k >> 3) & 1) << 6));
     } else {
-      const int row = crow + r * (NT / 4);
+      int row = crow + r * (NT / 4);
+      if (row >= BM) row = 0;
       offA[r] = row_off(g.a, m0 + row) + cc * 8;
       ldsA[r] = lds_off(row, cc);
     }
@@ -299,7 +306,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
 #pragma unroll
-      for (int r = 0; r < RA; ++r) stA[q][r] = *reinterpret_cast<const bf16x8*>(ka + q * g.a.plane_stride + offA[r]);
+      for (int r = 0; r < RA; ++r)
+        if (r + 1 < RA || tailA) stA[q][r] = *reinterpret_cast<const bf16x8*>(ka + q * g.a.plane_stride + offA[r]);
 #pragma unroll
       for (int r = 0; r < RB; ++r) stB[q][r] = *reinterpret_cast<const bf16x8*>(kb + q * g.b.plane_stride + offB[r]);
     }
@@ -309,7 +317,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
 #pragma unroll
-      for (int r = 0; r < RA; ++r) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsA[r]) = stA[q][r];
+      for (int r = 0; r < RA; ++r)
+        if (r + 1 < RA || tailA) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsA[r]) = stA[q][r];
 #pragma unroll
       for (int r = 0; r < RB; ++r) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsB[r]) = stB[q][r];
     }
@@ -540,8 +549,21 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   // (two blocks per CU) wins whenever all its tiles fit one per CU, or M is small; the 256-row tile for the many-tile
   // problems.  With >= 128 tiles only long K is worth splitting (>= 32 K-steps per split); with fewer, filling the
   // 256 CUs comes first, but never below 8 K-steps per split.
-  p.BM = (tiles128 <= 256 || d->M < 2048) ? 128 : 256;
-  const long tiles = p.BM == 256 ? tiles256 : tiles128;
+  // Tile height by wave quantisation: the grid runs in rounds of one tile per CU (256 CUs), so the cost of a tile
+  // height BM is ceil(tiles / 256) * BM; the commonest shape, M = 4608 x N = 1024, is 144 tiles at 256 rows (44 % of
+  // the CUs idle), 288 at 128 (two rounds) and 192 at 192 rows (one round, 75 % busy).  Ties go to the taller tile
+  // (fewer B re-reads).  The 192-row tile exists for the default precision only.
+  const long tiles192 = ((d->M + 191) / 192) * tn * nbatch;
+  if (tiles128 <= 256 || d->M < 2048) {
+    p.BM = 128;
+  } else {
+    const long c128 = ((tiles128 + 255) / 256) * 128, c192 = ((tiles192 + 255) / 256) * 192, c256 = ((tiles256 + 255) / 256) * 256;
+    p.BM = 256;
+    long best = c256;
+    if (d->precision == 3 && c192 < best) { p.BM = 192; best = c192; }
+    if (c128 < best) { p.BM = 128; best = c128; }
+  }
+  const long tiles = p.BM == 256 ? tiles256 : (p.BM == 192 ? tiles192 : tiles128);
   const int nk = p.Kp / BK;
   int ks = 1;
   if (tiles < 256) {
@@ -556,7 +578,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
     if (ks < 1) ks = 1;
   }
   // tuning overrides (tools/gemm_tune.py): VILCO_GEMM_BM = 128|256, VILCO_GEMM_KS = forced split count
-  if (const char* e = getenv("VILCO_GEMM_BM")) { const int v = atoi(e); if (v == 128 || v == 256) p.BM = v; }
+  if (const char* e = getenv("VILCO_GEMM_BM")) { const int v = atoi(e); if (v == 128 || v == 256 || (v == 192 && d->precision == 3)) p.BM = v; }
   if (const char* e = getenv("VILCO_GEMM_KS")) { const int v = atoi(e); if (v >= 1 && v <= nk) ks = v; }
   p.kchunk = (nk + ks - 1) / ks;
   p.ksplit = (nk + p.kchunk - 1) / p.kchunk;
@@ -571,7 +593,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
 
 template <int BM, int NP, bool F16, bool AKM, bool BKM>
 void launch_pp_km(const GArgs& g, dim3 grid, hipStream_t s) {
-  constexpr size_t a_el = AKM ? 32 * (BM + 16) : BM * 32, b_el = BKM ? 32 * (BN + 16) : BN * 32;
+  constexpr size_t a_el = AKM ? 32 * ((BM == 192 ? 256 : BM) + 16) : BM * 32, b_el = BKM ? 32 * (BN + 16) : BN * 32;
   constexpr size_t pipe = (size_t)2 * NP * (a_el + b_el) * sizeof(__bf16), epi = (size_t)8 * 16 * EPI_LD * 4;
   constexpr size_t lds = pipe > epi ? pipe : epi;
   static const bool once = [] {
@@ -677,7 +699,10 @@ extern "C" int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t 
       pa.amax = hdr; pa.namax = am.op[i].nblocks;
     }
   }
-  if (precision == 3) launch_amax(am, n, s);
+  if (precision == 3) {
+    if (dispatch_pack_fused(NP, pk.a, am.op, n, nbatch, s, VILCO_SITE_PACK)) return vilco_launch_status();   // amax + pack: 1 launch
+    launch_amax(am, n, s);
+  }
   if (n == 1 && nbatch == 1) dispatch_pack(NP, pk.a[0], false, 1, s);
   else dispatch_pack_multi(NP, pk, n, s, nbatch);
   return vilco_launch_status();
@@ -699,7 +724,9 @@ extern "C" size_t vilco_gemm_workspace(const vilco_gemm_desc* d) {
 extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (!d || !d->C || (!d->A && !d->a_planes) || (!d->B && !d->b_planes)) return VILCO_ERR_BADARG;
   if (d->a_planes || d->b_planes) {
-    if (d->tap_operand != VILCO_TAP_NONE || !use_km()) return VILCO_ERR_UNSUPPORTED;
+    // pre-packed operands: untapped problems, or the plain (weight) operand B of a k=3 conv whose taps are on A
+    const bool tap_ok = d->tap_operand == VILCO_TAP_NONE || (d->tap_operand == VILCO_TAP_A && !d->a_planes && d->b_kcontig);
+    if (!tap_ok || !use_km()) return VILCO_ERR_UNSUPPORTED;
     if (!vilco_aligned(d->a_planes, 256) || !vilco_aligned(d->b_planes, 256)) return VILCO_ERR_BADARG;
   }
   if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch_outer < 1 || d->batch_inner < 1) return VILCO_ERR_BADARG;
@@ -757,15 +784,20 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (p.b_km) { pb.rows = d->K; pb.K = d->N; pb.Kp = (int)align_up(d->N, 32); }   // natural [K][N] view
   pb.vec = vilco_aligned(d->B, 16) && (d->ldb % 4) == 0 && (d->sBo % 4) == 0 && (d->sBi % 4) == 0;
   pb.amax = f16 ? scales + AMAX_MAX_BLOCKS : nullptr; pb.namax = 0; pb.inv_scale = scales + 2 * AMAX_MAX_BLOCKS + 2;
+  bool doneA = !packA, doneB = !packB;
   if (f16 && (packA || packB)) {
+    // k-contiguous operands: amax + pack in one launch each (grid barrier, pack.h); transposing packs keep the amax launch
+    AmaxOp ma = amax_view(pa, p.a_tr, p.a_nbo, scales), mb = amax_view(pb, p.b_tr, p.b_nbo, scales + AMAX_MAX_BLOCKS);
+    if (packA && !p.a_tr) doneA = dispatch_pack_fused(p.NP, &pa, &ma, 1, p.a_nbo * p.a_nbi, s, VILCO_SITE_GEMMPACK);
+    if (packB && !p.b_tr) doneB = dispatch_pack_fused(p.NP, &pb, &mb, 1, p.b_nbo * p.b_nbi, s, VILCO_SITE_GEMMPACK);
     AmaxArgs am;
     int nops = 0;
-    if (packA) { am.op[nops] = amax_view(pa, p.a_tr, p.a_nbo, scales); pa.namax = am.op[nops++].nblocks; }
-    if (packB) { am.op[nops] = amax_view(pb, p.b_tr, p.b_nbo, scales + AMAX_MAX_BLOCKS); pb.namax = am.op[nops++].nblocks; }
-    launch_amax(am, nops, s);
+    if (!doneA) { am.op[nops++] = ma; pa.namax = ma.nblocks; }
+    if (!doneB) { am.op[nops++] = mb; pb.namax = mb.nblocks; }
+    if (nops) launch_amax(am, nops, s);
   }
-  if (packA) dispatch_pack(p.NP, pa, p.a_tr, p.a_nbo * p.a_nbi, s);
-  if (packB) dispatch_pack(p.NP, pb, p.b_tr, p.b_nbo * p.b_nbi, s);
+  if (!doneA) dispatch_pack(p.NP, pa, p.a_tr, p.a_nbo * p.a_nbi, s);
+  if (!doneB) dispatch_pack(p.NP, pb, p.b_tr, p.b_nbo * p.b_nbi, s);
   const float* inv_a = pa.inv_scale;
   const float* inv_b = pb.inv_scale;
   if (!packA) {    // planes from vilco_pack: [part][rows32][cols32] behind the header
@@ -817,7 +849,11 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
   {
     const bool ak = p.a_km, bk = p.b_km;
-    if (f16) { if (p.BM == 256) launch_pp<256, 2, true>(g, grid, s, ak, bk); else launch_pp<128, 2, true>(g, grid, s, ak, bk); }
+    if (f16) {
+      if (p.BM == 256) launch_pp<256, 2, true>(g, grid, s, ak, bk);
+      else if (p.BM == 192) launch_pp<192, 2, true>(g, grid, s, ak, bk);
+      else launch_pp<128, 2, true>(g, grid, s, ak, bk);
+    }
     else if (p.BM == 256) {
       if (p.NP == 1) launch_pp<256, 1>(g, grid, s, ak, bk);
       else if (p.NP == 2) launch_pp<256, 2>(g, grid, s, ak, bk);

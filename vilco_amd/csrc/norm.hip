@@ -82,7 +82,8 @@ template <int NV>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-    float* __restrict__ dx, float* __restrict__ ws, long rows, int C, int relu) {
+    float* __restrict__ dx, float* __restrict__ ws, long rows, int C, int relu,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, unsigned* sync) {
   __shared__ float red[LN_WAVES][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long wid = (long)blockIdx.x * LN_WAVES + wave;
@@ -158,10 +159,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
           const float4 t = *reinterpret_cast<const float4*>(&red[w][lane * 4]);
           a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
-        *reinterpret_cast<float4*>(wsb + which * C + c) = a;
+        float* o = wsb + which * C + c;         // crosses the in-launch barrier: write-through stores
+        vilco_st_agent(o, a.x); vilco_st_agent(o + 1, a.y); vilco_st_agent(o + 2, a.z); vilco_st_agent(o + 3, a.w);
       }
     }
   }
+  // ws rows are [dgamma | dbeta] per block: finish the column sums in this launch (grid barrier), when the host could
+  // give us a counter; otherwise a reduce_rows launch follows
+  if (sync) vilco_finish_colsum(ws, dgamma, dbeta, (int)gridDim.x, 2 * C, C, sync, blockIdx.x, gridDim.x);
 }
 
 // out[j] = sum_r ws[r][j]  (j < ncols); also used by every two-stage column reduction.
@@ -249,7 +254,8 @@ extern "C" int vilco_layernorm_bwd(const float* dy, const float* x, const float*
   const int nb = ln_blocks(rows);
   dim3 grid(nb);
   float* ws = reinterpret_cast<float*>(workspace);
-  LN_DISPATCH(nv, ln_bwd_kernel, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, (int)relu)
-  if (dgamma && dbeta) vilco_reduce_rows(ws, dgamma, dbeta, nb, 2 * C, C, s);  // ws rows: [dgamma | dbeta]
+  unsigned* sync = (dgamma && dbeta) ? vilco_sync_counter(s, VILCO_SITE_LN) : nullptr;   // nb <= 256 blocks: co-resident
+  LN_DISPATCH(nv, ln_bwd_kernel, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, (int)relu, dgamma, dbeta, sync)
+  if (dgamma && dbeta && !sync) vilco_reduce_rows(ws, dgamma, dbeta, nb, 2 * C, C, s);  // ws rows: [dgamma | dbeta]
   return vilco_launch_status();
 }

@@ -48,7 +48,7 @@ __device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3], f
 __device__ __forceinline__ float f16_scale_from(const float* parts, int nparts, float* out, bool writer) {
   __shared__ float red_[4];
   float m = 0.f;
-  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, parts[i]);
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, vilco_ld_agent(parts + i));   // may cross an in-launch barrier
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red_[threadIdx.x >> 6] = m;
   __syncthreads();
@@ -313,6 +313,73 @@ inline int kc_blocks(const PackArgs& a) {
   long blocks = ((long)a.out_rows * (width / 8) + 255) / 256;
   return (int)(blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks));
 }
+
+// ------------------------------------------------------------------------------------------ amax + pack in ONE launch
+// fmt 1 needs the tensor's amax before anything can be packed: phase 1 = every block's partial maximum over its share of
+// the source rows, grid barrier (common.h), phase 2 = the kc pack, which folds the partials into the scale exactly as
+// after a separate amax launch.  Up to four operands with the same batch count; the grid (gx, nops, nbatch) is sized
+// by the host to stay co-resident.
+struct FusedPackArgs { PackArgs a[4]; AmaxOp m[4]; unsigned* sync; };
+
+template <int NP>
+__global__ __launch_bounds__(256) void pack_kc_fused_kernel(FusedPackArgs args) {
+  {
+    const AmaxOp& o = args.m[blockIdx.y];
+    __shared__ float red[4];
+    const int nblk = gridDim.x * gridDim.z, lin = blockIdx.z * gridDim.x + blockIdx.x;
+    float m = 0.f;
+    const int total_rows = o.nbo * o.nbi * o.R;
+    const int sub = threadIdx.x / o.tw, col = threadIdx.x & (o.tw - 1), rpi = 256 / o.tw;
+    const bool vec = o.vec && (o.W & 3) == 0;
+    const int wq = vec ? (o.W >> 2) : o.W;
+    for (int row = lin * rpi + sub; row < total_rows; row += nblk * rpi) {
+      const int z = row / o.R, r = row - z * o.R;
+      const float* p = o.src + (long)(z / o.nbi) * o.so + (long)(z % o.nbi) * o.si + (long)r * o.ld;
+      if (vec) {
+        for (int c = col; c < wq; c += o.tw) {
+          const float4 v = *reinterpret_cast<const float4*>(p + c * 4);
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+      } else {
+        for (int c = col; c < wq; c += o.tw) m = fmaxf(m, fabsf(p[c]));
+      }
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) vilco_st_agent(o.parts + lin, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+  }
+  vilco_grid_barrier(args.sync, gridDim.x * gridDim.y * gridDim.z, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+  pack_kc_body<NP>(args.a[blockIdx.y], blockIdx.z, blockIdx.x, gridDim.x);
+}
+
+// Launches the fused form when a barrier counter is available and the grid fits; returns false (nothing launched) when
+// the caller has to use launch_amax + dispatch_pack*.  On success a[i].amax / namax describe the partials it wrote, so a
+// transposing pack of the same tensor launched afterwards can reuse them.
+inline bool dispatch_pack_fused(int NP, PackArgs* a, AmaxOp* m, int n, int nbatch, hipStream_t s, int site) {
+  if (n < 1 || n > 4 || (long)n * nbatch > VILCO_SYNC_MAX_BLOCKS) return false;
+  unsigned* sync = vilco_sync_counter(s, site);
+  if (!sync) return false;
+  int gx = 1;
+  for (int i = 0; i < n; ++i) gx = kc_blocks(a[i]) > gx ? kc_blocks(a[i]) : gx;
+  const int cap = VILCO_SYNC_MAX_BLOCKS / (n * nbatch);
+  if (gx > cap) gx = cap;
+  FusedPackArgs fa;
+  for (int i = 0; i < n; ++i) {
+    m[i].nblocks = gx * nbatch;                       // partial count = blocks per operand
+    a[i].amax = m[i].parts;
+    a[i].namax = gx * nbatch;
+    fa.a[i] = a[i];
+    fa.m[i] = m[i];
+  }
+  fa.sync = sync;
+  const dim3 grid(gx, n, nbatch);
+  if (NP == 1) hipLaunchKernelGGL((pack_kc_fused_kernel<1>), grid, dim3(256), 0, s, fa);
+  else if (NP == 2) hipLaunchKernelGGL((pack_kc_fused_kernel<2>), grid, dim3(256), 0, s, fa);
+  else hipLaunchKernelGGL((pack_kc_fused_kernel<3>), grid, dim3(256), 0, s, fa);
+  return true;
+}
+
 
 void dispatch_pack_multi(int NP, const PackArgs4& args, int n, hipStream_t s, int nbatch = 1) {
   int gx = 1;

@@ -187,6 +187,42 @@ def pack_many(items, precision=None, nbatch=1, relshift=False):
 # packed operands are shared between forward, dX and dW (env VILCO_PACK_REUSE=0: every GEMM packs its own operands)
 _reuse_packs = os.environ.get("VILCO_PACK_REUSE", "1") != "0"
 
+# ---- weight planes are packed ONCE per parameter version, not once per step.  A weight's planes (and the re-laid
+# [Cout][tap][Cin] images of k=3 conv weights) are cached on the parameter object, keyed by torch's in-place version
+# counter plus a generation number that everything writing parameters behind autograd's back must bump
+# (`weights_changed()`: FusedOptimizer.step does).  VILCO_WEIGHT_CACHE=0 re-packs on every call.
+_weight_cache = os.environ.get("VILCO_WEIGHT_CACHE", "1") != "0"
+_weight_gen = [0]
+
+
+def weights_changed():
+    """call after writing parameter memory through raw pointers (the fused optimizer kernels)"""
+    _weight_gen[0] += 1
+
+
+def _cached(w, tag, build):
+    """`build()` result cached on w's owning tensor under (tag, storage offset, shape, precision), valid while the
+    owner's version counter and the global weight generation stand still."""
+    if not _weight_cache:
+        return build()
+    owner = w._base if w._base is not None else w
+    if owner.requires_grad and not owner.is_leaf:
+        return build()                                      # an activation, not a stored weight
+    store = owner.__dict__.setdefault("_vilco_cache", {})
+    key = (tag, w.data_ptr(), tuple(w.shape), _precision)
+    ver = (owner._version, _weight_gen[0])
+    ent = store.get(key)
+    if ent is not None and ent[0] == ver:
+        return ent[1]
+    val = build()
+    store[key] = (ver, val)
+    return val
+
+
+def weight_planes(w, rows, cols):
+    """operand planes of the stored matrix w [rows][cols] (a Linear / 1x1-conv weight, an XLNet projection)"""
+    return _cached(w, ("planes", rows, cols), lambda: pack(w.detach(), rows, cols))
+
 
 def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0)):
     """dz = dropmask(dy) * act'(aux) * rowmask, optional column sums -> (dz, dbias)."""
@@ -226,7 +262,10 @@ class _Linear(torch.autograd.Function):
         px = pw = None
         if _reuse_packs:
             ctx.prec = _precision
-            px, pw = pack_many([(x, M, K), (w, N, K)])
+            if _weight_cache:
+                px, pw = pack(x, M, K), weight_planes(w, N, K)
+            else:
+                px, pw = pack_many([(x, M, K), (w, N, K)])
         ctx.drop = _new_drop(drop_site, drop_p, y.shape)      # nn.Dropout after the layer, fused into the epilogue
         gemm(x, w, y, M, N, K, 1, 1, K, K, N, bias=b, preact=pre, act=act, row_len=lens,
              rowT=T or 0, a_planes=px, b_planes=pw, drop=ctx.drop)
@@ -282,7 +321,10 @@ class _LinearKN(torch.autograd.Function):
         px = pw = None
         if _reuse_packs:
             ctx.prec = _precision
-            px, pw = pack_many([(x, M, K), (w, K, N)])
+            if _weight_cache:
+                px, pw = pack(x, M, K), weight_planes(w, K, N)
+            else:
+                px, pw = pack_many([(x, M, K), (w, K, N)])
         gemm(x, w, y, M, N, K, 1, 0, K, N, N, bias=b, a_planes=px, b_planes=pw)                 # NN
         ctx.has_bias = b is not None
         ctx.bshape = None if b is None else b.shape
@@ -324,6 +366,13 @@ def permute3(src, dims, off, strides):
     return out
 
 
+def _conv3_weight(w, dims, off, strides, rows, cols):
+    """(re-laid conv weight, its operand planes or None when the conv's GEMM packs for itself)"""
+    wp = permute3(w.detach(), dims, off, strides)
+    planes = pack(wp, rows, cols) if _reuse_packs else None
+    return wp, planes
+
+
 class _Conv3(torch.autograd.Function):
     """k=3 'same' conv over time + bias, output rows masked (MaskedConv1D, blocks.py:106-130).
     x [B,T,Cin], w [Cout,Cin,3] (reference layout) -> y [B,T,Cout].  Implicit GEMM over overlapped
@@ -335,10 +384,11 @@ class _Conv3(torch.autograd.Function):
         B, T, Cin = x.shape
         Cout = w.shape[0]
         assert w.shape[1] == Cin and w.shape[2] == 3
-        wp = permute3(w, (Cout, 3, Cin), 0, (Cin * 3, 1, 3))          # [Cout][tap][Cin]
+        # [Cout][tap][Cin] image of the weight and its planes: built once per weight version
+        wp, pwp = _cached(w, "conv3_fwd", lambda: _conv3_weight(w, (Cout, 3, Cin), 0, (Cin * 3, 1, 3), Cout, 3 * Cin))
         y = torch.empty(B, T, Cout, dtype=torch.float32, device=x.device)
         gemm(x, wp, y, B * T, Cout, 3 * Cin, 1, 1, Cin, 3 * Cin, Cout, tap=TAP_A, tapC=Cin, tapT=T,
-             bias=b, row_len=lens, rowT=T)
+             bias=b, row_len=lens, rowT=T, b_planes=pwp)
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, lens)
         return y
@@ -357,10 +407,10 @@ class _Conv3(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             # wt[ci][j'][co] = w[co][ci][2-j']: dX is the k=3 conv of dZ with flipped taps
-            wt = permute3(w, (Cin, 3, Cout), 2, (3, -1, Cin * 3))
+            wt, pwt = _cached(w, "conv3_dx", lambda: _conv3_weight(w, (Cin, 3, Cout), 2, (3, -1, Cin * 3), Cin, 3 * Cout))
             dx = torch.empty_like(x)
             gemm(dz, wt, dx, B * T, Cin, 3 * Cout, 1, 1, Cout, 3 * Cout, Cin, tap=TAP_A, tapC=Cout,
-                 tapT=T)
+                 tapT=T, b_planes=pwt)
         if ctx.needs_input_grad[1]:
             dwp = torch.empty(Cout, 3 * Cin, dtype=torch.float32, device=x.device)
             gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch import optim
 
-from .. import _lib
+from .. import _lib, ops
 from ..modeling.blocks import AffineDropPath, LayerNorm, MaskedConv1D, Scale
 from .lr_schedulers import LinearWarmupCosineAnnealingLR, LinearWarmupMultiStepLR
 
@@ -151,6 +151,7 @@ class FusedOptimizer(optim.Optimizer):
                                             plan['group'].data_ptr(), n, plan['nchunks'], CHUNK, lr, wd, ng,
                                             g0['betas'][0], g0['betas'][1], g0['eps'], g0['momentum'], tstep.data_ptr(),
                                             None if coef is None or clip_grad_l2norm <= 0 else coef.data_ptr(), stream))
+        ops.weights_changed()          # parameter memory was written behind autograd's back: cached weight planes are stale
         return None
 
 
