@@ -272,6 +272,29 @@ int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, co
                      float momentum, const float* tensor_step, const float* norm_coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* q/k/v pre-projection of MaskedMHCA fused with the block's first LayerNorm (MQ/libs/modeling/blocks.py:561-563 */
+/* `self.ln1(x)`, :363-369 query/key/value_conv (depthwise k=3, stride 1|2, masked) + query/key/value_norm):       */
+/*   h = LN1(x);  y_j = LN_j(dwconv3(h; w_j) * mask),  j = q, k, v.   One read of x, three writes (+ h on request).  */
+/* w / gam / bet / y / mean / rstd are HOST arrays of three device pointers (q, k, v); w_j is the [C][1][3] conv    */
+/* weight, gam_j / bet_j the [C] LayerNorm affine (the reference's [1,C,1] tensors).  mean1 / rstd1 [B*T] and       */
+/* mean_j / rstd_j [B*T/stride] are kept for backward; h may be NULL.  C must be a multiple of 256, at most 2304.   */
+/* Backward recomputes the conv outputs from h: dc_j (scratch, [B][T/stride][C] each) receives the gradient wrt the  */
+/* masked conv outputs, dh = dh_ext (may be NULL) + the conv-transpose of the three; dparams [15][C] = d gam_q,     */
+/* d bet_q, d gam_k, d bet_k, d gam_v, d bet_v, then d w_j[tap] as [j][tap][C] planes.  LN1's own backward is         */
+/* vilco_layernorm_bwd on (dh, x, mean1, rstd1).                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+int vilco_qkv_pre_supported(int32_t C);
+int vilco_qkv_pre_fwd(const float* x, const float* ln1_g, const float* ln1_b, const float* const* w,
+                      const float* const* gam, const float* const* bet, const int32_t* len, float* h,
+                      float* const* y, float* mean1, float* rstd1, float* const* mean, float* const* rstd,
+                      int32_t B, int32_t T, int32_t C, int32_t stride, float eps1, float eps, void* stream);
+size_t vilco_qkv_pre_bwd_workspace(int32_t B, int32_t T, int32_t C, int32_t stride);
+int vilco_qkv_pre_bwd(const float* h, const float* const* w, const float* const* gam, const float* const* dy,
+                      const float* const* mean, const float* const* rstd, const int32_t* len,
+                      const float* dh_ext, float* const* dc, float* dh, float* dparams, int32_t B, int32_t T,
+                      int32_t C, int32_t stride, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Point labelling + losses of the heads in two launches each way: label_points_single_video                    */
 /* (MQ/libs/modeling/meta_archs.py:1253-1344), losses (:1374-1447: focal on valid points x gaussian weights,      */
 /* DIoU on positives, "al" loss, loss_normalizer EMA :1407-1410), sigmoid_focal_loss / ctr_diou_loss_1d           */

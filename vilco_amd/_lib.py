@@ -102,6 +102,14 @@ SIGNATURES = {
     "vilco_grad_norm": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, f32, c_fp, c_fp, c_fp]),
     "vilco_optim_step": (C.c_int, [i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), i32,
                                    f32, f32, f32, f32, c_fp, c_fp, c_fp]),
+    "vilco_qkv_pre_supported": (C.c_int, [i32]),
+    "vilco_qkv_pre_fwd": (C.c_int, [c_fp, c_fp, c_fp, C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), c_fp, c_fp,
+                                    C.POINTER(c_fp), c_fp, c_fp, C.POINTER(c_fp), C.POINTER(c_fp), i32, i32, i32, i32, f32,
+                                    f32, c_fp]),
+    "vilco_qkv_pre_bwd_workspace": (sz, [i32, i32, i32, i32]),
+    "vilco_qkv_pre_bwd": (C.c_int, [c_fp, C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp),
+                                    C.POINTER(c_fp), c_fp, c_fp, C.POINTER(c_fp), c_fp, c_fp, i32, i32, i32, i32, c_fp, sz,
+                                    c_fp]),
     "vilco_mq_loss_workspace": (sz, [i32, i32, i32]),
     "vilco_mq_loss_fwd": (C.c_int, [C.POINTER(LossDesc), c_fp, c_fp, c_fp, c_fp, sz, c_fp]),
     "vilco_mq_loss_bwd": (C.c_int, [C.POINTER(LossDesc), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,

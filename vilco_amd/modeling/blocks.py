@@ -211,6 +211,25 @@ class MaskedMHCA(nn.Module):
         self.proj_drop = nn.Dropout(proj_pdrop)
         self.proj = nn.Conv1d(n_embd, n_embd, 1)
 
+    def fusable(self):
+        """the q/k/v pre-projection can run as ONE kernel together with the block's ln1 (ops.qkv_pre)"""
+        c = self.query_conv.conv
+        return (ops.use_qkv_pre and ops.qkv_pre_supported(self.n_embd) and c.kernel_size[0] == 3
+                and self.query_conv.stride == self.key_conv.stride == self.value_conv.stride and self.query_conv.stride in (1, 2)
+                and self.query_norm.eps == self.key_norm.eps == self.value_norm.eps and self.query_norm.affine)
+
+    def forward_tm_fused(self, x, lens, ln1, want_h):
+        """(attention output, q_lens, h = ln1(x) or None): ln1 + the three depthwise convs + their LayerNorms in one launch"""
+        s = self.query_conv.stride
+        outs = ops.qkv_pre(x, (ln1.weight, ln1.bias, ln1.eps),
+                           (self.query_conv.conv.weight, self.key_conv.conv.weight, self.value_conv.conv.weight),
+                           ((self.query_norm.weight, self.query_norm.bias), (self.key_norm.weight, self.key_norm.bias),
+                            (self.value_norm.weight, self.value_norm.bias), self.query_norm.eps), lens, s, want_h)
+        q, k, v = outs[:3]
+        q_lens = down_lens(lens, s)
+        out, q_lens = self._attend(q, k, v, q_lens, q_lens)
+        return out, q_lens, (outs[3] if want_h else None)
+
     def forward_tm(self, x, lens):
         q, q_lens = self.query_conv.forward_tm(x, lens)
         q = self.query_norm.forward_tm(q)
@@ -218,6 +237,9 @@ class MaskedMHCA(nn.Module):
         k = self.key_norm.forward_tm(k)
         v, _ = self.value_conv.forward_tm(x, lens)
         v = self.value_norm.forward_tm(v)
+        return self._attend(q, k, v, q_lens, kv_lens)
+
+    def _attend(self, q, k, v, q_lens, kv_lens):
         q = ops.linear(q, self.query.weight, self.query.bias)
         k = ops.linear(k, self.key.weight, self.key.bias)
         v = ops.linear(v, self.value.weight, self.value.bias)
@@ -371,8 +393,12 @@ class TransformerBlock(nn.Module):
         return None, None
 
     def forward_tm(self, x, lens, cross_y=None, cross_lens=None):
-        h = self.ln1.forward_tm(x)
-        a, out_lens = self.attn.forward_tm(h, lens)
+        need_h = (self.n_ds_strides[0] == 1 and self.n_ds_strides[1] == 1) or (self.adapters is not None and "attn" in self.adapters)
+        if self.attn.fusable() and self.ln1.affine:
+            a, out_lens, h = self.attn.forward_tm_fused(x, lens, self.ln1, need_h)
+        else:
+            h = self.ln1.forward_tm(x)
+            a, out_lens = self.attn.forward_tm(h, lens)
         if self.adapters is not None and "attn" in self.adapters:
             a = a + self.adapters["attn"].forward_tm(h)          # parallel adapter (meta_archs.py:144-148)
         skip = ops.maxpool3s2(x, lens) if self.n_ds_strides[0] > 1 else x

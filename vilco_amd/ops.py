@@ -1018,3 +1018,84 @@ def mq_loss(logits, offsets, level_scale, gauss, tables, level_len, gt, loss_nor
                al_weight=float(al_weight), use_al=bool(use_al))
     return _MQLoss.apply(logits.contiguous(), offsets.contiguous(), level_scale, gauss.contiguous(), tables, level_len, gt,
                          loss_norm, cfg)
+
+
+# ---------------------------------------------------------------------------------------- fused ln1 -> q/k/v pre-projection
+def qkv_pre_supported(Cn):
+    return bool(_lib.load().vilco_qkv_pre_supported(int(Cn)))
+
+
+use_qkv_pre = os.environ.get("VILCO_QKV_PRE", "1") != "0"
+
+
+def _ptr3(ts):
+    return (_lib.c_fp * 3)(*[_p(t) for t in ts])
+
+
+class _QkvPre(torch.autograd.Function):
+    """h = LN1(x); y_j = LN_j(dwconv3_stride(h; w_j) * mask), j = q, k, v   (blocks.py:561-563, 363-369) in one launch
+    (vilco_qkv_pre_fwd); backward = vilco_qkv_pre_bwd (conv outputs recomputed from h) + LN1's ordinary backward."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv, lens, stride, eps1, eps, want_h):
+        _chk(x, g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv)
+        lib = _lib.load()
+        B, T, Cn = x.shape
+        To = T // stride
+        dev = x.device
+        ys = [torch.empty(B, To, Cn, dtype=torch.float32, device=dev) for _ in range(3)]
+        h = torch.empty_like(x) if want_h else None
+        stats1 = torch.empty(2, B * T, dtype=torch.float32, device=dev)
+        stats = torch.empty(6, B * To, dtype=torch.float32, device=dev)
+        means, rstds = [stats[2 * j] for j in range(3)], [stats[2 * j + 1] for j in range(3)]
+        _lib.check(lib.vilco_qkv_pre_fwd(x.data_ptr(), _p(g1), _p(b1), _ptr3([wq, wk, wv]), _ptr3([gq, gk, gv]),
+                                         _ptr3([bq, bk, bv]), lens.data_ptr(), _p(h), _ptr3(ys), stats1[0].data_ptr(),
+                                         stats1[1].data_ptr(), _ptr3(means), _ptr3(rstds), B, T, Cn, int(stride),
+                                         float(eps1), float(eps), _stream()))
+        ctx.stride, ctx.eps1, ctx.want_h = int(stride), float(eps1), bool(want_h)
+        ctx.save_for_backward(x, g1, b1, wq, wk, wv, gq, gk, gv, lens, stats1, stats, h)
+        return (ys[0], ys[1], ys[2], h) if want_h else (ys[0], ys[1], ys[2])
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv, dh_ext=None):
+        x, g1, b1, wq, wk, wv, gq, gk, gv, lens, stats1, stats, h = ctx.saved_tensors
+        lib = _lib.load()
+        B, T, Cn = x.shape
+        To = T // ctx.stride
+        dev = x.device
+        if h is None:        # nobody else needed h in forward: rebuild it (one LayerNorm pass) for the conv recomputation
+            h = torch.empty_like(x)
+            _lib.check(lib.vilco_layernorm_fwd(x.data_ptr(), _p(g1), _p(b1), h.data_ptr(), None, None, B * T, Cn, ctx.eps1, 0,
+                                               _stream()))
+        dys = [torch.zeros(B, To, Cn, dtype=torch.float32, device=dev) if g is None else g.contiguous() for g in (dq, dk, dv)]
+        dcs = [torch.empty(B, To, Cn, dtype=torch.float32, device=dev) for _ in range(3)]
+        dh = torch.empty_like(x)
+        dpar = torch.empty(15, Cn, dtype=torch.float32, device=dev)
+        nws = lib.vilco_qkv_pre_bwd_workspace(B, T, Cn, ctx.stride)
+        ws = _ws(nws, dev)
+        means, rstds = [stats[2 * j] for j in range(3)], [stats[2 * j + 1] for j in range(3)]
+        dh_ext = None if dh_ext is None else dh_ext.contiguous()
+        _lib.check(lib.vilco_qkv_pre_bwd(h.data_ptr(), _ptr3([wq, wk, wv]), _ptr3([gq, gk, gv]), _ptr3(dys), _ptr3(means),
+                                         _ptr3(rstds), lens.data_ptr(), _p(dh_ext), _ptr3(dcs), dh.data_ptr(), dpar.data_ptr(),
+                                         B, T, Cn, ctx.stride, ws.data_ptr(), nws, _stream()))
+        del dcs
+        dx = torch.empty_like(x)
+        dg1 = torch.empty(Cn, dtype=torch.float32, device=dev)
+        db1 = torch.empty(Cn, dtype=torch.float32, device=dev)
+        ws1 = _ws(lib.vilco_layernorm_bwd_workspace(B * T, Cn), dev)
+        _lib.check(lib.vilco_layernorm_bwd(dh.data_ptr(), x.data_ptr(), None, _p(g1), stats1[0].data_ptr(), stats1[1].data_ptr(),
+                                           dx.data_ptr(), dg1.data_ptr(), db1.data_ptr(), B * T, Cn, 0, ws1.data_ptr(),
+                                           ws1.numel(), _stream()))
+        dws = [dpar[6 + 3 * j:9 + 3 * j].t().contiguous().view_as(w) for j, w in enumerate((wq, wk, wv))]
+        dgs = [dpar[2 * j].view_as(g) for j, g in enumerate((gq, gk, gv))]
+        dbs = [dpar[2 * j + 1].view_as(g) for j, g in enumerate((gq, gk, gv))]
+        return (dx, dg1.view_as(g1), db1.view_as(g1), dws[0], dws[1], dws[2], dgs[0], dbs[0], dgs[1], dbs[1], dgs[2], dbs[2],
+                None, None, None, None, None)
+
+
+def qkv_pre(x, ln1, convs, norms, lens, stride, want_h):
+    """x [B,T,C]; ln1 = (weight, bias, eps) of the block's first LayerNorm; convs = three depthwise [C,1,3] weights
+    (query, key, value); norms = three (weight, bias) pairs + one eps -> (q, k, v[, h])."""
+    (g1, b1, eps1), (wq, wk, wv), ((gq, bq), (gk, bk), (gv, bv), eps) = ln1, convs, norms
+    return _QkvPre.apply(x.contiguous(), g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv, lens, int(stride), float(eps1),
+                         float(eps), bool(want_h))
