@@ -192,7 +192,9 @@ int vilco_relshift_bwd(const float* ds, float* dbd, float scale, int32_t B, int3
 /* MaskedMHCA / MaskedMHA cores (blocks.py:383-400, 251-265) and, with `bias`, XLNet's             */
 /* rel_attn_core (modeling_xlnet_x.py:270-320; bias = scale * rel_shift(bd)).  Scores stay on chip. */
 /* q [B,Tq,H*hd], k/v [B,Tk,H*hd], bias [B,H,Tq,Tk] or null, lse [B,H,Tq] (saved for backward).     */
-/* mask modes as vilco_softmax_fwd (+ 3: XLNet mask with the bias given as unshifted position scores [B,H,Tq,Tq+Tk]); */
+/* mask modes as vilco_softmax_fwd (+ 3: XLNet mask with the bias given as unshifted position scores [B,H,Tq,Tq+Tk]; */
+/* + 4: sliding window |i - j| <= window below kv_len, Tq == Tk -- NLQ's LocalMaskedMHCA, NLQ/libs/modeling/blocks.py   */
+/* :417-755; only the key tiles a query tile's windows reach are visited);                                           */
 /* precision as vilco_gemm.  hd <= 64, hd % 4 == 0.  drop_p > 0: inverted dropout on the attention probabilities      */
 /* (after the softmax, before P V) with the counter-based mask of vilco_dropout: element (bh*Tq + i)*Tk + j of stream   */
 /* drop_seed; forward and backward must be given the same (drop_p, drop_seed).                                         */
@@ -202,14 +204,14 @@ int vilco_attn_supported(int32_t hd);
 size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
-                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, float drop_p,
+                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                    uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
 size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 /* dq/dk/dv are overwritten; dbias (optional, [B,H,Tq,Tk]) receives dS.  Deterministic (no atomics). */
 int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, const float* o, const float* lse, const float* dout,
                    float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
-                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, float drop_p,
+                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                    uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */

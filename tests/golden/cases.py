@@ -136,3 +136,32 @@ def reg_toy_loss(model):
 
 def reg_toy_loader(device='cpu'):
     return [torch.randn(4, 6, generator=torch.Generator().manual_seed(20 + i)).to(device) for i in range(3)]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# NLQ variant (BASELINE configs[3] scaled down): sliding-window attention blocks and the two-stream backbone
+NLQ_C, NLQ_H, NLQ_T, NLQ_L, NLQ_WIN, NLQ_CV, NLQ_CT = 32, 4, 96, 11, 9, 40, 24
+
+
+def nlq_inputs():
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(2, NLQ_C, NLQ_T, generator=g)
+    mask = (torch.arange(NLQ_T)[None, :] < torch.tensor([NLQ_T, NLQ_T - 21])[:, None]).unsqueeze(1)
+    x = x * mask
+    txt = torch.randn(2, NLQ_C, NLQ_L, generator=g)
+    tmask = (torch.arange(NLQ_L)[None, :] < torch.tensor([NLQ_L, NLQ_L - 3])[:, None]).unsqueeze(1)
+    return x, mask, txt * tmask, tmask
+
+
+def nlq_backbone_cfg():
+    return dict(n_vid_in=NLQ_CV, n_txt_in=NLQ_CT, n_embd=NLQ_C, n_head=NLQ_H, n_embd_ks=3, max_len=NLQ_T, arch=(2, 1, 1, 1, 2),
+                mha_win_size=[NLQ_WIN, NLQ_WIN, -1, -1], scale_factor=2, with_ln=True, path_pdrop=0.1, use_abs_pe=True)
+
+
+def nlq_backbone_inputs():
+    g = torch.Generator().manual_seed(321)
+    vid = torch.randn(2, NLQ_CV, NLQ_T, generator=g)
+    vmask = (torch.arange(NLQ_T)[None, :] < torch.tensor([NLQ_T, NLQ_T - 29])[:, None]).unsqueeze(1)
+    txt = torch.randn(2, NLQ_CT, NLQ_L, generator=g)
+    tmask = (torch.arange(NLQ_L)[None, :] < torch.tensor([NLQ_L - 4, NLQ_L])[:, None]).unsqueeze(1)
+    return vid * vmask, vmask, txt * tmask, tmask

@@ -183,6 +183,7 @@ struct AttnArgs {
   int B, H, Tq, Tk, hd, C;
   float scale;
   int mode;
+  int window;               // mode 4: half-width w of the local attention window
   // backward
   const float* dout; float* delta;     // delta[b,h,i] = dO_i . O_i: written by attn_bwd_dq, read by attn_bwd_dkdv
   const float* o_in;                   // forward output (backward only)
@@ -253,10 +254,14 @@ __device__ __forceinline__ float drop_keep(const AttnArgs& a, int bh, int i, int
 }
 
 // score of (query i, key j) after scale + bias: apply the mask
-__device__ __forceinline__ float mask_score(float s, int i, int j, int len, int Tk, int mode) {
+// mode 4 (NLQ's LocalMaskedMHCA, NLQ/libs/modeling/blocks.py:417-755): keys inside the sliding window |i - j| <= w and
+// below kv_len; the reference adds -1e4 to masked keys inside the window instead of removing them, which is exp(-1e4) = 0
+// in fp32 next to the always-valid key j = i
+__device__ __forceinline__ float mask_score(float s, int i, int j, int len, int Tk, int mode, int w = 0) {
   if (j >= Tk) return -INFINITY;
   if (mode == 0) return j < len ? s : -INFINITY;
   if (mode == 1) return (j >= len && j != i) ? s - 1e30f : s;
+  if (mode == 4) return (j < len && j - i <= w && i - j <= w) ? s : -INFINITY;
   return s;
 }
 
@@ -296,18 +301,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   int kend = a.Tk;
-  if (mmode == 0 && len < kend) kend = len;      // tiles entirely beyond kv_len contribute nothing
-  const int ntiles = (kend + BKV - 1) / BKV;
-  const int kfull = len < a.Tk ? len : a.Tk;      // keys below this index need no masking in any mode
+  if ((mmode == 0 || mmode == 4) && len < kend) kend = len;      // tiles entirely beyond kv_len contribute nothing
+  int ntiles = (kend + BKV - 1) / BKV, tlo = 0;
+  if (mmode == 4) {                                  // only the key tiles the 64 queries' windows reach
+    const int klo = qt * 64 - a.window, khi = qt * 64 + 63 + a.window;
+    tlo = klo > 0 ? klo / BKV : 0;
+    if (khi / BKV + 1 < ntiles) ntiles = khi / BKV + 1;
+  }
+  const int kfull = mmode == 4 ? 0 : (len < a.Tk ? len : a.Tk);      // keys below this index need no masking
   __bf16* myP = sP + wave * NP * 16 * BKV;
 
   TileStage<HDP, BKV, NP> stK;
   TileStage<BKV, HDP, NP> stV;
-  if (ntiles > 0) {
-    gload_tile<HDP, BKV, NP>(stK, a.kn, kbase, 0, 0, tid);
-    gload_tile<BKV, HDP, NP>(stV, a.vt, vbase, 0, 0, tid);
+  if (ntiles > tlo) {
+    gload_tile<HDP, BKV, NP>(stK, a.kn, kbase, tlo * BKV, 0, tid);
+    gload_tile<BKV, HDP, NP>(stV, a.vt, vbase, 0, tlo * BKV, tid);
   }
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = tlo; t < ntiles; ++t) {
     const int k0 = t * BKV;
     __syncthreads();                                // previous tile fully consumed
     lstore_tile<HDP, BKV, NP>(stK, sK, tid);
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float x = mask_score(s[mi][r] * qk_scale + (bias ? bvt[mi][r] : 0.f), qi, jb + r, len, a.Tk, mmode);
+          const float x = mask_score(s[mi][r] * qk_scale + (bias ? bvt[mi][r] : 0.f), qi, jb + r, len, a.Tk, mmode, a.window);
           s[mi][r] = x;
           tmax = fmaxf(tmax, x);
         }
@@ -504,19 +514,24 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   for (int i = 0; i < HDP / 16; ++i) dqacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int kend = a.Tk;
-  if (mmode == 0 && len < kend) kend = len;
-  const int ntiles = (kend + BKV - 1) / BKV;
-  const int kfull = len < a.Tk ? len : a.Tk;
+  if ((mmode == 0 || mmode == 4) && len < kend) kend = len;
+  int ntiles = (kend + BKV - 1) / BKV, tlo = 0;
+  if (mmode == 4) {
+    const int klo = qt * 64 - a.window, khi = qt * 64 + 63 + a.window;
+    tlo = klo > 0 ? klo / BKV : 0;
+    if (khi / BKV + 1 < ntiles) ntiles = khi / BKV + 1;
+  }
+  const int kfull = mmode == 4 ? 0 : (len < a.Tk ? len : a.Tk);
   __bf16* myS = sS + wave * NP * 16 * BKV;
 
   TileStage<HDP, BKV, NP> stK, stV;
   TileStage<BKV, HDP, NP> stKt;
-  if (ntiles > 0) {
-    gload_tile<HDP, BKV, NP>(stK, a.kn, knb, 0, 0, tid);
-    gload_tile<HDP, BKV, NP>(stV, a.vn, vnb, 0, 0, tid);
-    gload_tile<BKV, HDP, NP>(stKt, a.kt, ktb, 0, 0, tid);
+  if (ntiles > tlo) {
+    gload_tile<HDP, BKV, NP>(stK, a.kn, knb, tlo * BKV, 0, tid);
+    gload_tile<HDP, BKV, NP>(stV, a.vn, vnb, tlo * BKV, 0, tid);
+    gload_tile<BKV, HDP, NP>(stKt, a.kt, ktb, 0, tlo * BKV, tid);
   }
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = tlo; t < ntiles; ++t) {
     const int k0 = t * BKV;
     __syncthreads();
     lstore_tile<HDP, BKV, NP>(stK, sK, tid);
@@ -567,7 +582,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = s[r] * qk_scale;
-        if (!plain) x = mask_score(x + (bias ? bvt[mi][r] : 0.f), qi, jb + r, len, a.Tk, mmode);
+        if (!plain) x = mask_score(x + (bias ? bvt[mi][r] : 0.f), qi, jb + r, len, a.Tk, mmode, a.window);
         const float p = (x == -INFINITY) ? 0.f : fast_exp(x - lse);
         const float dpr = (!DROP || ((keep_bits >> (mi * 4 + r)) & 1u)) ? dp[r] : 0.f;
         ds[r] = p * (dpr - dlt);
@@ -674,10 +689,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
 #pragma unroll
   for (int i = 0; i < HDP / 16; ++i) { dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const bool tile_dead = (mmode == 0 && k0 >= len);      // every key of this tile is masked: grads are zero
-  const int kfull = len < a.Tk ? len : a.Tk;
+  const bool tile_dead = ((mmode == 0 || mmode == 4) && k0 >= len);      // every key of this tile is masked: grads are zero
+  const int kfull = mmode == 4 ? 0 : (len < a.Tk ? len : a.Tk);
   const bool plain = (bias == nullptr) && (k0 + BKV <= kfull);
-  const int nq = tile_dead ? 0 : (a.Tq + BQ - 1) / BQ;
+  int nq = tile_dead ? 0 : (a.Tq + BQ - 1) / BQ, qlo = 0;
+  if (mmode == 4) {                                   // only the query tiles whose windows reach these 64 keys
+    const int ilo = k0 - a.window, ihi = k0 + BKV - 1 + a.window;
+    qlo = ilo > 0 ? ilo / BQ : 0;
+    if (ihi / BQ + 1 < nq) nq = ihi / BQ + 1;
+    if (nq < qlo) nq = qlo;
+  }
   TileStage<HDP, BQ, NP> stQ, stdO;
   TileStage<BQ, HDP, NP> stQt, stdOt;
   // Additive bias of the [32 q][64 keys] tile.  In this kernel's orientation a lane owns one key and four query rows,
@@ -698,14 +719,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
       for (int e = 0; e < 4; ++e) stB[4 * h + e] = v4[e];
     }
   };
-  if (nq > 0) {
-    if (BIAS_LDS && bias) gload_bias(0);
-    gload_tile<HDP, BQ, NP>(stQ, a.qn, qnb, 0, 0, tid);
-    gload_tile<HDP, BQ, NP>(stdO, a.don, donb, 0, 0, tid);
-    gload_tile<BQ, HDP, NP>(stQt, a.qt, qtb, 0, 0, tid);
-    gload_tile<BQ, HDP, NP>(stdOt, a.dot, dotb, 0, 0, tid);
+  if (nq > qlo) {
+    if (BIAS_LDS && bias) gload_bias(qlo * BQ);
+    gload_tile<HDP, BQ, NP>(stQ, a.qn, qnb, qlo * BQ, 0, tid);
+    gload_tile<HDP, BQ, NP>(stdO, a.don, donb, qlo * BQ, 0, tid);
+    gload_tile<BQ, HDP, NP>(stQt, a.qt, qtb, 0, qlo * BQ, tid);
+    gload_tile<BQ, HDP, NP>(stdOt, a.dot, dotb, 0, qlo * BQ, tid);
   }
-  for (int t = 0; t < nq; ++t) {
+  for (int t = qlo; t < nq; ++t) {
     const int q0 = t * BQ;
     __syncthreads();
     lstore_tile<HDP, BQ, NP>(stQ, sQ, tid);
@@ -787,7 +808,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
         const int qi = q0 + mq * 16 + (lane >> 4) * 4 + r;
         float x = s[r] * qk_scale;
         if (!plain) {
-          x = mask_score(x + (bias ? bvt[nj][r] : 0.f), qi, j, len, a.Tk, mmode);
+          x = mask_score(x + (bias ? bvt[nj][r] : 0.f), qi, j, len, a.Tk, mmode, a.window);
         }
         p[r] = (qi < a.Tq && x != -INFINITY) ? fast_exp(x - lse4[r]) : 0.f;
         const float mf = (!DROP || ((keep_bits >> (nj * 4 + r)) & 1u)) ? 1.f : 0.f;
@@ -907,9 +928,9 @@ int dispatch(const AttnArgs& a, int precision, bool bwd, hipStream_t s) {
   return bwd ? launch_bwd<HDP, 3>(a, s) : launch_fwd<HDP, 3>(a, s);
 }
 
-int check_common(int B, int H, int Tq, int Tk, int hd, int mode, int precision) {
+int check_common(int B, int H, int Tq, int Tk, int hd, int mode, int precision, int window = 0) {
   if (B < 0 || H <= 0 || Tq < 0 || Tk < 0 || hd <= 0) return VILCO_ERR_BADARG;
-  if (mode < 0 || mode > 3 || precision < 0 || precision > 3) return VILCO_ERR_BADARG;
+  if (mode < 0 || mode > 4 || precision < 0 || precision > 3 || (mode == 4 && (window < 0 || Tq != Tk))) return VILCO_ERR_BADARG;
   if (hd > 64 || (hd % 4) != 0) return VILCO_ERR_UNSUPPORTED;      // head dims 4..64 (P: 64, tests: 8, 16, 32)
   return VILCO_OK;
 }
@@ -1029,9 +1050,9 @@ extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int
 
 extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                               const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
-                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, float drop_p,
+                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                               uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = check_common(B, H, Tq, Tk, hd, mode, precision);
+  int rc = check_common(B, H, Tq, Tk, hd, mode, precision, window);
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
   if (!q || !k || !v || !o || !lse) return VILCO_ERR_BADARG;
@@ -1043,7 +1064,7 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.lse = lse; a.kv_len = kv_len;
-  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
+  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode; a.window = window;
   a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
   unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
   ScaleWs sw;
@@ -1074,9 +1095,9 @@ extern "C" size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int
 extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* bias,
                               const int32_t* kv_len, const float* o, const float* lse, const float* dout,
                               float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
-                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t precision, float drop_p,
+                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                               uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream) {
-  int rc = check_common(B, H, Tq, Tk, hd, mode, precision);
+  int rc = check_common(B, H, Tq, Tk, hd, mode, precision, window);
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
   if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv) return VILCO_ERR_BADARG;
@@ -1091,7 +1112,7 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   wsb += up((long)B * H * Tq * 4, 256);
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.lse = const_cast<float*>(lse); a.kv_len = kv_len;
-  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode;
+  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode; a.window = window;
   a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
   a.dout = dout; a.delta = delta; a.o_in = o; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
   ScaleWs sw;

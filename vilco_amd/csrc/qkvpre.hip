@@ -19,6 +19,7 @@
 //   params:  per channel, d gamma_j / d beta_j / d w_j accumulated over row chunks (no reductions: statistics are saved)
 //   dh:      dh = sum_j dwconv^T(dc_j) + dh from the other consumers, one pass
 // followed by the ordinary LayerNorm backward of LN1 (norm.hip).
+#include <cstdlib>
 #include "common.h"
 
 void vilco_reduce_rows(const float* ws, float* out0, float* out1, int nrows, int ncols, int split, hipStream_t s);
@@ -60,124 +61,157 @@ __device__ __forceinline__ void block_sums(float (&v)[N], float* red) {
   }
 }
 
-// NT threads per block (256, or 768 for wide rows: C = 2304 is then 3 channels per thread), thread i owns channels
-// i, i + NT, ...  A block takes SEG consecutive output tokens and works on ALL of them at once: the SEG*s + 2 input rows
-// are loaded up front (every load of the block in flight together), their LayerNorm statistics are TWO block reductions
-// for the whole batch of rows (not two per row), the 3*SEG conv rows two more.  Four barriers-with-reduction per
-// segment instead of four per token: the first version (one token at a time) ran at 1.4 TB/s, latency-bound.
-template <int CPT, int NT, int SEG, int S>
-__global__ __launch_bounds__(NT) void qkv_pre_fwd_kernel(QkvArgs a) {
-  constexpr int QT = NT, NW = NT / 64, NR = SEG * S + 2;        // input rows s*t0 - 1 .. s*t0 + SEG*S
-  __shared__ float red[NW * (3 * SEG > NR ? 3 * SEG : NR)];
-  const int b = blockIdx.y;
-  const int t0 = blockIdx.x * SEG;
-  const int C = a.C, T = a.T, tid = threadIdx.x;
+// Forward, third version.  ONE WAVE owns TB consecutive output tokens and all C channels of them; a lane owns 4
+// consecutive channels of every 256-channel chunk (16-byte accesses, 1 KB per wave instruction); no block barrier
+// anywhere, every reduction is a wavefront reduction.  Three passes over the S*TB + 2 input rows:
+//   0: LayerNorm statistics of the input rows            (x from HBM)
+//   1: h = LN1(x), the three convs, THEIR statistics     (x again: L2 / Infinity Cache; h written when asked for)
+//   2: h and the convs once more, normalise, write q,k,v (x again)
+// The conv outputs are recomputed instead of kept (9 FMAs per element against 3 x C floats of registers per token).
+// Statistics are shifted one-pass sums -- sum(v - k), sum((v - k)^2) with k = the row's first element, so the
+// subtraction in E[d^2] - E[d]^2 cancels nothing unless |mean - k| >> std, which a member of the row is not.
+// (Version 1 walked tokens sequentially with four block barriers each: 1.4 TB/s.  Version 2 batched the rows of a block
+// through registers: 1.3 TB/s at C = 2304 with spills, 2.7 TB/s at C = 1024.)
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float hsum(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
+
+template <int TB, int S>
+__global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
+  constexpr int NR = S * TB + 2;
+  const int lane = threadIdx.x & 63;
+  const int groups = (a.Tout + TB - 1) / TB;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (long)a.B * groups) return;                 // whole waves only: no barrier below
+  const int b = (int)(wid / groups), t0 = (int)(wid % groups) * TB;
+  const int C = a.C, T = a.T, NG = C >> 8;
   const float invC = 1.f / (float)C;
   const int len = a.len[b];
   const int r0 = S * t0 - 1;
+  const float* xb = a.x + (long)b * T * C + lane * 4;
 
-  // ---- LN1 of the NR input rows (rows outside [0, T) are the conv's zero padding)
-  float h[NR][CPT];
-  float sm[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const int t = r0 + r;
-    sm[r] = 0.f;
-    if (t >= 0 && t < T) {
-      const float* xr = a.x + ((long)b * T + t) * C;
-#pragma unroll
-      for (int k = 0; k < CPT; ++k) { h[r][k] = xr[tid + k * QT]; sm[r] += h[r][k]; }
-    } else {
-#pragma unroll
-      for (int k = 0; k < CPT; ++k) h[r][k] = 0.f;
-    }
-  }
-  block_sums<NR, NW>(sm, red);
-  float sq[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    sm[r] *= invC;
-    sq[r] = 0.f;
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) { h[r][k] -= sm[r]; sq[r] += h[r][k] * h[r][k]; }
-  }
-  block_sums<NR, NW>(sq, red);
+  // ---- pass 0: statistics of the input rows
+  float mu[NR], rs[NR];
   {
-    float g1[CPT], b1[CPT];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) { g1[k] = a.g1 ? a.g1[tid + k * QT] : 1.f; b1[k] = a.b1 ? a.b1[tid + k * QT] : 0.f; }
+    float k[NR], s1[NR], s2[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int t = r0 + r;
-      const bool in = t >= 0 && t < T;
-      const float rs = 1.0f / sqrtf(sq[r] * invC + a.eps1);
+      k[r] = (t >= 0 && t < T) ? a.x[((long)b * T + t) * C] : 0.f;
+      s1[r] = 0.f; s2[r] = 0.f;
+    }
+    for (int g = 0; g < NG; ++g) {
 #pragma unroll
-      for (int k = 0; k < CPT; ++k) h[r][k] = in ? h[r][k] * rs * g1[k] + b1[k] : 0.f;
-      // rows [S*t0, S*t0 + S*SEG) are OWNED by this block (the halo rows belong to the neighbours)
-      if (in && r >= 1 && r <= SEG * S) {
-        if (a.h) {
-          float* hr = a.h + ((long)b * T + t) * C;
-#pragma unroll
-          for (int k = 0; k < CPT; ++k) hr[tid + k * QT] = h[r][k];
-        }
-        if (tid == 0 && a.mean1) { a.mean1[(long)b * T + t] = sm[r]; a.rstd1[(long)b * T + t] = rs; }
+      for (int r = 0; r < NR; ++r) {
+        const int t = r0 + r;
+        if (t < 0 || t >= T) continue;
+        const float4 v = ldg4(xb + (long)t * C + g * 256);
+        const float d0 = v.x - k[r], d1 = v.y - k[r], d2 = v.z - k[r], d3 = v.w - k[r];
+        s1[r] += (d0 + d1) + (d2 + d3);
+        s2[r] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const float m = wave_sum(s1[r]) * invC, q = wave_sum(s2[r]) * invC;
+      mu[r] = k[r] + m;
+      rs[r] = 1.0f / sqrtf(fmaxf(q - m * m, 0.f) + a.eps1);
+      const int t = r0 + r;
+      if (lane == 0 && a.mean1 && r >= 1 && r <= S * TB && t < T) { a.mean1[(long)b * T + t] = mu[r]; a.rstd1[(long)b * T + t] = rs[r]; }
     }
   }
 
-  // ---- the three depthwise convs of the SEG output tokens, masked, then their LayerNorms
-  float c[3][SEG][CPT];
-  float cs[3 * SEG];
+  // h rows of chunk g (zero outside [0, T): the conv's padding)
+  auto load_h = [&](int g, float4 (&h)[NR]) {
+    const float4 g1 = a.g1 ? ldg4(a.g1 + g * 256 + lane * 4) : f4(1.f);
+    const float4 b1 = a.b1 ? ldg4(a.b1 + g * 256 + lane * 4) : f4(0.f);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    float w0[CPT], w1[CPT], w2[CPT];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-      const float* wp = a.w[j] + (tid + k * QT) * 3;
-      w0[k] = wp[0]; w1[k] = wp[1]; w2[k] = wp[2];
+    for (int r = 0; r < NR; ++r) {
+      const int t = r0 + r;
+      if (t < 0 || t >= T) { h[r] = f4(0.f); continue; }
+      const float4 v = ldg4(xb + (long)t * C + g * 256);
+      h[r].x = (v.x - mu[r]) * rs[r] * g1.x + b1.x; h[r].y = (v.y - mu[r]) * rs[r] * g1.y + b1.y;
+      h[r].z = (v.z - mu[r]) * rs[r] * g1.z + b1.z; h[r].w = (v.w - mu[r]) * rs[r] * g1.w + b1.w;
     }
+  };
+  // conv j of chunk g for the TB tokens: w[c][3] of 4 consecutive channels = 12 floats
+  auto conv = [&](int j, int g, const float4 (&h)[NR], float4 (&c)[TB]) {
+    const float* wp = a.w[j] + (g * 256 + lane * 4) * 3;
+    const float4 wa = ldg4(wp), wb = ldg4(wp + 4), wc = ldg4(wp + 8);       // x: a.x a.y a.z | y: a.w b.x b.y | z: b.z b.w c.x | w: c.y c.z c.w
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) {
+    for (int i = 0; i < TB; ++i) {
       const int t = t0 + i;
-      const bool valid = t < a.Tout && S * t < len;
-      float acc = 0.f;
+      if (!(t < a.Tout && S * t < len)) { c[i] = f4(0.f); continue; }
+      const float4 &p = h[S * i], &q = h[S * i + 1], &n = h[S * i + 2];
+      c[i].x = wa.x * p.x + wa.y * q.x + wa.z * n.x;
+      c[i].y = wa.w * p.y + wb.x * q.y + wb.y * n.y;
+      c[i].z = wb.z * p.z + wb.w * q.z + wc.x * n.z;
+      c[i].w = wc.y * p.w + wc.z * q.w + wc.w * n.w;
+    }
+  };
+
+  // ---- pass 1: h (stored when asked for), conv statistics
+  float cm[3][TB], cr[3][TB];
+  {
+    float k[3][TB], s1[3][TB], s2[3][TB];
 #pragma unroll
-      for (int k = 0; k < CPT; ++k) {
-        c[j][i][k] = valid ? w0[k] * h[S * i][k] + w1[k] * h[S * i + 1][k] + w2[k] * h[S * i + 2][k] : 0.f;
-        acc += c[j][i][k];
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < TB; ++i) { k[j][i] = 0.f; s1[j][i] = 0.f; s2[j][i] = 0.f; }
+    for (int g = 0; g < NG; ++g) {
+      float4 h[NR];
+      load_h(g, h);
+      if (a.h) {
+#pragma unroll
+        for (int r = 1; r <= S * TB; ++r) {
+          const int t = r0 + r;
+          if (t < T) *reinterpret_cast<float4*>(a.h + ((long)b * T + t) * C + g * 256 + lane * 4) = h[r];
+        }
       }
-      cs[j * SEG + i] = acc;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float4 c[TB];
+        conv(j, g, h, c);
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+          if (g == 0) k[j][i] = __shfl(c[i].x, 0, 64);
+          const float d0 = c[i].x - k[j][i], d1 = c[i].y - k[j][i], d2 = c[i].z - k[j][i], d3 = c[i].w - k[j][i];
+          s1[j][i] += (d0 + d1) + (d2 + d3);
+          s2[j][i] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < TB; ++i) {
+        const float m = wave_sum(s1[j][i]) * invC, q = wave_sum(s2[j][i]) * invC;
+        cm[j][i] = k[j][i] + m;
+        cr[j][i] = 1.0f / sqrtf(fmaxf(q - m * m, 0.f) + a.eps);
+        const int t = t0 + i;
+        if (lane == 0 && a.mean[j] && t < a.Tout) { a.mean[j][(long)b * a.Tout + t] = cm[j][i]; a.rstd[j][(long)b * a.Tout + t] = cr[j][i]; }
+      }
   }
-  block_sums<3 * SEG, NW>(cs, red);
-  float cq[3 * SEG];
+
+  // ---- pass 2: normalise and write
+  for (int g = 0; g < NG; ++g) {
+    float4 h[NR];
+    load_h(g, h);
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 3; ++j) {
+      float4 c[TB];
+      conv(j, g, h, c);
+      const float4 gm = a.gam[j] ? ldg4(a.gam[j] + g * 256 + lane * 4) : f4(1.f);
+      const float4 bt = a.bet[j] ? ldg4(a.bet[j] + g * 256 + lane * 4) : f4(0.f);
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-      const float mu = cs[j * SEG + i] * invC;
-      cs[j * SEG + i] = mu;
-      float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < CPT; ++k) { c[j][i][k] -= mu; acc += c[j][i][k] * c[j][i][k]; }
-      cq[j * SEG + i] = acc;
-    }
-  block_sums<3 * SEG, NW>(cq, red);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    float gam[CPT], bet[CPT];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) { gam[k] = a.gam[j] ? a.gam[j][tid + k * QT] : 1.f; bet[k] = a.bet[j] ? a.bet[j][tid + k * QT] : 0.f; }
-#pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-      const int t = t0 + i;
-      if (t >= a.Tout) continue;
-      const long row = (long)b * a.Tout + t;
-      const float rs = 1.0f / sqrtf(cq[j * SEG + i] * invC + a.eps);
-      float* yr = a.y[j] + row * C;
-#pragma unroll
-      for (int k = 0; k < CPT; ++k) yr[tid + k * QT] = c[j][i][k] * rs * gam[k] + bet[k];
-      if (tid == 0 && a.mean[j]) { a.mean[j][row] = cs[j * SEG + i]; a.rstd[j][row] = rs; }
+      for (int i = 0; i < TB; ++i) {
+        const int t = t0 + i;
+        if (t >= a.Tout) continue;
+        float4 o;
+        o.x = (c[i].x - cm[j][i]) * cr[j][i] * gm.x + bt.x; o.y = (c[i].y - cm[j][i]) * cr[j][i] * gm.y + bt.y;
+        o.z = (c[i].z - cm[j][i]) * cr[j][i] * gm.z + bt.z; o.w = (c[i].w - cm[j][i]) * cr[j][i] * gm.w + bt.w;
+        *reinterpret_cast<float4*>(a.y[j] + ((long)b * a.Tout + t) * C + g * 256 + lane * 4) = o;
+      }
     }
   }
 }
@@ -356,11 +390,9 @@ int param_blocks(long rows) {
 
 }  // namespace
 
-// widths the forward kernel has an instantiation for: multiples of 256 up to 1024, of 512 up to 2048, of 768 up to 3072
-extern "C" int vilco_qkv_pre_supported(int32_t C) {
-  if (C <= 0 || (C % 256) != 0 || C / 256 > 9) return 0;
-  return (C / 256 <= 4) || (C % 768 == 0 && C / 768 <= 4) || (C % 512 == 0 && C / 512 <= 4);
-}
+// row widths: multiples of 256 (a lane owns 4 consecutive channels of every 256-channel chunk) up to 2304 (the
+// backward row kernel keeps 9 channels per thread)
+extern "C" int vilco_qkv_pre_supported(int32_t C) { return C > 0 && (C % 256) == 0 && C / 256 <= 9; }
 
 // (channels per thread, threads per block) of a row width: 256 threads up to C = 1024, 768 threads for multiples of
 // 768 up to 3072 (C = 2304: 3 per thread), else 256 threads with up to 9 per thread (sequential-token kernels only)
@@ -390,46 +422,28 @@ extern "C" int vilco_qkv_pre_supported(int32_t C) {
     }                                                                                                               \
   } while (0)
 
-// forward: batch-of-rows kernel, (CPT, NT) in {1..4} x {256, 768}; SEG output tokens per block by register budget
-template <int CPT, int NT>
-void launch_fwd_seg(const QkvArgs& a, hipStream_t s) {
-  constexpr int SEG1 = CPT <= 2 ? 8 : 4, SEG2 = CPT <= 2 ? 4 : 2;       // stride 1 / stride 2 (twice the input rows)
-  if (a.stride == 1) {
-    const dim3 grid((a.Tout + SEG1 - 1) / SEG1, a.B);
-    hipLaunchKernelGGL((qkv_pre_fwd_kernel<CPT, NT, SEG1, 1>), grid, dim3(NT), 0, s, a);
-  } else {
-    const dim3 grid((a.Tout + SEG2 - 1) / SEG2, a.B);
-    hipLaunchKernelGGL((qkv_pre_fwd_kernel<CPT, NT, SEG2, 2>), grid, dim3(NT), 0, s, a);
-  }
+template <int TB, int S>
+void launch_fwd_tb(const QkvArgs& a, hipStream_t s) {
+  const long waves = (long)a.B * ((a.Tout + TB - 1) / TB);
+  hipLaunchKernelGGL((qkv_pre_fwd_kernel<TB, S>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
 }
 
+// tokens per wave: more tokens = fewer halo re-reads and parameter loads, fewer = more waves in flight and fewer
+// registers.  Measured at [8, 2304, 2304] (r02): TB = 1 / 2 / 4 -> 1.90 / 2.49 / 2.16 TB/s.  VILCO_QKV_TB overrides (tuning).
 bool launch_fwd(const QkvArgs& a, hipStream_t s) {
-  const int C = a.C;
-  if (C % 768 == 0 && C / 768 >= 2 && C / 768 <= 4) {
-    switch (C / 768) {
-      case 2: launch_fwd_seg<2, 768>(a, s); break;
-      case 3: launch_fwd_seg<3, 768>(a, s); break;
-      default: launch_fwd_seg<4, 768>(a, s); break;
-    }
-    return true;
+  if (a.C % 256 != 0) return false;
+  static const int forced = [] { const char* e = getenv("VILCO_QKV_TB"); return e ? atoi(e) : 0; }();
+  if (a.stride == 1) {
+    int tb = forced ? forced : 2;
+    if (tb >= 4) launch_fwd_tb<4, 1>(a, s);
+    else if (tb == 1) launch_fwd_tb<1, 1>(a, s);
+    else launch_fwd_tb<2, 1>(a, s);
+  } else {
+    int tb = forced ? forced : 2;
+    if (tb >= 2) launch_fwd_tb<2, 2>(a, s);
+    else launch_fwd_tb<1, 2>(a, s);
   }
-  if (C % 256 == 0 && C / 256 <= 4) {
-    switch (C / 256) {
-      case 1: launch_fwd_seg<1, 256>(a, s); break;
-      case 2: launch_fwd_seg<2, 256>(a, s); break;
-      case 3: launch_fwd_seg<3, 256>(a, s); break;
-      default: launch_fwd_seg<4, 256>(a, s); break;
-    }
-    return true;
-  }
-  if (C % 512 == 0 && C / 512 <= 4) {      // 1280 is not, 1536 / 2048 are: 512 threads
-    switch (C / 512) {
-      case 3: launch_fwd_seg<3, 512>(a, s); break;
-      default: launch_fwd_seg<4, 512>(a, s); break;
-    }
-    return true;
-  }
-  return false;
+  return true;
 }
 
 extern "C" int vilco_qkv_pre_fwd(const float* x, const float* ln1_g, const float* ln1_b, const float* const* w,

@@ -656,6 +656,7 @@ def mask_rows_(x, lens):
 # ---------------------------------------------------------------------------------------- attention
 MASK_KEYS, MASK_XLNET, MASK_NONE = 0, 1, 2
 MASK_XLNET_REL = 3      # XLNet mask + bias given as UNSHIFTED position scores [B,H,Tq,Tq+Tk] (attn.hip: bias_at)
+MASK_LOCAL = 4          # sliding window |i - j| <= window below kv_len (NLQ LocalMaskedMHCA)
 use_flash = True     # fused attention kernels when the head dim is supported; False = materialised scores
 
 
@@ -716,7 +717,7 @@ def flash_supported(hd):
     return bool(_lib.load().vilco_attn_supported(int(hd)))
 
 
-def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode, drop=(0.0, 0)):
+def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode, drop=(0.0, 0), window=0):
     lib = _lib.load()
     B, Tq, Cn = q.shape
     Tk = k.shape[1]
@@ -725,12 +726,12 @@ def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode, drop=(0.0, 0)):
     nws = lib.vilco_attn_fwd_workspace(B, H, Tq, Tk, Cn // H, _precision)
     ws = _ws(nws, q.device)
     _lib.check(lib.vilco_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
-                                  lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, _precision, float(drop[0]),
+                                  lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
                                   int(drop[1]), ws.data_ptr(), nws, _stream()))
     return o, lse
 
 
-def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, drop=(0.0, 0)):
+def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, drop=(0.0, 0), window=0):
     lib = _lib.load()
     B, Tq, Cn = q.shape
     Tk = k.shape[1]
@@ -740,7 +741,7 @@ def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, dr
     ws = _ws(nws, q.device)
     _lib.check(lib.vilco_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
                                   lse.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                  _p(dbias), B, H, Tq, Tk, Cn // H, scale, mode, _precision, float(drop[0]),
+                                  _p(dbias), B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
                                   int(drop[1]), ws.data_ptr(), nws, _stream()))
     return dq, dk, dv, dbias
 
@@ -750,11 +751,11 @@ class _FlashAttention(torch.autograd.Function):
     from (q, k, lse)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, kv_len, H, scale, mode, drop_p=0.0):
+    def forward(ctx, q, k, v, kv_len, H, scale, mode, drop_p=0.0, window=0):
         _chk(q, k, v)
         ctx.drop = _new_drop("attn_prob", drop_p, (q.shape[0], H, q.shape[1], k.shape[1]))
-        o, lse = _flash_fwd(q, k, v, None, kv_len, H, scale, mode, ctx.drop)
-        ctx.H, ctx.scale, ctx.mode = H, scale, mode
+        o, lse = _flash_fwd(q, k, v, None, kv_len, H, scale, mode, ctx.drop, window)
+        ctx.H, ctx.scale, ctx.mode, ctx.window = H, scale, mode, window
         ctx.save_for_backward(q, k, v, kv_len, o, lse)
         return o
 
@@ -762,16 +763,19 @@ class _FlashAttention(torch.autograd.Function):
     def backward(ctx, do):
         q, k, v, kv_len, o, lse = ctx.saved_tensors
         dq, dk, dv, _ = _flash_bwd(q, k, v, None, kv_len, o, lse, do.contiguous(), ctx.H, ctx.scale, ctx.mode, False,
-                                   ctx.drop)
-        return dq, dk, dv, None, None, None, None, None
+                                   ctx.drop, ctx.window)
+        return dq, dk, dv, None, None, None, None, None, None
 
 
-def attention(q, k, v, kv_len, n_head, scale=None, mode=MASK_KEYS, drop_p=0.0):
-    """drop_p: dropout on the attention probabilities (training only; the caller passes 0 in eval)."""
+def attention(q, k, v, kv_len, n_head, scale=None, mode=MASK_KEYS, drop_p=0.0, window=0):
+    """drop_p: dropout on the attention probabilities (training only; the caller passes 0 in eval).
+    mode MASK_LOCAL: sliding-window self-attention, keys |i - j| <= window (fused kernels only)."""
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1] // n_head)
     if use_flash and flash_supported(q.shape[-1] // n_head):
-        return _FlashAttention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode), float(drop_p))
+        return _FlashAttention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode), float(drop_p), int(window))
+    if mode == MASK_LOCAL:
+        raise NotImplementedError("local-window attention needs the fused kernels (head dim <= 64, multiple of 4)")
     if drop_p > 0.0:
         raise NotImplementedError("attention dropout needs the fused kernels (head dim <= 64, multiple of 4)")
     return _Attention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode))
