@@ -235,6 +235,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="clips per GPU (mq_vilco.yaml: 2)")
     ap.add_argument("--precision", default="f16x2", choices=["split3", "split", "bf16", "f16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-targets", action="store_true", help="skip the target-kernel micro-benchmarks and the W / cfg1 side lines")
     ap.add_argument("--extra-batch", type=int, default=8,
                     help="also time a few steps at this many clips per GPU (reported beside the headline; 0 = skip)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -352,6 +353,51 @@ def main():
         dist.destroy_process_group()
 
 
+def side_config(name, dev, steps=3, warm=2):
+    """fwd+bwd clips/s of another BASELINE / SURVEY 8d configuration, a few steps only (side line, not the headline):
+    "W" = config P with D = 2304 (hd = 144, no XLNet layer; 9874 GFLOP/clip), "cfg1" = BASELINE configs[0] (T = 256,
+    Cin = 512, D = 512, H = 4, XLNet layer, 53.4 GFLOP/clip).  Head dims above 64 run the materialised-score attention."""
+    import vilco_amd.modeling as vm
+    from vilco_amd.core.config import make_config
+    if name == "W":
+        over = dict(dataset=dict(input_dim=2304, num_classes=22, max_seq_len=2304),
+                    model=dict(embd_dim=2304, fpn_dim=2304, head_dim=2304, n_head=16, backbone_arch=(2, 2, 5), use_abs_pe=True,
+                               use_cross_modal=True, n_txt_in=768, max_buffer_len_factor=1.0, use_xl=False),
+                    train_cfg=dict(init_loss_norm=100, dropout=0.0, droppath=0.1))
+        T, Cin, gflop, xl = 2304, 2304, 9874.0, None
+    else:
+        over = dict(dataset=dict(input_dim=512, num_classes=22, max_seq_len=256),
+                    model=dict(embd_dim=512, fpn_dim=512, head_dim=512, n_head=4, backbone_arch=(2, 2, 5), use_abs_pe=True,
+                               use_cross_modal=True, n_txt_in=768, max_buffer_len_factor=1.0, use_xl=True),
+                    train_cfg=dict(init_loss_norm=100, dropout=0.0, droppath=0.1))
+        T, Cin, gflop = 256, 512, 53.4
+        xl = dict(P_XLNET, d_model=512, n_head=4, d_head=128, d_inner=1024, dropout=0.0)
+    cfg = make_config(**over)['model']
+    torch.manual_seed(0)
+    kw = dict(cfg, xlnet_config=xl) if xl is not None else dict(cfg)
+    model = vm.make_meta_arch('LocPointTransformer', **kw).to(dev).train()
+    batch = synth_batch(2, dev, seed=0, T=T, Cin=Cin)
+    if T < 2304:      # the synthetic segments of synth_batch end at 130.25 < 256: fine
+        pass
+
+    def one():
+        model.zero_grad(set_to_none=True)
+        model(batch, is_training=True)['final_loss'].backward()
+    for _ in range(warm):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del model
+    torch.cuda.empty_cache()
+    return {"config": name, "clips_per_gpu": 2, "ms_per_step": dt * 1e3, "clips_per_s": 2 / dt, "gflop_per_clip_fwd_bwd": gflop,
+            "model_mfma_frac": 2 / dt * gflop / 1e3 / PEAK_BF16_TFLOPS, "steps": steps,
+            "note": "dropout 0 (droppath 0.1), %d timed steps after %d warm-up: a side line, not the headline workload" % (steps, warm)}
+
+
 def local_sections(out, args, model, step, dev, ms, world):
     """rank-0-only measurements after the timed region: GEMM roofline, optimizer step, larger batch, CPU baseline"""
     gp = gemm_profile(step)
@@ -402,6 +448,26 @@ def local_sections(out, args, model, step, dev, ms, world):
         dtb = (time.perf_counter() - t1) / 5
         out["larger_batch"] = {"clips_per_gpu": args.extra_batch, "ms_per_step": dtb * 1e3,
                                "clips_per_s": args.extra_batch / dtb}
+    if world == 1 and not args.no_targets:
+        # the two kernels the north star sets explicit targets on, and the other SURVEY 8d configurations
+        del model
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_targets
+        try:
+            out["targets"] = {
+                "qkv_pre_projection": {"target": ">= 60 % of 8 TB/s HBM on the fused LN -> depthwise conv x3 -> LN x3 at T = C = 2304",
+                                       "measured": [bench_targets.qkv_pre_target(dev, 2), bench_targets.qkv_pre_target(dev, 8)]},
+                "cross_attention": {"target": ">= 40 % MFMA utilisation on the cross-attention block (T' = 1152, L = 77, D = 1024)",
+                                    "measured": [bench_targets.cross_attn_target(dev, 2), bench_targets.cross_attn_target(dev, 8)]}}
+        except Exception as e:      # a side measurement must not take the headline line down
+            out["targets"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["side_configs"] = []
+        for name in ("cfg1", "W"):
+            try:
+                out["side_configs"].append(side_config(name, dev))
+            except Exception as e:
+                out["side_configs"].append({"config": name, "error": "%s: %s" % (type(e).__name__, e)})
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
 

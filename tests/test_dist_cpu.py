@@ -88,3 +88,53 @@ def test_bench_protocol_two_ranks():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["dryrun"] is True
+
+
+class _FakeDetector(torch.nn.Module):
+    """stands in for the model in the evaluator-format plumbing: deterministic segments per video id"""
+    use_adapt = False
+
+    def forward(self, video_list, task_id=0, is_training=False):
+        out = []
+        for v in video_list:
+            key = sum((i + 1) * ord(c) for i, c in enumerate(v['video_id']))          # (str hashes differ between processes)
+            n = 1 + key % 3
+            g = torch.Generator().manual_seed(key)
+            seg = torch.rand(n, 2, generator=g).sort(dim=1)[0]
+            out.append({'video_id': v['video_id'], 'segments': seg, 'scores': torch.rand(n, generator=g),
+                        'labels': torch.randint(0, 5, (n,), generator=g)})
+        return out
+
+
+def _val_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vilco_amd.utils.train_utils import collect_results_sharded
+    batches = [[{'video_id': 'vid%02d' % i}] for i in range(7)]
+    res = collect_results_sharded(batches, _FakeDetector(), rank=rank, world=world)
+    q.put((rank, res['video-id'], res['t-start'].tolist(), res['label'].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_validation_equals_single_rank():
+    """evaluator-format results gathered from two ranks = the single-rank pass (as a multiset of rows)"""
+    from vilco_amd.utils.train_utils import collect_results, results_to_anet_json
+    batches = [[{'video_id': 'vid%02d' % i}] for i in range(7)]
+    single = collect_results(batches, _FakeDetector())
+    assert sorted(single) == ['label', 'score', 't-end', 't-start', 'video-id'] and len(single['video-id']) == len(single['score'])
+    js = results_to_anet_json(single)
+    assert sorted(js) == ['external_data', 'results', 'version'] and set(js['results']) == set(single['video-id'])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 13) % 2000)
+    procs = [ctx.Process(target=_val_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = sorted(zip(single['video-id'], single['t-start'].tolist(), single['label'].tolist()))
+    for rank, vids, starts, labels in got:
+        assert sorted(zip(vids, starts, labels)) == want

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of environment toggles on ONE box: tools/ab_bench.sh "VAR=a" "VAR=b" ...   (each argument = env assignments for one run)
 for cfg in "$@"; do
-  out=$(env $cfg python bench.py --no-cpu-baseline --extra-batch 0 2>/dev/null)
+  out=$(env $cfg python bench.py --no-cpu-baseline --no-targets --extra-batch 0 2>/dev/null)
   echo "$out" | python -c "
 import json,sys
 d=json.load(sys.stdin); r=d['roofline']

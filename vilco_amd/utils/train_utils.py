@@ -312,3 +312,28 @@ def results_to_anet_json(results, version="vilco_amd"):
                                 results['score']):
         out.setdefault(vid, []).append({"label": int(l), "score": float(sc), "segment": [float(s), float(e)]})
     return {"version": version, "results": out, "external_data": {}}
+
+
+def merge_results(parts):
+    """concatenate evaluator-format result dicts (the output of collect_results) in the given order"""
+    out = {'video-id': [], 't-start': [], 't-end': [], 'label': [], 'score': []}
+    for p in parts:
+        out['video-id'].extend(p['video-id'])
+    for k in ('t-start', 't-end', 'label', 'score'):
+        out[k] = np.concatenate([np.asarray(p[k]) for p in parts]) if parts else np.zeros(0)
+    return out
+
+
+def collect_results_sharded(val_batches, model, task_id=0, rank=0, world=1, group=None):
+    """Validation sharded over data-parallel ranks (the reference validates on rank 0 only, train_cl.py:283): rank r
+    runs batches r, r + world, ... through `collect_results`, the per-rank result dicts travel once
+    (all_gather_object) and every rank returns the merged dict in rank order -- the same rows a single-rank pass
+    produces, up to that order (the evaluator groups by video id)."""
+    val_batches = list(val_batches)
+    mine = collect_results(val_batches[rank::world], model, task_id=task_id)
+    if world == 1:
+        return mine
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    return merge_results(parts)
