@@ -331,7 +331,9 @@ def main():
                "dtype": {"split3": "bf16 MFMA x3-part split, fp32 accumulate (fp32-equivalent)",
                          "split": "bf16 MFMA x2-part split, fp32 accumulate", "bf16": "bf16",
                          "f16x2": "fp16 MFMA on 2-part splits of power-of-two scaled fp32 operands (22 significant bits, "
-                                  "3 MFMAs per product), fp32 accumulate: fp32-equivalent"}[args.precision],
+                                  "3 MFMAs per product), fp32 accumulate: fp32-equivalent; weight-gradient products with "
+                                  "contraction length >= 2048 use the leading fp16 parts only (11-bit operands, 1 MFMA; "
+                                  "<= 3.5e-4 of the 3-MFMA gradients at this config, tests/test_fullsize_gpu.py)"}[args.precision],
                "data": "synthetic",
                "config": {"workload": "MQ ViLCo backbone config P: T=2304 Cin=2304 D=1024 H=16 arch(2,2,5) XLNet layer "
                                       "text L=77x768 22 classes, train mode with the reference's dropout 0.1 / droppath 0.1 "

@@ -51,7 +51,10 @@ int vilco_sync_timeouts_read(void);
 /* bf16 MFMA (v_mfma_f32_16x16x32_bf16) with fp32 accumulate; precision 0 = split-bf16 (hi+lo, */
 /* 3 MFMAs, ~2^-17 relative), 1 = single bf16 pass, 2 = three-part split (6 MFMAs, ~2^-25:    */
 /* numerically an fp32 GEMM), 3 = two fp16 parts of operands scaled by a per-tensor power of   */
-/* two (v_mfma_f32_16x16x32_f16, 3 MFMAs, ~2^-22; the default).                                */
+/* two (v_mfma_f32_16x16x32_f16, 3 MFMAs, ~2^-22; the default); 4 = the same fp16 x2 planes, but the  */
+/* product takes their leading parts only (1 MFMA, 11-bit operands, fp32 accumulate): for the weight-  */
+/* gradient products dW = dY^T X, whose rounding errors average over the B*T contraction and feed   */
+/* nothing downstream (ops.py: dw_precision).                                                        */
 /* ------------------------------------------------------------------------------------------ */
 enum { VILCO_ACT_NONE = 0, VILCO_ACT_RELU = 1, VILCO_ACT_GELU = 2 };
 enum { VILCO_TAP_NONE = 0, VILCO_TAP_A = 1, VILCO_TAP_B = 2 };

@@ -503,7 +503,7 @@ struct Plan {
 };
 
 void make_plan(const vilco_gemm_desc* d, Plan& p) {
-  p.NP = d->precision == 1 ? 1 : ((d->precision == 0 || d->precision == 3) ? 2 : 3);
+  p.NP = d->precision == 1 ? 1 : ((d->precision == 0 || d->precision == 3 || d->precision == 4) ? 2 : 3);
   p.Kp = (int)align_up(d->K > 0 ? d->K : 1, 32);
   p.a_tr = !d->a_kcontig;
   p.b_tr = !d->b_kcontig;
@@ -560,7 +560,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
     const long c128 = ((tiles128 + 255) / 256) * 128, c192 = ((tiles192 + 255) / 256) * 192, c256 = ((tiles256 + 255) / 256) * 256;
     p.BM = 256;
     long best = c256;
-    if (d->precision == 3 && c192 < best) { p.BM = 192; best = c192; }
+    if ((d->precision == 3 || d->precision == 4) && c192 < best) { p.BM = 192; best = c192; }
     if (c128 < best) { p.BM = 128; best = c128; }
   }
   const long tiles = p.BM == 256 ? tiles256 : (p.BM == 192 ? tiles192 : tiles128);
@@ -578,7 +578,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
     if (ks < 1) ks = 1;
   }
   // tuning overrides (tools/gemm_tune.py): VILCO_GEMM_BM = 128|256, VILCO_GEMM_KS = forced split count
-  if (const char* e = getenv("VILCO_GEMM_BM")) { const int v = atoi(e); if (v == 128 || v == 256 || (v == 192 && d->precision == 3)) p.BM = v; }
+  if (const char* e = getenv("VILCO_GEMM_BM")) { const int v = atoi(e); if (v == 128 || v == 256 || (v == 192 && d->precision >= 3)) p.BM = v; }
   if (const char* e = getenv("VILCO_GEMM_KS")) { const int v = atoi(e); if (v >= 1 && v <= nk) ks = v; }
   p.kchunk = (nk + ks - 1) / ks;
   p.ksplit = (nk + p.kchunk - 1) / p.kchunk;
@@ -731,7 +731,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   }
   if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch_outer < 1 || d->batch_inner < 1) return VILCO_ERR_BADARG;
   if (d->M == 0 || d->N == 0) return VILCO_OK;
-  if (d->precision < 0 || d->precision > 3) return VILCO_ERR_BADARG;
+  if (d->precision < 0 || d->precision > 4) return VILCO_ERR_BADARG;
   if (d->act < 0 || d->act > 2) return VILCO_ERR_BADARG;
   if (d->band < 0 || d->band > 3 || (d->band && d->bandT <= 0)) return VILCO_ERR_BADARG;
   if (!(d->drop_p >= 0.f) || d->drop_p >= 1.f) return VILCO_ERR_BADARG;
@@ -761,7 +761,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   __bf16* planesA = reinterpret_cast<__bf16*>(ws);
   __bf16* planesB = reinterpret_cast<__bf16*>(ws + p.a_bytes);
   float* parts = reinterpret_cast<float*>(ws + p.a_bytes + p.b_bytes);
-  const bool f16 = d->precision == 3;
+  const bool f16 = d->precision == 3 || d->precision == 4;      // 4: fp16 x2 planes, the product uses their first parts only
 
   // ---- pack A and B into bf16 planes
   PackArgs pa;
@@ -849,7 +849,11 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
   {
     const bool ak = p.a_km, bk = p.b_km;
-    if (f16) {
+    if (d->precision == 4) {          // one MFMA per product on the leading fp16 parts (plane strides unchanged)
+      if (p.BM == 256) launch_pp<256, 1, true>(g, grid, s, ak, bk);
+      else if (p.BM == 192) launch_pp<192, 1, true>(g, grid, s, ak, bk);
+      else launch_pp<128, 1, true>(g, grid, s, ak, bk);
+    } else if (f16) {
       if (p.BM == 256) launch_pp<256, 2, true>(g, grid, s, ak, bk);
       else if (p.BM == 192) launch_pp<192, 2, true>(g, grid, s, ak, bk);
       else launch_pp<128, 2, true>(g, grid, s, ak, bk);

@@ -22,6 +22,24 @@ DEFAULT_PRECISION = _PRECISIONS[os.environ.get("VILCO_PRECISION", "f16x2")]
 _precision = DEFAULT_PRECISION
 
 
+# Weight-gradient products dW = dZ^T X (one third of the GEMM flops).  Their operands are already packed as fp16 x2
+# planes for the forward / dX products; "f16x1" multiplies only the leading parts (1 MFMA instead of 3).  Unlike the
+# forward (where a LayerNorm -> ReLU pre-activation within 1e-5 of zero flips its derivative below ~20 operand bits)
+# and the dX chain (whose errors travel on through every earlier layer), a dW error is a zero-mean 2^-11 rounding per
+# product and ends in that one gradient tensor; relative to the tensor's largest entries (the parity metric) it shrinks
+# with the contraction length K = B*T: measured 5e-4 .. 1e-3 at K = 128 (the golden size: too close to the 1e-3 bar),
+# 2e-4 .. 3.5e-4 at K = 4608 (config P, tests/test_fullsize_gpu.py).  So it is used for LONG contractions only (K >= DW_FAST_MIN_K), where
+# the time is; short ones keep three MFMAs.  VILCO_DW_PRECISION=f16x2 restores three MFMAs everywhere.
+_DW = {"f16x1": 4, "f16x2": None}
+dw_precision = _DW[os.environ.get("VILCO_DW_PRECISION", "f16x1")]
+DW_FAST_MIN_K = 2048
+
+
+def _dw_prec(prec, K=0):
+    """precision code of a weight-gradient product with contraction length K whose planes were packed in `prec`"""
+    return dw_precision if (dw_precision is not None and prec == 3 and K >= DW_FAST_MIN_K) else prec
+
+
 def set_precision(p=None):
     """'split' / 0: two-part split-bf16 MFMA (~2^-17);  'bf16' / 1: single bf16 pass;
     'split3' / 'fp32' / 2: three-part bf16 split, numerically an fp32 GEMM (~2^-25);
@@ -295,7 +313,7 @@ class _Linear(torch.autograd.Function):
             gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=prec, a_planes=pz, b_planes=pw)   # dX = dZ W     (NN)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=prec, a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
+            gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(prec, M), a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -348,7 +366,7 @@ class _LinearKN(torch.autograd.Function):
             gemm(dy, w, dx, M, K, N, 1, 1, N, N, K, precision=prec, a_planes=pz, b_planes=pw)   # dX = dY W^T   (NT)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            gemm(x, dy, dw, K, N, M, 0, 0, K, N, N, precision=prec, a_planes=px, b_planes=pz)   # dW = X^T dY   (TN)
+            gemm(x, dy, dw, K, N, M, 0, 0, K, N, N, precision=_dw_prec(prec, M), a_planes=px, b_planes=pz)   # dW = X^T dY   (TN)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy.view(M, N)).view(ctx.bshape)
         return dx, dw, db
@@ -414,7 +432,7 @@ class _Conv3(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dwp = torch.empty(Cout, 3 * Cin, dtype=torch.float32, device=x.device)
             gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
-                 tapT=T)
+                 tapT=T, precision=_dw_prec(_precision, B * T))
             dw = permute3(dwp, (Cout, Cin, 3), 0, (3 * Cin, 1, Cin))
         return dx, dw, db, None
 
