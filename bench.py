@@ -179,9 +179,15 @@ def gemm_profile(step_fn, n=3):
         recs.append((e0, e1, flop))
         return out
 
+    mfma_flops = [0.0]          # MFMA work actually issued: x3 (fp16 x2 planes), x1 for the single-part weight-gradient products
+
     def gemm(A, B, Cc, M, N, K, *a, **k):
         batch = k.get("batch", (1, 1))
-        return timed(lambda: real_gemm(A, B, Cc, M, N, K, *a, **k), 2.0 * M * N * K * batch[0] * batch[1])
+        fl = 2.0 * M * N * K * batch[0] * batch[1]
+        prec = k.get("precision")
+        prec = ops.get_precision() if prec is None else prec
+        mfma_flops[0] += fl * {0: 3, 1: 1, 2: 6, 3: 3, 4: 1}[prec]
+        return timed(lambda: real_gemm(A, B, Cc, M, N, K, *a, **k), fl)
 
     def pack(*a, **k):
         return timed(lambda: real_pack(*a, **k), 0.0)
@@ -200,18 +206,21 @@ def gemm_profile(step_fn, n=3):
     launches = int(cnt.value)
     return {"avg_launch_us": ms.value * 1e3 / launches, "tflops": flops / (ms.value * 1e-3) / 1e12,
             "launches_per_step": launches // n, "kernel_ms_per_step": ms.value / n,
-            "gflop_per_launch": flops / launches / 1e9,
+            "gflop_per_launch": flops / launches / 1e9, "mfma_tflops": mfma_flops[0] / (ms.value * 1e-3) / 1e12,
+            "mfma_per_product_avg": mfma_flops[0] / flops,
             "call_ms_per_step": call_ms / n, "call_tflops": flops / (call_ms * 1e-3) / 1e12}
 
 
 def pmc_traffic():
     """HBM bytes per GEMM-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950
     note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); None when the summary is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        return json.load(open(path))["gemm_pp_kernel"]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # newest committed summary
+        try:
+            return json.load(open(os.path.join(prof, name)))["gemm_pp_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
 def dryrun_parts(dev, rank):
@@ -410,8 +419,8 @@ def local_sections(out, args, model, step, dev, ms, world):
                        "launches_per_step": gp["launches_per_step"],
                        "kernel_ms_per_step": gp["kernel_ms_per_step"],
                        "algorithmic_gflop_per_launch": gp["gflop_per_launch"],
-                       "mfma_per_algorithmic_product": mfma_per_product,
-                       "mfma_issue_frac": gp["tflops"] * mfma_per_product / PEAK_BF16_TFLOPS,
+                       "mfma_per_algorithmic_product": gp["mfma_per_product_avg"],
+                       "mfma_issue_frac": gp["mfma_tflops"] / PEAK_BF16_TFLOPS,
                        "gemm_calls_ms_per_step_incl_pack_and_reduce": gp["call_ms_per_step"],
                        "gemm_calls_tflops_incl_pack_and_reduce": gp["call_tflops"]}
     # the optimizer step is reported separately (BASELINE.json metric = fwd+bwd): fused clip-norm + AdamW

@@ -1,8 +1,10 @@
-"""gpurun_out/r01_z_* -> profiles/ (bench line, kernel stats, PMC traffic summary) and a printed recap."""
-import json, csv, shutil, os
+"""gpurun_out/<TAG>_* -> profiles/ (bench line, kernel stats, PMC traffic summary) and a printed recap.  TAG from argv[1] (default r02_z)."""
+import json, csv, shutil, os, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02_z"
+RND = TAG.split("_")[0]
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 g = lambda f: os.path.join(R, 'gpurun_out', f)
-f = json.load(open(g('r01_z_pmc_fetch.json'))); w = json.load(open(g('r01_z_pmc_write.json')))
+f = json.load(open(g(TAG + '_pmc_fetch.json'))); w = json.load(open(g(TAG + '_pmc_write.json')))
 def agg(rows, key):
     tot = n = 0
     for r in rows:
@@ -11,20 +13,20 @@ def agg(rows, key):
     return tot, n
 ft, fn = agg(f, 'FETCH_SIZE'); wt, wn = agg(w, 'WRITE_SIZE')
 per = 2 * ft * 1024 / fn + wt * 1024 / wn
-rows = list(csv.DictReader(open(g('r01_z_bench_kernel_stats.csv'))))
+rows = list(csv.DictReader(open(g(TAG + '_bench_kernel_stats.csv'))))
 gg = [r for r in rows if 'gemm_pp_kernel' in r['Name']]
 tot = sum(float(r['TotalDurationNs']) for r in gg); calls = sum(int(r['Calls']) for r in gg)
 out = {"gemm_pp_kernel": {"launches_fetch_pass": fn, "launches_write_pass": wn, "FETCH_SIZE_KB_sum": ft, "WRITE_SIZE_KB_sum": wt,
        "hbm_bytes_per_launch": per, "rocprof_avg_launch_us": tot / calls / 1e3, "rocprof_launches": calls,
-       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --no-cpu-baseline --extra-batch 0 "
+       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --no-cpu-baseline --no-targets --extra-batch 0 "
                "--steps 2 --warmup 1`; FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section), "
                "units KB; summed over all gemm_pp_kernel instantiations; rocprof_avg from `rocprofv3 --kernel-trace --stats -- python3 "
-               "bench.py --no-cpu-baseline --extra-batch 0`"}}
-json.dump(out, open(os.path.join(R, 'profiles', 'r01_pmc_traffic.json'), 'w'), indent=1)
+               "bench.py --no-cpu-baseline --no-targets --extra-batch 0`"}}
+json.dump(out, open(os.path.join(R, 'profiles', RND + '_pmc_traffic.json'), 'w'), indent=1)
 for n in ('bench_kernel_stats.csv', 'pmc_fetch.json', 'pmc_write.json'):
-    shutil.copy(g('r01_z_' + n), os.path.join(R, 'profiles', 'r01_z_' + n))
-d = json.loads(open(g('r01_z_bench.json')).read().strip().split('\n')[-1])
+    shutil.copy(g(TAG + '_' + n), os.path.join(R, 'profiles', TAG + '_' + n))
+d = json.loads(open(g(TAG + '_bench.json')).read().strip().split('\n')[-1])
 d['roofline']['traffic'] = per            # the PMC passes of THIS bundle (bench.py read the previous summary)
-open(os.path.join(R, 'profiles', 'r01_z_bench.json'), 'w').write(json.dumps(d) + '\n')
+open(os.path.join(R, 'profiles', TAG + '_bench.json'), 'w').write(json.dumps(d) + '\n')
 print(json.dumps({k: d[k] for k in ('value', 'ms_per_step', 'roofline', 'cpu_baseline', 'optimizer_step', 'larger_batch')}, indent=1))
 print('HBM MB/launch %.1f  rocprof avg us %.1f over %d launches (%.1f steps)' % (per / 1e6, tot / calls / 1e3, calls, calls / d['roofline']['launches_per_step']))

@@ -1,12 +1,13 @@
-# round-end measurement: bench line (with cpu_baseline), rocprofv3 kernel stats of the same command, PMC traffic passes
-R=$PWD; TAG=${TAG:-r01_z}
+# round-end measurement bundle: bench line (with cpu_baseline, targets, side configs), rocprofv3 kernel stats of the SAME
+# workload (bench.py --no-cpu-baseline --no-targets --extra-batch 0), PMC traffic passes (FETCH_SIZE / WRITE_SIZE separately)
+R=$PWD; TAG=${TAG:-r02_z}
 if [ -z "$SKIP_BENCH" ]; then python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -1 gpurun_out/${TAG}_bench.json | cut -c1-300; fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ps /tmp/pf /tmp/pw
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -o s -- python3 $R/bench.py --no-cpu-baseline --extra-batch 0 > $R/gpurun_out/${TAG}_prof_bench.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -o s -- python3 $R/bench.py --no-cpu-baseline --no-targets --extra-batch 0 > $R/gpurun_out/${TAG}_prof_bench.json 2> /dev/null
 cp /tmp/ps/s_kernel_stats.csv $R/gpurun_out/${TAG}_bench_kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python3 $R/bench.py --no-cpu-baseline --extra-batch 0 --steps 2 --warmup 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --no-cpu-baseline --extra-batch 0 --steps 2 --warmup 1 > /dev/null 2>&1
+VILCO_BENCH_SETTLE_S=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python3 $R/bench.py --no-cpu-baseline --no-targets --extra-batch 0 --steps 2 --warmup 1 > /dev/null 2>&1
+VILCO_BENCH_SETTLE_S=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --no-cpu-baseline --no-targets --extra-batch 0 --steps 2 --warmup 1 > /dev/null 2>&1
 python3 $R/tools/pmc_summary.py /tmp/pf/f_counter_collection.csv $R/gpurun_out/${TAG}_pmc_fetch.json > /dev/null
 python3 $R/tools/pmc_summary.py /tmp/pw/w_counter_collection.csv $R/gpurun_out/${TAG}_pmc_write.json > /dev/null
 ls -la $R/gpurun_out | grep ${TAG}
