@@ -149,4 +149,4 @@ def test_single_part_weight_gradients_at_full_size(dev):
     assert l1 == l2
     errs = sorted((((g1[k] - g2[k]).abs().max() / g2[k].abs().max().clamp_min(1e-7)).item(), k) for k in g1)
     assert errs[-1][0] < 5e-4, errs[-5:]          # measured: 3.5e-4 worst (branch.0 key.weight), 2e-4 typical
-    assert sum(1 for e, _ in errs if e > 0) > 50          # the fast mode is actually in use
+    assert sum(1 for e, _ in errs if e > 0) > 30          # the fast mode is actually in use (48 weight tensors at P)

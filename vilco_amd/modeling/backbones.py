@@ -14,6 +14,17 @@ from .modeling_xlnet_x import XLNetConfig, XLNetModel
 from .models import register_backbone
 
 
+_TEXT_STREAM = os.environ.get("VILCO_TEXT_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _text_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def _find_xlnet_config(n_embd):
     """the reference opens 'configs/xlnet_config_<D>.json' relative to CWD (backbones.py:132);
     VILCO_XLNET_CONFIG_DIR may point elsewhere.  None when no file exists for this width."""
@@ -113,16 +124,30 @@ class ConvTransformerBackbone(nn.Module):
                 pe = pe[0].t().contiguous()
             x = ops.add_pe(x, pe.contiguous(), lens)
 
+        # The text side (77 tokens per clip: ~150 launch-latency-bound kernels forward, as many backward) depends on
+        # nothing the video embedding and stem produce, and is first read by branch 0's cross-attention: it runs on a
+        # second HIP stream underneath the video stem's large kernels (autograd replays every node's backward on the
+        # stream of its forward, so the backward overlaps the same way).  VILCO_TEXT_STREAM=0: one stream.
         q = q_lens = None
+        side = None
         if self.use_cross_modal and text is not None:
-            q, q_lens = text, text_lens
-            for conv, norm in zip(self.txt_embd, self.txt_embd_norm):
-                q, q_lens = self._conv_ln_relu(conv, norm, q, q_lens)
-            for blk in self.txt_stem:
-                q, q_lens = blk.forward_tm(q, q_lens)
+            main = torch.cuda.current_stream()
+            side = _text_stream(x.device) if (_TEXT_STREAM and x.is_cuda) else None
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                q, q_lens = text, text_lens
+                for conv, norm in zip(self.txt_embd, self.txt_embd_norm):
+                    q, q_lens = self._conv_ln_relu(conv, norm, q, q_lens)
+                for blk in self.txt_stem:
+                    q, q_lens = blk.forward_tm(q, q_lens)
 
         for blk in self.stem:
             x, lens = blk.forward_tm(x, lens)            # stem blocks are called without cross_y
+
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            q.record_stream(torch.cuda.current_stream())
 
         feats, all_lens = [x], [lens]
         for idx, blk in enumerate(self.branch):
