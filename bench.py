@@ -459,6 +459,25 @@ def local_sections(out, args, model, step, dev, ms, world):
         dtb = (time.perf_counter() - t1) / 5
         out["larger_batch"] = {"clips_per_gpu": args.extra_batch, "ms_per_step": dtb * 1e3,
                                "clips_per_s": args.extra_batch / dtb}
+    if world == 1 and not args.no_targets and args.precision == "f16x2":
+        # BASELINE.md 3.3 asks for a bf16 perf run beside the parity run: the SAME step with single-pass bf16 MFMA operands
+        # (1 MFMA per product, 8-bit mantissas).  It does NOT meet the 1e-3 parity bar (median gradient
+        # error 6e-2) and is not the headline.
+        from vilco_amd import ops
+        try:
+            ops.set_precision("bf16")
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
+            dtb = (time.perf_counter() - t1) / 8
+            out["bf16_perf_run"] = {"ms_per_step": dtb * 1e3, "clips_per_s": args.batch / dtb, "parity": "fails the 1e-3 bar "
+                                    "(single bf16 pass, 2^-9 operands); reported because BASELINE.md 3.3 asks for it"}
+        finally:
+            ops.set_precision(args.precision)
     if world == 1 and not args.no_targets:
         # the two kernels the north star sets explicit targets on, and the other SURVEY 8d configurations
         del model

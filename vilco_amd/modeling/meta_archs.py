@@ -414,7 +414,9 @@ class PtTransformer(nn.Module):
 
     @property
     def device(self):
-        return list(set(p.device for p in self.parameters()))[0]
+        """the reference walks every parameter here (meta_archs.py:709-713; ~1 ms of host time per call at 465 tensors,
+        several calls per step); all parameters live on one device, so the first one answers"""
+        return self.mu.device
 
     def augment_classification(self, num_new_classes, device):
         device = self.mu.device
