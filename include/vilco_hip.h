@@ -134,6 +134,10 @@ typedef struct vilco_pack_item {
   /* relshift = 1: pack XLNet's unshifted view [rows][rows + cols] of src[rows][cols] (element (i,p) =            */
   /* src[i][p - rows + i] or 0): the adjoint of rel_shift_bnij, so dS feeds the position-term gradients directly  */
   int32_t relshift;
+  /* optional (precision 3): `namax` partial maxima of |src| already on the device -- left by the kernel that produced  */
+  /* src (vilco_layernorm_fwd_amax, vilco_act_bwd_amax, vilco_qkv_pre_fwd) -- so the pack needs no amax launch          */
+  const float* amax;
+  int32_t namax;
 } vilco_pack_item;
 size_t vilco_pack_item_bytes(const vilco_pack_item* item, int32_t precision);   /* honours nbatch / relshift */
 int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t precision, void* stream);
@@ -146,6 +150,11 @@ int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t precision, 
 int vilco_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                         float* mean, float* rstd, int64_t rows, int32_t C, float eps,
                         int32_t relu, void* stream);
+/* the same, and the kernel also leaves *n_parts per-block partial maxima of |y| in amax_parts (device, >= 2048 floats): */
+/* the operand pack of y (vilco_pack_item.amax) then needs no separate pass over it                                     */
+int vilco_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y,
+                             float* mean, float* rstd, int64_t rows, int32_t C, float eps,
+                             int32_t relu, float* amax_parts, int32_t* n_parts, void* stream);
 size_t vilco_layernorm_bwd_workspace(int64_t rows, int32_t C);
 /* y (forward output) is only read when relu=1.  dgamma/dbeta are overwritten. */
 int vilco_layernorm_bwd(const float* dy, const float* x, const float* y, const float* gamma,
@@ -244,6 +253,10 @@ int vilco_axpby(float* out, const float* a, const float* b, float alpha, float b
 int vilco_act_bwd(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
                   const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p, uint32_t drop_seed,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* the same + partial maxima of |dz| (amax_parts: device, >= 2048 floats; *n_parts = how many were written) */
+int vilco_act_bwd_amax(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
+                       const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p, uint32_t drop_seed,
+                       void* workspace, size_t workspace_bytes, float* amax_parts, int32_t* n_parts, void* stream);
 /* out[c] = sum_r x[r][c] */
 int vilco_colsum(const float* x, float* out, int64_t rows, int32_t C, void* workspace,
                  size_t workspace_bytes, void* stream);
@@ -289,10 +302,14 @@ int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, co
 /* vilco_layernorm_bwd on (dh, x, mean1, rstd1).                                                                    */
 /* ------------------------------------------------------------------------------------------ */
 int vilco_qkv_pre_supported(int32_t C);
+/* amax_parts (may be NULL): three device arrays of vilco_qkv_pre_amax_parts(B, T, stride) floats that receive the        */
+/* partial maxima of |q|, |k|, |v| (0 = too many partials: not emitted).                                                 */
+int vilco_qkv_pre_amax_parts(int32_t B, int32_t T, int32_t stride);
 int vilco_qkv_pre_fwd(const float* x, const float* ln1_g, const float* ln1_b, const float* const* w,
                       const float* const* gam, const float* const* bet, const int32_t* len, float* h,
                       float* const* y, float* mean1, float* rstd1, float* const* mean, float* const* rstd,
-                      int32_t B, int32_t T, int32_t C, int32_t stride, float eps1, float eps, void* stream);
+                      float* const* amax_parts, int32_t B, int32_t T, int32_t C, int32_t stride, float eps1, float eps,
+                      void* stream);
 size_t vilco_qkv_pre_bwd_workspace(int32_t B, int32_t T, int32_t C, int32_t stride);
 int vilco_qkv_pre_bwd(const float* h, const float* const* w, const float* const* gam, const float* const* dy,
                       const float* const* mean, const float* const* rstd, const int32_t* len,

@@ -51,7 +51,7 @@ class LossDesc(C.Structure):
 class PackItem(C.Structure):
     """Mirror of `vilco_pack_item`."""
     _fields_ = [("src", c_fp), ("rows", i64), ("cols", i64), ("ld", i64), ("planes", c_fp), ("planes_bytes", sz),
-                ("nbatch", i32), ("batch_stride", i64), ("relshift", i32)]
+                ("nbatch", i32), ("batch_stride", i64), ("relshift", i32), ("amax", c_fp), ("namax", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/vilco_hip.h declares
@@ -68,6 +68,7 @@ SIGNATURES = {
     "vilco_pack": (C.c_int, [c_fp, i64, i64, i64, i32, c_fp, sz, c_fp]),
     "vilco_pack_many": (C.c_int, [C.POINTER(PackItem), i32, i32, c_fp]),
     "vilco_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp]),
+    "vilco_layernorm_fwd_amax": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp, C.POINTER(i32), c_fp]),
     "vilco_layernorm_bwd_workspace": (sz, [i64, i32]),
     "vilco_layernorm_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32,
                                       i32, c_fp, sz, c_fp]),
@@ -94,6 +95,8 @@ SIGNATURES = {
     "vilco_dropout": (C.c_int, [c_fp, c_fp, i64, f32, C.c_uint32, C.c_uint64, c_fp]),
     "vilco_axpby": (C.c_int, [c_fp, c_fp, c_fp, f32, f32, i64, c_fp]),
     "vilco_act_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp]),
+    "vilco_act_bwd_amax": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp,
+                                     C.POINTER(i32), c_fp]),
     "vilco_colsum": (C.c_int, [c_fp, c_fp, i64, i32, c_fp, sz, c_fp]),
     "vilco_mask_rows": (C.c_int, [c_fp, c_fp, i32, i32, i32, c_fp]),
     "vilco_add_pe": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),
@@ -103,9 +106,10 @@ SIGNATURES = {
     "vilco_optim_step": (C.c_int, [i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), i32,
                                    f32, f32, f32, f32, c_fp, c_fp, c_fp]),
     "vilco_qkv_pre_supported": (C.c_int, [i32]),
+    "vilco_qkv_pre_amax_parts": (C.c_int, [i32, i32, i32]),
     "vilco_qkv_pre_fwd": (C.c_int, [c_fp, c_fp, c_fp, C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), c_fp, c_fp,
-                                    C.POINTER(c_fp), c_fp, c_fp, C.POINTER(c_fp), C.POINTER(c_fp), i32, i32, i32, i32, f32,
-                                    f32, c_fp]),
+                                    C.POINTER(c_fp), c_fp, c_fp, C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), i32, i32,
+                                    i32, i32, f32, f32, c_fp]),
     "vilco_qkv_pre_bwd_workspace": (sz, [i32, i32, i32, i32]),
     "vilco_qkv_pre_bwd": (C.c_int, [c_fp, C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp),
                                     C.POINTER(c_fp), c_fp, c_fp, C.POINTER(c_fp), c_fp, c_fp, i32, i32, i32, i32, c_fp, sz,

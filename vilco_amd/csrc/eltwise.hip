@@ -166,7 +166,9 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ dz,
     float* __restrict__ ws, int act, const int* __restrict__ len, int T, long rows, int C,
     int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, float drop_inv_keep, float* __restrict__ dbias,
-    unsigned* sync) {
+    unsigned* sync, float* __restrict__ amax_parts) {
+  __shared__ float amax_red[EW_THREADS / 64];
+  float amax = 0.f;          // max |dz| of this block: dz goes straight into an operand pack
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
@@ -181,8 +183,16 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
       else if (act == VILCO_ACT_GELU) g *= gelu_grad_f(aux[r * C + c]);
       dz[r * C + c] = g;
       acc += g;
+      amax = fmaxf(amax, fabsf(g));
     }
     if (ws) vilco_st_agent(ws + (long)blockIdx.x * C + c, acc);
+  }
+  if (amax_parts) {
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      amax_parts[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
   }
   if (sync) vilco_finish_colsum(ws, dbias, nullptr, (int)gridDim.x, C, C, sync, blockIdx.y * gridDim.x + blockIdx.x,
                                 gridDim.x * gridDim.y);
@@ -394,6 +404,15 @@ extern "C" int vilco_axpby(float* out, const float* a, const float* b, float alp
 extern "C" int vilco_act_bwd(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
                              const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p,
                              uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream) {
+  return vilco_act_bwd_amax(dy, aux, dz, dbias, act, len, T, rows, C, drop_p, drop_seed, workspace, workspace_bytes, nullptr,
+                            nullptr, stream);
+}
+
+extern "C" int vilco_act_bwd_amax(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
+                                  const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p,
+                                  uint32_t drop_seed, void* workspace, size_t workspace_bytes, float* amax_parts,
+                                  int32_t* n_parts, void* stream) {
+  if (n_parts) *n_parts = 0;
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (!dy || !dz || rows < 0 || C <= 0 || act < 0 || act > 2) return VILCO_ERR_BADARG;
   if (act != VILCO_ACT_NONE && !aux) return VILCO_ERR_BADARG;
@@ -405,8 +424,11 @@ extern "C" int vilco_act_bwd(const float* dy, const float* aux, float* dz, float
   const int rpb = (int)((rows + nb - 1) / nb);
   float* ws = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
   unsigned* sync = (dbias && C <= 256 * VILCO_SYNC_MAX_BLOCKS) ? vilco_sync_counter(s, VILCO_SITE_COLSUM) : nullptr;
+  const bool emit = amax_parts && n_parts;
+  if (emit) *n_parts = nb * ((C + EW_THREADS - 1) / EW_THREADS);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
-                     (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync);
+                     (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,
+                     emit ? amax_parts : nullptr);
   if (dbias && !sync) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }

@@ -674,6 +674,7 @@ extern "C" int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t 
   const int NP = np_of_precision(precision);
   PackArgs4 pk;
   AmaxArgs am;
+  bool have_amax[4] = {false, false, false, false};
   const int nbatch = items[0].nbatch > 1 ? items[0].nbatch : 1;
   for (int i = 0; i < n; ++i) {
     const vilco_pack_item& it = items[i];
@@ -697,11 +698,20 @@ extern "C" int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t 
       src_view.K = (int)it.cols; src_view.tap = 0;
       am.op[i] = amax_view(src_view, false, 1, hdr);
       pa.amax = hdr; pa.namax = am.op[i].nblocks;
+      if (it.amax && it.namax > 0) { pa.amax = it.amax; pa.namax = it.namax; have_amax[i] = true; }   // left by the producer
     }
   }
   if (precision == 3) {
-    if (dispatch_pack_fused(NP, pk.a, am.op, n, nbatch, s, VILCO_SITE_PACK)) return vilco_launch_status();   // amax + pack: 1 launch
-    launch_amax(am, n, s);
+    int todo = 0;
+    for (int i = 0; i < n; ++i) todo += have_amax[i] ? 0 : 1;
+    if (todo == n && dispatch_pack_fused(NP, pk.a, am.op, n, nbatch, s, VILCO_SITE_PACK)) return vilco_launch_status();   // amax + pack: 1 launch
+    if (todo) {
+      AmaxArgs am2;
+      int k = 0;
+      for (int i = 0; i < n; ++i)
+        if (!have_amax[i]) am2.op[k++] = am.op[i];
+      launch_amax(am2, k, s);
+    }
   }
   if (n == 1 && nbatch == 1) dispatch_pack(NP, pk.a[0], false, 1, s);
   else dispatch_pack_multi(NP, pk, n, s, nbatch);
@@ -710,7 +720,7 @@ extern "C" int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t 
 
 extern "C" int vilco_pack(const float* src, int64_t rows, int64_t cols, int64_t ld, int32_t precision, void* planes,
                           size_t planes_bytes, void* stream) {
-  const vilco_pack_item it = {src, rows, cols, ld, planes, planes_bytes, 1, 0, 0};
+  const vilco_pack_item it = {src, rows, cols, ld, planes, planes_bytes, 1, 0, 0, nullptr, 0};
   return vilco_pack_many(&it, 1, precision, stream);
 }
 

@@ -13,7 +13,9 @@ template <int NV>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long rows, int C,
-    float eps, int relu) {
+    float eps, int relu, float* __restrict__ amax_parts) {
+  __shared__ float amax_red[LN_WAVES];
+  float amax = 0.f;          // max |y| over this lane's outputs: the consumer's operand pack needs the tensor's amax
   const int lane = threadIdx.x & 63;
   const long wid = (long)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
   const long wstride = (long)gridDim.x * LN_WAVES;
@@ -70,8 +72,20 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
         if (relu) {
           o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         *reinterpret_cast<float4*>(yr + c) = o;
       }
+    }
+  }
+  if (amax_parts) {          // one partial maximum per block, folded by the pack kernel exactly like amax_kernel's
+    amax = wave_max(amax);
+    if (lane == 0) amax_red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = amax_red[0];
+#pragma unroll
+      for (int w = 1; w < LN_WAVES; ++w) m = fmaxf(m, amax_red[w]);
+      amax_parts[blockIdx.x] = m;
     }
   }
 }
@@ -223,14 +237,23 @@ void vilco_reduce_rows(const float* ws, float* out0, float* out1, int nrows, int
 extern "C" int vilco_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                                    float* mean, float* rstd, int64_t rows, int32_t C, float eps,
                                    int32_t relu, void* stream) {
+  return vilco_layernorm_fwd_amax(x, gamma, beta, y, mean, rstd, rows, C, eps, relu, nullptr, nullptr, stream);
+}
+
+extern "C" int vilco_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y,
+                                        float* mean, float* rstd, int64_t rows, int32_t C, float eps,
+                                        int32_t relu, float* amax_parts, int32_t* n_parts, void* stream) {
   if (!x || !y || rows < 0 || C <= 0) return VILCO_ERR_BADARG;
+  if (n_parts) *n_parts = 0;
   if (rows == 0) return VILCO_OK;
   if ((C % 4) != 0 || C > 4096) return VILCO_ERR_UNSUPPORTED;
   if (!vilco_aligned(x, 16) || !vilco_aligned(y, 16)) return VILCO_ERR_BADARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nv = (C + 255) / 256;
   dim3 grid(ln_blocks(rows, 2048));
-  LN_DISPATCH(nv, ln_fwd_kernel, x, gamma, beta, y, mean, rstd, (long)rows, (int)C, eps, (int)relu)
+  if (amax_parts && n_parts) *n_parts = (int32_t)grid.x;
+  LN_DISPATCH(nv, ln_fwd_kernel, x, gamma, beta, y, mean, rstd, (long)rows, (int)C, eps, (int)relu,
+              (amax_parts && n_parts) ? amax_parts : nullptr)
   return vilco_launch_status();
 }
 

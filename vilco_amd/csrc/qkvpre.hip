@@ -38,6 +38,7 @@ struct QkvArgs {
   float* y[3];               // [B][Tout][C]
   float* mean1; float* rstd1;                       // [B*T]
   float* mean[3]; float* rstd[3];                   // [B*Tout]
+  float* amax[3];            // optional: one partial max |y_j| per WAVE (the consumers' operand packs fold them)
   int B, T, Tout, C, stride, seg;
   float eps1, eps;
 };
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
   }
 
   // ---- pass 2: normalise and write
+  float omax[3] = {0.f, 0.f, 0.f};
   for (int g = 0; g < NG; ++g) {
     float4 h[NR];
     load_h(g, h);
@@ -210,10 +212,17 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
         float4 o;
         o.x = (c[i].x - cm[j][i]) * cr[j][i] * gm.x + bt.x; o.y = (c[i].y - cm[j][i]) * cr[j][i] * gm.y + bt.y;
         o.z = (c[i].z - cm[j][i]) * cr[j][i] * gm.z + bt.z; o.w = (c[i].w - cm[j][i]) * cr[j][i] * gm.w + bt.w;
+        omax[j] = fmaxf(fmaxf(omax[j], fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         *reinterpret_cast<float4*>(a.y[j] + ((long)b * a.Tout + t) * C + g * 256 + lane * 4) = o;
       }
     }
   }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    if (a.amax[j]) {
+      const float m = wave_max(omax[j]);
+      if (lane == 0) a.amax[j][wid] = m;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- backward, rows
@@ -430,9 +439,14 @@ void launch_fwd_tb(const QkvArgs& a, hipStream_t s) {
 
 // tokens per wave: more tokens = fewer halo re-reads and parameter loads, fewer = more waves in flight and fewer
 // registers.  Measured at [8, 2304, 2304] (r02): TB = 1 / 2 / 4 -> 1.90 / 2.49 / 2.16 TB/s.  VILCO_QKV_TB overrides (tuning).
+int forced_tb() {
+  static const int forced = [] { const char* e = getenv("VILCO_QKV_TB"); return e ? atoi(e) : 0; }();
+  return forced;
+}
+
 bool launch_fwd(const QkvArgs& a, hipStream_t s) {
   if (a.C % 256 != 0) return false;
-  static const int forced = [] { const char* e = getenv("VILCO_QKV_TB"); return e ? atoi(e) : 0; }();
+  const int forced = forced_tb();
   if (a.stride == 1) {
     int tb = forced ? forced : 2;
     if (tb >= 4) launch_fwd_tb<4, 1>(a, s);
@@ -446,10 +460,17 @@ bool launch_fwd(const QkvArgs& a, hipStream_t s) {
   return true;
 }
 
+extern "C" int vilco_qkv_pre_amax_parts(int32_t B, int32_t T, int32_t stride) {
+  if (B <= 0 || T <= 0 || (stride != 1 && stride != 2)) return 0;
+  const long waves = (long)B * ((T / stride + 1) / 2);          // TB = 2 tokens per wave, both strides (launch_fwd)
+  return waves <= 4096 ? (int)waves : 0;                        // more partials than that cost the packs more than an amax launch
+}
+
 extern "C" int vilco_qkv_pre_fwd(const float* x, const float* ln1_g, const float* ln1_b, const float* const* w,
                                  const float* const* gam, const float* const* bet, const int32_t* len, float* h,
                                  float* const* y, float* mean1, float* rstd1, float* const* mean, float* const* rstd,
-                                 int32_t B, int32_t T, int32_t C, int32_t stride, float eps1, float eps, void* stream) {
+                                 float* const* amax_parts, int32_t B, int32_t T, int32_t C, int32_t stride, float eps1,
+                                 float eps, void* stream) {
   if (!x || !w || !gam || !bet || !len || !y || !mean || !rstd || bad_common(B, T, C, stride)) return VILCO_ERR_BADARG;
   if (!vilco_qkv_pre_supported(C)) return VILCO_ERR_UNSUPPORTED;
   if (B == 0 || T == 0) return VILCO_OK;
@@ -459,6 +480,7 @@ extern "C" int vilco_qkv_pre_fwd(const float* x, const float* ln1_g, const float
   for (int j = 0; j < 3; ++j) {
     if (!w[j] || !y[j]) return VILCO_ERR_BADARG;
     a.w[j] = w[j]; a.gam[j] = gam[j]; a.bet[j] = bet[j]; a.y[j] = y[j]; a.mean[j] = mean[j]; a.rstd[j] = rstd[j];
+    a.amax[j] = (amax_parts && !forced_tb() && vilco_qkv_pre_amax_parts(B, T, stride) > 0) ? amax_parts[j] : nullptr;
   }
   a.B = B; a.T = T; a.Tout = T / stride; a.C = C; a.stride = stride; a.seg = 0;
   a.eps1 = eps1; a.eps = eps;

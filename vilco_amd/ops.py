@@ -172,6 +172,28 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     _lib.check(lib.vilco_gemm(C.byref(d), _stream()))
 
 
+# ---- amax partials left by the producing kernel.  The fp16 x2 planes need max|x| of the whole tensor before anything can be
+# packed; kernels whose output goes (mostly) straight into a matrix product -- LayerNorm forward, the fused q/k/v
+# pre-projection, the activation backward -- leave per-block partial maxima next to their output, tagged on the tensor
+# as `_vilco_amax = (partials, count, version)`; `pack` hands them to vilco_pack_many, which then skips its amax launch.
+# The tag is ignored once the tensor's version counter moved (in-place edits) or another precision is active.
+produce_amax = os.environ.get("VILCO_PRODUCER_AMAX", "1") != "0"
+AMAX_PARTS = 2048
+
+
+def _tag_amax(t, parts, n):
+    if n > 0:
+        t._vilco_amax = (parts, int(n), t._version)
+    return t
+
+
+def _amax_of(x):
+    tag = getattr(x, "_vilco_amax", None)
+    if tag is None or tag[2] != x._version or not produce_amax:
+        return None, 0
+    return tag[0], tag[1]
+
+
 def pack(x, rows, cols, precision=None):
     """One pass over the fp32 row-major matrix x[rows][cols] -> 16-bit operand planes (a uint8 tensor) that every
     product the tensor appears in consumes, in either orientation (vilco_pack, include/vilco_hip.h)."""
@@ -179,7 +201,15 @@ def pack(x, rows, cols, precision=None):
     prec = _precision if precision is None else int(precision)
     nbytes = lib.vilco_pack_bytes(int(rows), int(cols), prec)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    _lib.check(lib.vilco_pack(x.data_ptr(), int(rows), int(cols), int(cols), prec, buf.data_ptr(), nbytes, _stream()))
+    parts, n = _amax_of(x) if prec == 3 else (None, 0)
+    if parts is None:
+        _lib.check(lib.vilco_pack(x.data_ptr(), int(rows), int(cols), int(cols), prec, buf.data_ptr(), nbytes, _stream()))
+    else:
+        it = _lib.PackItem()
+        it.src, it.rows, it.cols, it.ld = x.data_ptr(), int(rows), int(cols), int(cols)
+        it.planes, it.planes_bytes, it.nbatch, it.batch_stride, it.relshift = buf.data_ptr(), nbytes, 1, 0, 0
+        it.amax, it.namax = parts.data_ptr(), n
+        _lib.check(lib.vilco_pack_many(C.byref(it), 1, prec, _stream()))
     return buf
 
 
@@ -249,9 +279,13 @@ def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0)):
     dz = torch.empty_like(dy)
     db = torch.empty(Cn, dtype=torch.float32, device=dy.device) if want_bias else None
     ws = _ws(lib.vilco_colsum_workspace(rows, Cn), dy.device) if want_bias else None
-    _lib.check(lib.vilco_act_bwd(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
-                                 int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
-                                 _stream()))
+    parts = torch.empty(AMAX_PARTS, dtype=torch.float32, device=dy.device) if (produce_amax and _precision == 3) else None
+    n = C.c_int32(0)
+    _lib.check(lib.vilco_act_bwd_amax(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
+                                      int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
+                                      _p(parts), C.byref(n), _stream()))
+    if parts is not None:
+        _tag_amax(dz, parts, n.value)
     return dz, db
 
 
@@ -443,6 +477,8 @@ def conv3(x, w, b=None, lens=None):
 
 # ---------------------------------------------------------------------------------------- LayerNorm
 class _LayerNorm(torch.autograd.Function):
+    last_amax = (None, 0)
+
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, relu):
         _chk(x, gamma, beta)
@@ -452,11 +488,14 @@ class _LayerNorm(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        _lib.check(lib.vilco_layernorm_fwd(x.data_ptr(), _p(gamma), _p(beta), y.data_ptr(),
-                                           mean.data_ptr(), rstd.data_ptr(), rows, Cn, eps,
-                                           int(relu), _stream()))
+        parts = torch.empty(AMAX_PARTS, dtype=torch.float32, device=x.device) if (produce_amax and _precision == 3) else None
+        n = C.c_int32(0)
+        _lib.check(lib.vilco_layernorm_fwd_amax(x.data_ptr(), _p(gamma), _p(beta), y.data_ptr(),
+                                                mean.data_ptr(), rstd.data_ptr(), rows, Cn, eps,
+                                                int(relu), _p(parts), C.byref(n), _stream()))
         ctx.relu = bool(relu)
         ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
+        _LayerNorm.last_amax = (parts, n.value)          # picked up by `layernorm` (attributes set here do not survive apply)
         return y
 
     @staticmethod
@@ -479,7 +518,10 @@ class _LayerNorm(torch.autograd.Function):
 
 def layernorm(x, gamma, beta, eps=1e-5, relu=False):
     """gamma/beta may have the reference's [1,C,1] shape (blocks.py:152-155) or [C]."""
-    return _LayerNorm.apply(x, gamma, beta, float(eps), bool(relu))
+    y = _LayerNorm.apply(x, gamma, beta, float(eps), bool(relu))
+    parts, n = _LayerNorm.last_amax
+    _LayerNorm.last_amax = (None, 0)
+    return _tag_amax(y, parts, n) if parts is not None else y
 
 
 # ---------------------------------------------------------------------------------------- dwconv / pool
@@ -1055,6 +1097,7 @@ def _ptr3(ts):
 
 
 class _QkvPre(torch.autograd.Function):
+    last_amax = (None, 0)
     """h = LN1(x); y_j = LN_j(dwconv3_stride(h; w_j) * mask), j = q, k, v   (blocks.py:561-563, 363-369) in one launch
     (vilco_qkv_pre_fwd); backward = vilco_qkv_pre_bwd (conv outputs recomputed from h) + LN1's ordinary backward."""
 
@@ -1070,10 +1113,14 @@ class _QkvPre(torch.autograd.Function):
         stats1 = torch.empty(2, B * T, dtype=torch.float32, device=dev)
         stats = torch.empty(6, B * To, dtype=torch.float32, device=dev)
         means, rstds = [stats[2 * j] for j in range(3)], [stats[2 * j + 1] for j in range(3)]
+        npart = lib.vilco_qkv_pre_amax_parts(B, T, int(stride)) if (produce_amax and _precision == 3) else 0
+        parts = torch.empty(3, npart, dtype=torch.float32, device=dev) if npart > 0 else None
         _lib.check(lib.vilco_qkv_pre_fwd(x.data_ptr(), _p(g1), _p(b1), _ptr3([wq, wk, wv]), _ptr3([gq, gk, gv]),
                                          _ptr3([bq, bk, bv]), lens.data_ptr(), _p(h), _ptr3(ys), stats1[0].data_ptr(),
-                                         stats1[1].data_ptr(), _ptr3(means), _ptr3(rstds), B, T, Cn, int(stride),
-                                         float(eps1), float(eps), _stream()))
+                                         stats1[1].data_ptr(), _ptr3(means), _ptr3(rstds),
+                                         _ptr3([parts[0], parts[1], parts[2]]) if parts is not None else None, B, T, Cn,
+                                         int(stride), float(eps1), float(eps), _stream()))
+        _QkvPre.last_amax = (parts, npart)
         ctx.stride, ctx.eps1, ctx.want_h = int(stride), float(eps1), bool(want_h)
         ctx.save_for_backward(x, g1, b1, wq, wk, wv, gq, gk, gv, lens, stats1, stats, h)
         return (ys[0], ys[1], ys[2], h) if want_h else (ys[0], ys[1], ys[2])
@@ -1119,5 +1166,11 @@ def qkv_pre(x, ln1, convs, norms, lens, stride, want_h):
     """x [B,T,C]; ln1 = (weight, bias, eps) of the block's first LayerNorm; convs = three depthwise [C,1,3] weights
     (query, key, value); norms = three (weight, bias) pairs + one eps -> (q, k, v[, h])."""
     (g1, b1, eps1), (wq, wk, wv), ((gq, bq), (gk, bk), (gv, bv), eps) = ln1, convs, norms
-    return _QkvPre.apply(x.contiguous(), g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv, lens, int(stride), float(eps1),
+    outs = _QkvPre.apply(x.contiguous(), g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv, lens, int(stride), float(eps1),
                          float(eps), bool(want_h))
+    parts, n = _QkvPre.last_amax
+    _QkvPre.last_amax = (None, 0)
+    if parts is not None:
+        for j in range(3):
+            _tag_amax(outs[j], parts[j], n)
+    return outs
