@@ -14,7 +14,9 @@ from .modeling_xlnet_x import XLNetConfig, XLNetModel
 from .models import register_backbone
 
 
-_TEXT_STREAM = os.environ.get("VILCO_TEXT_STREAM", "1") != "0"
+# off by default: measured ~0.8 ms faster per step in most runs, but one run in four lands 3-7 ms SLOWER (r02, same box:
+# 32.3 / 39.3 / 32.0 ms) -- the interleaving of the two queues is not under our control.  VILCO_TEXT_STREAM=1 enables it.
+_TEXT_STREAM = os.environ.get("VILCO_TEXT_STREAM", "0") == "1"
 _side_streams = {}
 
 
@@ -127,7 +129,7 @@ class ConvTransformerBackbone(nn.Module):
         # The text side (77 tokens per clip: ~150 launch-latency-bound kernels forward, as many backward) depends on
         # nothing the video embedding and stem produce, and is first read by branch 0's cross-attention: it runs on a
         # second HIP stream underneath the video stem's large kernels (autograd replays every node's backward on the
-        # stream of its forward, so the backward overlaps the same way).  VILCO_TEXT_STREAM=0: one stream.
+        # stream of its forward, so the backward overlaps the same way).  Optional, see _TEXT_STREAM.
         q = q_lens = None
         side = None
         if self.use_cross_modal and text is not None:

@@ -49,13 +49,25 @@ def down_lens(lens, stride):
     return torch.div(lens + (stride - 1), stride, rounding_mode="floor").to(torch.int32)
 
 
+_DROP_POOL = {}          # (device, B, keep) -> [rows of ready factors, next row]
+_DROP_POOL_ROWS = 64
+
+
 def _drop_rowscale(x, drop_prob, training):
-    """per-sample stochastic-depth factor (blocks.py:628-641) as a [B] row scale, or None."""
+    """per-sample stochastic-depth factor (blocks.py:628-641) as a [B] row scale, or None.
+    The reference draws `keep + rand(B)`, floors it and divides by keep at each of its ~30 sites per step (four tiny
+    launches each); the same factors are drawn here 64 sites at a time and handed out row by row."""
     if drop_prob == 0.0 or not training:
         return None
     keep = 1.0 - drop_prob
-    m = torch.floor(keep + torch.rand(x.shape[0], dtype=x.dtype, device=x.device))
-    rs = (m / keep).contiguous()
+    B = x.shape[0]
+    key = (x.device, B, keep, torch.cuda.current_stream().cuda_stream if x.is_cuda else 0)     # one pool per stream
+    pool = _DROP_POOL.get(key)
+    if pool is None or pool[1] >= _DROP_POOL_ROWS:
+        r = torch.rand(_DROP_POOL_ROWS, B, dtype=torch.float32, device=x.device)
+        pool = _DROP_POOL[key] = [torch.floor(keep + r).div_(keep), 0]
+    rs = pool[0][pool[1]]
+    pool[1] += 1
     if ops.dropout_log is not None:          # parity tests replay the factors into the oracle
         ops.dropout_log.append(("droppath", rs))
     return rs
