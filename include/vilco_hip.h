@@ -114,6 +114,10 @@ int vilco_gemm(const vilco_gemm_desc* d, void* stream);
 /* brackets its main kernel with HIP events on the caller's stream; end waits for them and returns the sum.          */
 int vilco_gemm_profile_begin(void);
 int vilco_gemm_profile_end(double* kernel_ms, int64_t* launches);
+/* per-launch records of the last begin/end bracket (measurement tooling, tools/gemm_shapes.py): desc[i*10 + 0..9] =
+ * M, N, K, batch, tile rows, split-K count, precision, a k-major, b k-major, tap flags; ms[i] = that launch's kernel
+ * time.  Returns the number of records available (may exceed cap). */
+int64_t vilco_gemm_profile_records(int64_t* desc, double* ms, int64_t cap);
 
 /* Splits the fp32 row-major matrix src[rows][cols] (row stride ld) ONCE into the 16-bit operand planes of         */
 /* `precision` ([part][rows32][cols32], zero padded; precision 3 also leaves the per-tensor power-of-two scale in  */

@@ -40,3 +40,10 @@ for bi in range(2):
     errs.sort(reverse=True)
     for e in errs[:12]:
         print("  %.3e %-60s max|g| %.3e" % e)
+    for name in ('reg_head.norm.0.weight', 'reg_head.norm.0.bias'):
+        q = dict(model.named_parameters())[name]
+        g, w = q.grad.detach().double().cpu().reshape(-1), p[name].grad.reshape(-1)
+        order = w.abs().argsort()
+        print("  ", name, "n", g.numel(), "max|g| %.3e" % float(w.abs().max()))
+        for i in order[:6].tolist():
+            print("     elem %3d  hip % .6e  fp64 % .6e" % (i, float(g[i]), float(w[i])))

@@ -63,6 +63,7 @@ SIGNATURES = {
     "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "vilco_gemm_profile_begin": (C.c_int, []),
     "vilco_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "vilco_gemm_profile_records": (C.c_int64, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int64]),
     "vilco_pack_bytes": (sz, [i64, i64, i32]),
     "vilco_pack_item_bytes": (sz, [C.POINTER(PackItem), i32]),
     "vilco_pack": (C.c_int, [c_fp, i64, i64, i64, i32, c_fp, sz, c_fp]),

@@ -624,7 +624,13 @@ extern "C" int vilco_lab_read(unsigned long long* out) {
 
 // ---- optional timing of the MFMA kernel alone (bench.py's roofline line): HIP events on the caller's stream
 namespace {
-struct ProfState { bool on = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+struct ProfRec { int64_t v[10]; };   // M, N, K, batch, BM, ksplit, precision, a_km, b_km, tap
+struct ProfState {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<ProfRec> rec;          // one per event pair
+  std::vector<double> ms;            // filled by profile_end, read by profile_records
+};
 ProfState& prof() { static ProfState p; return p; }
 }  // namespace
 
@@ -632,6 +638,8 @@ extern "C" int vilco_gemm_profile_begin(void) {
   ProfState& p = prof();
   for (auto& e : p.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   p.ev.clear();
+  p.rec.clear();
+  p.ms.clear();
   p.on = true;
   return VILCO_OK;
 }
@@ -645,12 +653,24 @@ extern "C" int vilco_gemm_profile_end(double* kernel_ms, int64_t* launches) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, e.first, e.second);
     total += ms;
+    p.ms.push_back(ms);
   }
   if (kernel_ms) *kernel_ms = total;
   if (launches) *launches = (int64_t)p.ev.size();
   for (auto& e : p.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   p.ev.clear();
   return VILCO_OK;
+}
+
+// per-launch records of the last begin/end bracket: desc[i*10 ..] = M, N, K, batch, BM, ksplit, precision, a_km, b_km, tap
+extern "C" int64_t vilco_gemm_profile_records(int64_t* desc, double* ms, int64_t cap) {
+  ProfState& p = prof();
+  const int64_t n = (int64_t)std::min(p.rec.size(), p.ms.size());
+  for (int64_t i = 0; i < n && i < cap; ++i) {
+    if (desc) for (int j = 0; j < 10; ++j) desc[i * 10 + j] = p.rec[i].v[j];
+    if (ms) ms[i] = p.ms[i];
+  }
+  return n;
 }
 
 static inline int np_of_precision(int precision) { return precision == 1 ? 1 : ((precision == 0 || precision == 3) ? 2 : 3); }
@@ -878,7 +898,11 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
       else launch_pp<128, 3>(g, grid, s, ak, bk);
     }
   }
-  if (ev0) { hipEventRecord(ev1, s); prof().ev.emplace_back(ev0, ev1); }
+  if (ev0) {
+    hipEventRecord(ev1, s);
+    prof().ev.emplace_back(ev0, ev1);
+    prof().rec.push_back(ProfRec{{d->M, d->N, d->K, nz, p.BM, p.ksplit, d->precision, p.a_km, p.b_km, p.a_tap | (p.b_tap << 4)}});
+  }
   if (p.ksplit > 1) {
     long blocks = ((long)d->M * d->N * nz + 255) / 256;
     if (blocks > 2048) blocks = 2048;
