@@ -2,10 +2,11 @@
 set -e
 cd "$(dirname "$0")/../../vilco_amd/csrc"
 mkdir -p ../../tools/lab/obj
-for f in gemm attn norm conv eltwise nms optim status; do
+for f in gemm attn norm conv eltwise nms optim loss qkvpre sync status; do
   extra=""; [ $f = nms ] && extra="-ffp-contract=off"
   [ $f = gemm ] && extra="-DVILCO_LAB $LABFLAGS"
-  if [ $f = gemm ] || [ ! -f ../../tools/lab/obj/$f.o ]; then
+  [ $f = attn ] && extra="-DVILCO_LAB_ATTN $LABFLAGS"
+  if [ $f = gemm ] || [ $f = attn ] || [ ! -f ../../tools/lab/obj/$f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -Wno-unused-value -Wno-comment $extra -c $f.hip -o ../../tools/lab/obj/$f.o &
   fi
 done

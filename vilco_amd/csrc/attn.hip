@@ -22,6 +22,7 @@
 // Backward = two kernels that recompute P from (q, k, lse): attn_bwd_dq (same orientation, one workgroup per
 // query tile: dS -> dQ, optional dBias) and attn_bwd_dkdv (one workgroup per key tile, S = Q K^T orientation so
 // P^T / dS^T are packed stores: dV^T = dO^T P, dK^T = Q^T dS).  No atomics: results are bitwise reproducible.
+#include <type_traits>
 #include "common.h"
 #include "pack.h"
 
@@ -448,6 +449,267 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ forward, hd = 64 fast path
+// The MQ blocks' attention (blocks.py:191-247: hd = 64, prefix key mask, no bias, attn_pdrop = 0) in fp16 x2 planes.
+// Differences from the general kernel above, all of them about instruction count -- the general kernel spends ~360
+// VALU + ~50 SALU instructions per 16-query x 64-key wave tile next to 48 MFMAs (rocprofv3 SQ_INSTS_*), i.e. the
+// vector ALU, not the matrix pipe or the LDS, sets its speed:
+//  * 128 queries per workgroup, 32 per wave: two MFMA column groups share every K / V fragment read and every loop
+//    overhead instruction;
+//  * P never goes through LDS.  S^T = K Q^T leaves lane (q, g4) with keys 16 mi + 4 g4 + r; the contraction index of
+//    O^T += V^T P^T may be enumerated in any order as long as both operands agree, so k-step ks, element e of a lane is
+//    key 32 ks + 16 (e >> 2) + 4 g4 + (e & 3): P's B fragments are then the lane's own registers, and the V^T
+//    fragments come out of the NATURAL V tile by gfx950's transposing LDS read with its two 4-key reads placed on
+//    exactly those keys (tr_frag64) -- no transposed V planes are packed for this path;
+//  * softmax in the exp2 domain with the score scale, log2(e) and the 2^15 fp16 range shift of P folded into one FMA
+//    per score; the row sums stay per lane until the epilogue; O is rescaled only when some row's maximum moved;
+//  * interior tiles carry no masking or bounds code at all (out-of-range rows / columns of the last tile are clamped
+//    to valid memory and masked by the key-length test).
+__device__ __forceinline__ f32x4 mfma3h(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x4 c) {
+  const f16x8 a0 = __builtin_bit_cast(f16x8, a[0]), a1 = __builtin_bit_cast(f16x8, a[1]);
+  const f16x8 b0 = __builtin_bit_cast(f16x8, b[0]), b1 = __builtin_bit_cast(f16x8, b[1]);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);
+}
+
+constexpr int F64_Q = 128;       // queries per workgroup of the fast path
+constexpr int RS64 = 80;                 // LDS row stride (elements) of a natural [64 rows][64 d] tile
+constexpr int PL64 = 64 * RS64;          // elements per part
+
+__device__ __forceinline__ bf16x8 tr_frag64(const __bf16* p) {     // k rows at p, k rows + 16 at p + 16 rows
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 16 * RS64));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+
+#ifdef VILCO_LAB_ATTN   // tools/lab only: in-kernel cycle stamps of block (0,0,0) wave 0 (never compiled into the product)
+__device__ unsigned long long vilco_lab_attn_stamps[64 * 8];
+#define ASTAMP(i)                                                                                             \
+  do {                                                                                                         \
+    if (stamp_on && stamp_t < 64) {                                                                            \
+      const unsigned long long c_ = __builtin_amdgcn_s_memtime();                                              \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+      if (lane == 0) vilco_lab_attn_stamps[stamp_t * 8 + (i)] = c_;                                            \
+    }                                                                                                          \
+  } while (0)
+#else
+#define ASTAMP(i) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) {
+  constexpr int HDP = 64, BKV = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);          // [2 parts][64 keys][RS64]
+  __bf16* sV = sK + 2 * PL64;                                 // [2 parts][64 keys][RS64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bh = b * a.H + h;
+  const int q0 = blockIdx.x * F64_Q + wave * 32;
+  const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
+  const int kend = len < a.Tk ? len : a.Tk;
+  const int ntiles = (kend + BKV - 1) / BKV;
+  const AttnScales sc = *a.sc;
+  const float c2 = a.scale * sc.iq * sc.ik * 1.44269504088896340736f;      // log2-domain score = acc * c2
+  const __bf16* kbase = a.kn.p + (long)bh * a.kn.batch_stride;
+  const __bf16* vbase = a.vn.p + (long)bh * a.vn.batch_stride;
+  const int g4 = lane >> 4;
+  const int fbn = (lane & 15) * RS64 + g4 * 8;                          // natural fragment: row lane & 15, chunk g4 (+ 4 ks)
+  const int fbt = (4 * g4 + ((lane & 15) >> 2)) * RS64 + 4 * (lane & 3);   // transposing fragment (tr_frag64)
+
+  QFrag<HDP, 2> qf[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) load_qfrag<HDP, 2>(qf[g], a.qn, a.qn.p + (long)bh * a.qn.batch_stride, q0 + 16 * g, lane);
+
+  f32x4 oacc[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oacc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+  // staging: thread owns chunks (row = tid >> 3 (+32), 16-byte chunk c = tid & 7) of the K and the V tile (both natural)
+  bf16x8 stK[2][2], stV[2][2];
+  const int srow = tid >> 3, sc8 = tid & 7;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int kr = k0 + srow + 32 * i;
+      kr = kr < a.kn.rows ? kr : a.kn.rows - 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        stK[q][i] = *reinterpret_cast<const bf16x8*>(kbase + q * a.kn.part_stride + (long)kr * HDP + sc8 * 8);
+        stV[q][i] = *reinterpret_cast<const bf16x8*>(vbase + q * a.vn.part_stride + (long)kr * HDP + sc8 * 8);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (srow + 32 * i) * RS64 + sc8 * 8;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<bf16x8*>(sK + q * PL64 + o) = stK[q][i];
+        *reinterpret_cast<bf16x8*>(sV + q * PL64 + o) = stV[q][i];
+      }
+    }
+  };
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const f32x2 c2v = {c2, c2};
+#ifdef VILCO_LAB_ATTN
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0;
+#endif
+  // one 64-key tile (MASKED only for the tile that holds the end of the keys)
+  auto tile = [&](int t, bool more, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int k0 = t * BKV;
+#ifdef VILCO_LAB_ATTN
+    const int stamp_t = t;
+#endif
+    ASTAMP(0);
+    __syncthreads();                                // previous tile fully consumed
+    lstore();
+    __syncthreads();
+    ASTAMP(1);
+    if (more) gload(k0 + BKV);                      // next tile's loads fly under this tile's MFMAs
+
+    // S^T[key][q] = K Q^T for both query groups.  Fragment reads run one step ahead of the MFMAs that use them, and the
+    // two accumulators of a step alternate so that consecutive MFMAs never depend on each other.
+    f32x4 s[2][4];
+    bf16x8 kf[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) kf[0][q] = *reinterpret_cast<const bf16x8*>(sK + q * PL64 + fbn);
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int mi = st >> 1, ks = st & 1;
+      if (st + 1 < 8) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          kf[(st + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(sK + q * PL64 + fbn + ((st + 1) >> 1) * 16 * RS64 + ((st + 1) & 1) * 32);
+      }
+      const f16x8 k0h = __builtin_bit_cast(f16x8, kf[st & 1][0]), k1h = __builtin_bit_cast(f16x8, kf[st & 1][1]);
+      const f16x8 a0 = __builtin_bit_cast(f16x8, qf[0].f[ks][0]), a1 = __builtin_bit_cast(f16x8, qf[0].f[ks][1]);
+      const f16x8 b0 = __builtin_bit_cast(f16x8, qf[1].f[ks][0]), b1 = __builtin_bit_cast(f16x8, qf[1].f[ks][1]);
+      f32x4 c0 = ks ? s[0][mi] : f32x4{0.f, 0.f, 0.f, 0.f}, c1 = ks ? s[1][mi] : f32x4{0.f, 0.f, 0.f, 0.f};
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, a0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, b0, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, a1, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, b1, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, a0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, b0, c1, 0, 0, 0);
+      s[0][mi] = c0; s[1][mi] = c1;
+    }
+    ASTAMP(2);
+    if constexpr (MASKED) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (k0 + mi * 16 + g4 * 4 + r >= kend) { s[0][mi][r] = -INFINITY; s[1][mi][r] = -INFINITY; }
+    }
+    bf16x8 pb[2][2][2];                             // [group][k-step][part]: P^T B fragments, built in registers
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      // scores to the log2 domain, then the row maximum over this lane's 16 keys and the 4 lanes of the query
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const f32x2 a01 = f32x2{s[g][mi][0], s[g][mi][1]} * c2v, a23 = f32x2{s[g][mi][2], s[g][mi][3]} * c2v;
+        s[g][mi] = f32x4{a01[0], a01[1], a23[0], a23[1]};
+      }
+      float mx = fmaxf(fmaxf(s[g][0][0], s[g][0][1]), fmaxf(s[g][0][2], s[g][0][3]));
+#pragma unroll
+      for (int mi = 1; mi < 4; ++mi) mx = fmaxf(mx, fmaxf(fmaxf(s[g][mi][0], s[g][mi][1]), fmaxf(s[g][mi][2], s[g][mi][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[g], mx);             // finite: every tile holds at least one valid key
+      const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+      const float off = 15.f - m_new;                      // P is formed as P * 2^15 (fp16 range)
+      const f32x2 offv = {off, off};
+      f32x2 psum = {0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 sv = {s[g][2 * ks + (e >> 2)][e & 3], s[g][2 * ks + (e >> 2)][(e & 3) + 1]};
+          const f32x2 arg = sv + offv;                     // v_pk_add_f32
+          const f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+          psum += p;                                       // v_pk_add_f32
+          const f16x2 hp = {(_Float16)p[0], (_Float16)p[1]};                 // v_cvt_pk_f16_f32 (round to nearest even)
+          const uint32_t hpu = __builtin_bit_cast(uint32_t, hp);
+          uint32_t lo;                                     // second part = fp16(p - h0): the mixed-precision FMA reads the
+          asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hpu), "v"(p[0]));      // fp16 half in place
+          asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hpu), "v"(p[1]));
+          h0[e >> 1] = hpu;
+          h1[e >> 1] = lo;
+        }
+        pb[g][ks][0] = __builtin_bit_cast(bf16x8, h0);
+        pb[g][ks][1] = __builtin_bit_cast(bf16x8, h1);
+      }
+      l_run[g] = l_run[g] * alpha + (psum[0] + psum[1]);   // per-lane partial row sum (this lane's keys only)
+      m_run[g] = m_new;
+      if (__any(alpha != 1.f)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { oacc[g][i][0] *= alpha; oacc[g][i][1] *= alpha; oacc[g][i][2] *= alpha; oacc[g][i][3] *= alpha; }
+      }
+    }
+    ASTAMP(3);
+    // O^T[d][q] += V^T P^T, V^T fragments by transposing reads of the natural tile (keys in the order P sits in the registers)
+    bf16x8 vf[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) vf[0][q] = tr_frag64(sV + q * PL64 + fbt);
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int ks = st >> 2, di = st & 3;
+      if (st + 1 < 8) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) vf[(st + 1) & 1][q] = tr_frag64(sV + q * PL64 + fbt + ((st + 1) >> 2) * 32 * RS64 + ((st + 1) & 3) * 16);
+      }
+      const f16x8 v0h = __builtin_bit_cast(f16x8, vf[st & 1][0]), v1h = __builtin_bit_cast(f16x8, vf[st & 1][1]);
+      const f16x8 a0 = __builtin_bit_cast(f16x8, pb[0][ks][0]), a1 = __builtin_bit_cast(f16x8, pb[0][ks][1]);
+      const f16x8 b0 = __builtin_bit_cast(f16x8, pb[1][ks][0]), b1 = __builtin_bit_cast(f16x8, pb[1][ks][1]);
+      f32x4 c0 = oacc[0][di], c1 = oacc[1][di];
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1h, a0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1h, b0, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, a1, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, b1, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, a0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, b0, c1, 0, 0, 0);
+      oacc[0][di] = c0; oacc[1][di] = c1;
+    }
+    ASTAMP(5);
+  };
+
+  if (ntiles > 0) gload(0);
+  const int nfull = kend / BKV;                     // tiles with all 64 keys valid
+  for (int t = 0; t < nfull; ++t) tile(t, t + 1 < ntiles, std::false_type{});
+  if (nfull < ntiles) tile(nfull, false, std::true_type{});
+
+  // finish: lane holds query q0 + 16 g + (lane & 15), channels di*16 + 4*g4 + r
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    float l = l_run[g];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const int qi = q0 + 16 * g + (lane & 15);
+    if (qi < a.Tq) {
+      const float inv = (l > 0.f ? 1.f / l : 0.f) * sc.iv;
+      float* og = a.o + ((long)b * a.Tq + qi) * a.C + h * HDP;
+#pragma unroll
+      for (int di = 0; di < 4; ++di)
+        *reinterpret_cast<float4*>(og + di * 16 + g4 * 4) =
+            make_float4(oacc[g][di][0] * inv, oacc[g][di][1] * inv, oacc[g][di][2] * inv, oacc[g][di][3] * inv);
+      if (a.lse && g4 == 0) a.lse[(long)bh * a.Tq + qi] = 0.69314718055994530942f * (m_run[g] + __builtin_amdgcn_logf(l) - 15.f);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dBias)
 template <int HDP, int NP, bool F16, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
@@ -633,6 +895,398 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
       const int d = di * 16 + (lane >> 4) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) if (d + r < a.hd) g[d + r] = dqacc[di][r] * (a.scale * ds_unscale * sc.ik);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward dQ, hd = 64 fast path
+// Same conditions and the same ideas as attn_fwd64_kernel (32 queries per wave, exp2-domain softmax with every scale
+// folded into one FMA, dS kept in registers as the B fragments of the dQ product, interior tiles without mask code), plus:
+// the K tile is kept in LDS ONCE, natural [key][d] with a row stride of 80 elements (40 dwords = 8 mod 64 banks), and
+// read both ways -- 16-byte fragment reads for S^T = K Q^T, and gfx950's transposing ds_read_b64_tr_b16 for the K^T
+// operand of dQ^T += K^T dS^T (lane 4q+p of a 16-lane group points at key row q / channels 4p..4p+3 and receives channel
+// i's four keys; the two reads of a fragment take keys 32 ks + 4 g4 + {0..3} and + 16, the order dS sits in the
+// registers).  No transposed K planes, no transposed tile in LDS.
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs a) {
+  constexpr int HDP = 64, BKV = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);          // [2 parts][64 keys][RS64]
+  __bf16* sV = sK + 2 * PL64;                                 // [2 parts][64 keys][RS64]
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bh = b * a.H + h;
+  const int q0 = blockIdx.x * F64_Q + wave * 32;
+  const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
+  const int kend = len < a.Tk ? len : a.Tk;
+  const int ntiles = (kend + BKV - 1) / BKV;
+  const long row_bh = (long)bh * a.Tq;
+  const AttnScales sc = *a.sc;
+  const float c2 = a.scale * sc.iq * sc.ik * 1.44269504088896340736f;      // log2-domain score = acc * c2
+  const float ds_unscale = DS_INV * sc.ido * sc.iv;                         // dS = dS' * this
+  const __bf16* knb = a.kn.p + (long)bh * a.kn.batch_stride;
+  const __bf16* vnb = a.vn.p + (long)bh * a.vn.batch_stride;
+  const int g4 = lane >> 4;
+  const int fbn = (lane & 15) * RS64 + g4 * 8;                          // natural fragment: row lane & 15, chunk g4 (+ 4 ks)
+  const int fbt = (4 * g4 + ((lane & 15) >> 2)) * RS64 + 4 * (lane & 3);   // transposing fragment (see above)
+
+  QFrag<HDP, 2> qf[2], dof[2];
+  float lse2[2], dlt[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    load_qfrag<HDP, 2>(qf[g], a.qn, a.qn.p + (long)bh * a.qn.batch_stride, q0 + 16 * g, lane);
+    load_qfrag<HDP, 2>(dof[g], a.don, a.don.p + (long)bh * a.don.batch_stride, q0 + 16 * g, lane);
+    const int qi = q0 + 16 * g + (lane & 15);
+    // P * 2^-22 = exp2(acc * c2 - lse2): natural-log lse to the log2 domain, the fp16 range shift of dS folded in
+    lse2[g] = qi < a.Tq ? a.lse[row_bh + qi] * 1.44269504088896340736f + 22.f : 0.f;
+    // delta_i = dO_i . O_i in exact fp32 (lane group g4 covers channels ks*32 + 8 g4 .. +7); also left for attn_bwd_dkdv
+    float delta_i = 0.f;
+    if (qi < a.Tq) {
+      const float* po = a.o_in + ((long)b * a.Tq + qi) * a.C + h * HDP;
+      const float* pg = a.dout + ((long)b * a.Tq + qi) * a.C + h * HDP;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int d = ks * 32 + g4 * 8 + hh * 4;
+          const float4 x = *reinterpret_cast<const float4*>(po + d), y = *reinterpret_cast<const float4*>(pg + d);
+          delta_i += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+    }
+    delta_i += __shfl_xor(delta_i, 16, 64);
+    delta_i += __shfl_xor(delta_i, 32, 64);
+    if (g4 == 0 && qi < a.Tq) a.delta[row_bh + qi] = delta_i;
+    dlt[g] = (delta_i * sc.sdo) * sc.sv;                   // plane units; never form sdO * sV (see attn_bwd_dq_kernel)
+  }
+
+  f32x4 dqacc[2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dqacc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: thread owns chunks (row = tid >> 3 (+32), 16-byte chunk c = tid & 7) of the K and the V tile
+  bf16x8 stK[2][2], stV[2][2];
+  const int srow = tid >> 3, sc8 = tid & 7;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int kr = k0 + srow + 32 * i;
+      kr = kr < a.kn.rows ? kr : a.kn.rows - 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        stK[q][i] = *reinterpret_cast<const bf16x8*>(knb + q * a.kn.part_stride + (long)kr * HDP + sc8 * 8);
+        stV[q][i] = *reinterpret_cast<const bf16x8*>(vnb + q * a.vn.part_stride + (long)kr * HDP + sc8 * 8);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (srow + 32 * i) * RS64 + sc8 * 8;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<bf16x8*>(sK + q * PL64 + o) = stK[q][i];
+        *reinterpret_cast<bf16x8*>(sV + q * PL64 + o) = stV[q][i];
+      }
+    }
+  };
+  const f32x2 c2v = {c2, c2};
+
+  auto tile = [&](int t, bool more, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int k0 = t * BKV;
+    __syncthreads();                                // previous tile fully consumed
+    lstore();
+    __syncthreads();
+    if (more) gload(k0 + BKV);
+
+    bf16x8 dsf[2][2][2];                            // [group][32-key half][part]: dS^T B fragments, built in registers
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      f32x4 s[2][2], dp[2][2];                      // [group][16-key block bb of this half]
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int mi = 2 * kh + bb;
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int o = fbn + mi * 16 * RS64 + ks * 32;
+          const f16x8 k0h = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(sK + o));
+          const f16x8 k1h = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(sK + PL64 + o));
+          const f16x8 v0h = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(sV + o));
+          const f16x8 v1h = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(sV + PL64 + o));
+          const f16x8 qa0 = __builtin_bit_cast(f16x8, qf[0].f[ks][0]), qa1 = __builtin_bit_cast(f16x8, qf[0].f[ks][1]);
+          const f16x8 qb0 = __builtin_bit_cast(f16x8, qf[1].f[ks][0]), qb1 = __builtin_bit_cast(f16x8, qf[1].f[ks][1]);
+          const f16x8 oa0 = __builtin_bit_cast(f16x8, dof[0].f[ks][0]), oa1 = __builtin_bit_cast(f16x8, dof[0].f[ks][1]);
+          const f16x8 ob0 = __builtin_bit_cast(f16x8, dof[1].f[ks][0]), ob1 = __builtin_bit_cast(f16x8, dof[1].f[ks][1]);
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, qa0, s0, 0, 0, 0);      // S^T  = K Q^T
+          s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, qb0, s1, 0, 0, 0);
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1h, oa0, d0, 0, 0, 0);      // dP^T = V dO^T
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1h, ob0, d1, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qa1, s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qb1, s1, 0, 0, 0);
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, oa1, d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, ob1, d1, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qa0, s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qb0, s1, 0, 0, 0);
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, oa0, d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, ob0, d1, 0, 0, 0);
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + mi * 16 + g4 * 4 + r >= kend) { s0[r] = -INFINITY; s1[r] = -INFINITY; }
+        }
+        s[0][bb] = s0; s[1][bb] = s1; dp[0][bb] = d0; dp[1][bb] = d1;
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x2 lv = {-lse2[g], -lse2[g]}, dv = {-dlt[g], -dlt[g]};
+        u32x4 h0, h1;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 sv = {s[g][e >> 2][e & 3], s[g][e >> 2][(e & 3) + 1]};
+          const f32x2 pv = {dp[g][e >> 2][e & 3], dp[g][e >> 2][(e & 3) + 1]};
+          const f32x2 arg = sv * c2v + lv;                 // v_pk_fma_f32
+          const f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};      // P * 2^-22
+          const f32x2 d = p * (pv + dv);                   // dS' = P (dP - delta) 2^-22, |dS'| < 2^15
+          const f16x2 hp = {(_Float16)d[0], (_Float16)d[1]};
+          const uint32_t hpu = __builtin_bit_cast(uint32_t, hp);
+          uint32_t lo;
+          asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hpu), "v"(d[0]));
+          asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hpu), "v"(d[1]));
+          h0[e >> 1] = hpu;
+          h1[e >> 1] = lo;
+        }
+        dsf[g][kh][0] = __builtin_bit_cast(bf16x8, h0);
+        dsf[g][kh][1] = __builtin_bit_cast(bf16x8, h1);
+      }
+    }
+    // dQ^T[d][q] += K^T dS^T, K^T fragments by transposing reads of the natural tile
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+      for (int di = 0; di < 4; ++di) {
+        const int o = fbt + kh * 32 * RS64 + di * 16;
+        const f16x8 k0h = __builtin_bit_cast(f16x8, tr_frag64(sK + o)), k1h = __builtin_bit_cast(f16x8, tr_frag64(sK + PL64 + o));
+        const f16x8 a0 = __builtin_bit_cast(f16x8, dsf[0][kh][0]), a1 = __builtin_bit_cast(f16x8, dsf[0][kh][1]);
+        const f16x8 b0 = __builtin_bit_cast(f16x8, dsf[1][kh][0]), b1 = __builtin_bit_cast(f16x8, dsf[1][kh][1]);
+        f32x4 c0 = dqacc[0][di], c1 = dqacc[1][di];
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, a0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, b0, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, a1, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, b1, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, a0, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, b0, c1, 0, 0, 0);
+        dqacc[0][di] = c0; dqacc[1][di] = c1;
+      }
+    }
+  };
+
+  if (ntiles > 0) gload(0);
+  const int nfull = kend / BKV;
+  for (int t = 0; t < nfull; ++t) tile(t, t + 1 < ntiles, std::false_type{});
+  if (nfull < ntiles) tile(nfull, false, std::true_type{});
+
+  const float oscale = a.scale * ds_unscale * sc.ik;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int qi = q0 + 16 * g + (lane & 15);
+    if (qi < a.Tq) {
+      float* gq = a.dq + ((long)b * a.Tq + qi) * a.C + h * HDP;
+#pragma unroll
+      for (int di = 0; di < 4; ++di)
+        *reinterpret_cast<float4*>(gq + di * 16 + g4 * 4) =
+            make_float4(dqacc[g][di][0] * oscale, dqacc[g][di][1] * oscale, dqacc[g][di][2] * oscale, dqacc[g][di][3] * oscale);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward dK / dV, hd = 64 fast path
+// One workgroup per (b, h, 64 keys); a wave owns 16 keys for everything: its K and V fragments stay in registers for
+// the whole kernel, S = Q K^T and dP = dO V^T for a 64-query tile leave lane (key, g4) with queries 16 mi + 4 g4 + r,
+// which is (with the contraction index enumerated as in attn_fwd64_kernel) exactly the B fragment of
+// dV^T += dO^T P and dK^T += Q^T dS: P and dS never leave the registers.  The Q and dO tiles sit in LDS once,
+// natural layout (row stride 80), read by 16-byte fragment reads for S / dP and by the transposing ds_read_b64_tr_b16
+// for the dO^T / Q^T operands -- no transposed planes of q and dO are packed for this path.
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArgs a) {
+  constexpr int HDP = 64, BQ = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);          // [2 parts][64 q][RS64]
+  __bf16* sdO = sQ + 2 * PL64;                                // [2 parts][64 q][RS64]
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bh = b * a.H + h;
+  const int k0 = blockIdx.x * 64;
+  const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
+  const int kend = len < a.Tk ? len : a.Tk;
+  const long row_bh = (long)bh * a.Tq;
+  const AttnScales sc = *a.sc;
+  const float c2 = a.scale * sc.iq * sc.ik * 1.44269504088896340736f;      // log2-domain score = acc * c2
+  const __bf16* qnb = a.qn.p + (long)bh * a.qn.batch_stride;
+  const __bf16* donb = a.don.p + (long)bh * a.don.batch_stride;
+  const int g4 = lane >> 4;
+  const int fbn = (lane & 15) * RS64 + g4 * 8;
+  const int fbt = (4 * g4 + ((lane & 15) >> 2)) * RS64 + 4 * (lane & 3);
+  const int key = k0 + wave * 16 + (lane & 15);
+  const float koff = key < kend ? 0.f : -INFINITY;       // a masked key: every probability of this lane is exp2(-inf) = 0
+
+  QFrag<HDP, 2> kf, vf;                                     // B fragments of this wave's 16 keys (rows >= Tk read as zero)
+  load_qfrag<HDP, 2>(kf, a.kn, a.kn.p + (long)bh * a.kn.batch_stride, k0 + wave * 16, lane);
+  load_qfrag<HDP, 2>(vf, a.vn, a.vn.p + (long)bh * a.vn.batch_stride, k0 + wave * 16, lane);
+
+  f32x4 dvacc[4], dkacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { dvacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dkacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // staging: thread owns chunks (row = tid >> 3 (+32), 16-byte chunk c = tid & 7) of the Q and the dO tile; query rows
+  // >= Tq are ZERO (their probabilities are garbage-but-finite and must meet zeros in dV / dK)
+  bf16x8 stQ[2][2], stO[2][2];
+  const int srow = tid >> 3, sc8 = tid & 7;
+  auto gload = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qr = q0 + srow + 32 * i;
+      const bool ok = qr < a.Tq;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bf16x8 z = {};
+        stQ[q][i] = ok ? *reinterpret_cast<const bf16x8*>(qnb + q * a.qn.part_stride + (long)qr * HDP + sc8 * 8) : z;
+        stO[q][i] = ok ? *reinterpret_cast<const bf16x8*>(donb + q * a.don.part_stride + (long)qr * HDP + sc8 * 8) : z;
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (srow + 32 * i) * RS64 + sc8 * 8;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<bf16x8*>(sQ + q * PL64 + o) = stQ[q][i];
+        *reinterpret_cast<bf16x8*>(sdO + q * PL64 + o) = stO[q][i];
+      }
+    }
+  };
+  const f32x2 c2v = {c2, c2};
+  constexpr float T37 = 7.2759576141834259e-12f;           // 2^-37: dS' = (P 2^15) ((dP - delta) 2^-37) = dS 2^-22 in plane units
+  const f32x2 t37v = {T37, T37};
+  const f16x8 k0h[2] = {__builtin_bit_cast(f16x8, kf.f[0][0]), __builtin_bit_cast(f16x8, kf.f[1][0])};
+  const f16x8 k1h[2] = {__builtin_bit_cast(f16x8, kf.f[0][1]), __builtin_bit_cast(f16x8, kf.f[1][1])};
+  const f16x8 v0h[2] = {__builtin_bit_cast(f16x8, vf.f[0][0]), __builtin_bit_cast(f16x8, vf.f[1][0])};
+  const f16x8 v1h[2] = {__builtin_bit_cast(f16x8, vf.f[0][1]), __builtin_bit_cast(f16x8, vf.f[1][1])};
+
+  const int nq = k0 < kend ? (a.Tq + BQ - 1) / BQ : 0;     // every key of this tile masked: the gradients are zero
+  if (nq > 0) gload(0);
+  for (int t = 0; t < nq; ++t) {
+    const int q0 = t * BQ;
+    __syncthreads();                                // previous tile fully consumed
+    lstore();
+    __syncthreads();
+    if (t + 1 < nq) gload(q0 + BQ);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {                // 32 queries at a time: one k-step of the dV / dK products
+      // lse and delta of this lane's 8 queries (16 bb + 4 g4 + r of this half); queries >= Tq: 0 (see gload)
+      float4 ls[2], dl[2];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int qi = q0 + 32 * kh + 16 * bb + 4 * g4;
+        if (qi + 4 <= a.Tq) {
+          ls[bb] = *reinterpret_cast<const float4*>(a.lse + row_bh + qi);
+          dl[bb] = *reinterpret_cast<const float4*>(a.delta + row_bh + qi);
+        } else {
+          float l4[4], d4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            l4[r] = qi + r < a.Tq ? a.lse[row_bh + qi + r] : 0.f;
+            d4[r] = qi + r < a.Tq ? a.delta[row_bh + qi + r] : 0.f;
+          }
+          ls[bb] = make_float4(l4[0], l4[1], l4[2], l4[3]);
+          dl[bb] = make_float4(d4[0], d4[1], d4[2], d4[3]);
+        }
+      }
+      f32x4 s[2], dp[2];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int mi = 2 * kh + bb;
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, d0 = s0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int o = fbn + mi * 16 * RS64 + ks * 32;
+          const f16x8 q0h = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(sQ + o));
+          const f16x8 q1h = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(sQ + PL64 + o));
+          const f16x8 o0h = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(sdO + o));
+          const f16x8 o1h = __builtin_bit_cast(f16x8, *reinterpret_cast<const bf16x8*>(sdO + PL64 + o));
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q1h, k0h[ks], s0, 0, 0, 0);      // S  = Q K^T
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(o1h, v0h[ks], d0, 0, 0, 0);      // dP = dO V^T
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0h, k1h[ks], s0, 0, 0, 0);
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(o0h, v1h[ks], d0, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0h, k0h[ks], s0, 0, 0, 0);
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(o0h, v0h[ks], d0, 0, 0, 0);
+        }
+        s[bb] = s0; dp[bb] = d0;
+      }
+      u32x4 p0, p1, e0, e1;                         // fp16 x2 parts of P * 2^15 and of dS'
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const int bb = e >> 2, r = e & 3;
+        const float la = r == 0 ? ls[bb].x : ls[bb].z, lb = r == 0 ? ls[bb].y : ls[bb].w;
+        const float da = r == 0 ? dl[bb].x : dl[bb].z, db = r == 0 ? dl[bb].y : dl[bb].w;
+        // P 2^15 = exp2(acc c2 - lse log2(e) + 15 [+ -inf for a masked key])
+        const f32x2 lv = {__builtin_fmaf(la, -1.44269504088896340736f, 15.f) + koff, __builtin_fmaf(lb, -1.44269504088896340736f, 15.f) + koff};
+        const f32x2 sv = {s[bb][r], s[bb][r + 1]};
+        const f32x2 arg = sv * c2v + lv;
+        const f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+        // (dP - delta) 2^-37, delta brought to plane units one scale at a time (see attn_bwd_dq_kernel)
+        const f32x2 dv = {(da * sc.sdo) * sc.sv, (db * sc.sdo) * sc.sv};
+        const f32x2 pv = {dp[bb][r], dp[bb][r + 1]};
+        const f32x2 d = p * ((pv - dv) * t37v);
+        const f16x2 hp = {(_Float16)p[0], (_Float16)p[1]}, hd = {(_Float16)d[0], (_Float16)d[1]};
+        const uint32_t hpu = __builtin_bit_cast(uint32_t, hp), hdu = __builtin_bit_cast(uint32_t, hd);
+        uint32_t lp, ld;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hpu), "v"(p[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hpu), "v"(p[1]));
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ld) : "v"(hdu), "v"(d[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ld) : "v"(hdu), "v"(d[1]));
+        p0[e >> 1] = hpu; p1[e >> 1] = lp; e0[e >> 1] = hdu; e1[e >> 1] = ld;
+      }
+      const f16x8 pb0 = __builtin_bit_cast(f16x8, p0), pb1 = __builtin_bit_cast(f16x8, p1);
+      const f16x8 sb0 = __builtin_bit_cast(f16x8, e0), sb1 = __builtin_bit_cast(f16x8, e1);
+      // dV^T[d][key] += dO^T[d][q] P[q][key] ; dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+      for (int di = 0; di < 4; ++di) {
+        const int o = fbt + kh * 32 * RS64 + di * 16;
+        const f16x8 o0h = __builtin_bit_cast(f16x8, tr_frag64(sdO + o)), o1h = __builtin_bit_cast(f16x8, tr_frag64(sdO + PL64 + o));
+        const f16x8 q0h = __builtin_bit_cast(f16x8, tr_frag64(sQ + o)), q1h = __builtin_bit_cast(f16x8, tr_frag64(sQ + PL64 + o));
+        f32x4 cv = dvacc[di], ck = dkacc[di];
+        cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(o1h, pb0, cv, 0, 0, 0);
+        ck = __builtin_amdgcn_mfma_f32_16x16x32_f16(q1h, sb0, ck, 0, 0, 0);
+        cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(o0h, pb1, cv, 0, 0, 0);
+        ck = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0h, sb1, ck, 0, 0, 0);
+        cv = __builtin_amdgcn_mfma_f32_16x16x32_f16(o0h, pb0, cv, 0, 0, 0);
+        ck = __builtin_amdgcn_mfma_f32_16x16x32_f16(q0h, sb0, ck, 0, 0, 0);
+        dvacc[di] = cv; dkacc[di] = ck;
+      }
+    }
+  }
+
+  // lane: key = k0 + wave*16 + (lane & 15), channels di*16 + 4 g4 + r
+  if (key < a.Tk) {
+    float* gk = a.dk + ((long)b * a.Tk + key) * a.C + h * HDP;
+    float* gv = a.dv + ((long)b * a.Tk + key) * a.C + h * HDP;
+    const float ksc = a.scale * (DS_INV * sc.ido * sc.iv) * sc.iq, vsc = P_INV * sc.ido;
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int d = di * 16 + g4 * 4;
+      *reinterpret_cast<float4*>(gk + d) = make_float4(dkacc[di][0] * ksc, dkacc[di][1] * ksc, dkacc[di][2] * ksc, dkacc[di][3] * ksc);
+      *reinterpret_cast<float4*>(gv + d) = make_float4(dvacc[di][0] * vsc, dvacc[di][1] * vsc, dvacc[di][2] * vsc, dvacc[di][3] * vsc);
     }
   }
 }
@@ -881,8 +1535,28 @@ void set_lds(K kernel, size_t bytes) {
   (void)hipGetLastError();
 }
 
+bool fwd64_enabled();
+// the MQ blocks' attention: hd = 64, fp16 x2 planes, prefix key mask, no bias / dBias, no dropout -> the *64 kernels
+inline bool fast64(const AttnArgs& a, int precision) {
+  return precision == 3 && a.hd == 64 && !a.bias && !a.dbias && (a.mode == 0 || a.mode == 2) && !a.drop_thresh && fwd64_enabled();
+}
+bool fwd64_enabled() { static const bool on = [] { const char* e = getenv("VILCO_ATTN_FAST"); return !(e && e[0] == '0'); }(); return on; }
+
 template <int HDP, int NP, bool F16 = false>
 int launch_fwd(const AttnArgs& a, hipStream_t s) {
+  if constexpr (HDP == 64 && NP == 2 && F16) {
+    if (fast64(a, 3)) {
+      size_t lds = 2 * 2 * PL64 * sizeof(__bf16);
+#ifdef VILCO_LAB_ATTN
+      if (const char* e = getenv("VILCO_LAB_ATTN_LDS")) {       // lab: pad the LDS request to limit workgroups per CU
+        lds = (size_t)atoi(e);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      }
+#endif
+      hipLaunchKernelGGL(attn_fwd64_kernel, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), lds, s, a);
+      return vilco_launch_status();
+    }
+  }
   static const bool once = [] {
     set_lds(&attn_fwd_kernel<HDP, NP, F16, false>, fwd_lds<HDP, NP>());
     set_lds(&attn_fwd_kernel<HDP, NP, F16, true>, fwd_lds<HDP, NP>());
@@ -910,7 +1584,17 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
   (void)once;
   dim3 gq((a.Tq + 63) / 64, a.H, a.B), gk((a.Tk + 63) / 64, a.H, a.B);
   const size_t lq = dq_lds<HDP, NP>(), lk = dkdv_lds<HDP, NP>();
-  if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16, true>), gq, dim3(ATT_THREADS), lq, s, a);
+  bool fast = false;
+  if constexpr (HDP == 64 && NP == 2 && F16)
+    fast = fast64(a, 3);
+  if (fast) {
+    if constexpr (HDP == 64 && NP == 2 && F16) {
+      constexpr size_t l64 = 2 * 2 * PL64 * sizeof(__bf16);
+      hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), l64, s, a);
+      hipLaunchKernelGGL(attn_bwd_dkdv64_kernel, gk, dim3(ATT_THREADS), l64, s, a);
+      return vilco_launch_status();
+    }
+  } else if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16, true>), gq, dim3(ATT_THREADS), lq, s, a);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16, false>), gq, dim3(ATT_THREADS), lq, s, a);
   const bool dr = a.drop_thresh != 0;
   if (a.bias && dr) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NP, F16, true, true>), gk, dim3(ATT_THREADS), lk, s, a);
@@ -1040,6 +1724,12 @@ void flush_packs(PackQueue& pq, ScaleWs& sw, bool f16, int NP, int nbatch, hipSt
 
 }  // namespace
 
+#ifdef VILCO_LAB_ATTN
+extern "C" int vilco_lab_attn_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vilco_lab_attn_stamps), sizeof(unsigned long long) * 64 * 8);
+}
+#endif
+
 extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 64 && (hd % 4) == 0; }
 
 extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
@@ -1079,7 +1769,10 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   PackQueue pq;
   a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
   a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
-  a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
+  if (fast64(a, precision))       // the hd = 64 fast kernel reads V from its natural planes (transposing LDS reads)
+    a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
+  else
+    a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
   flush_packs(pq, sw, precision == 3, NP, B * H, s);
   return hd <= 32 ? dispatch<32>(a, precision, false, s) : dispatch<64>(a, precision, false, s);
 }
@@ -1125,13 +1818,17 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   float* so = sw.out;
   __bf16* w = reinterpret_cast<__bf16*>(wsb + ATT_SCALE_BYTES);
   PackQueue pq;
+  // the hd = 64 fast kernels read every operand from its natural planes only (transposing LDS reads)
+  const bool nat_only = fast64(a, precision);
   a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
   a.don = pack_operand(dout, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6, &pq);
-  a.qt = pack_operand(q, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
-  a.dot = pack_operand(dout, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6, &pq);
+  if (!nat_only) {
+    a.qt = pack_operand(q, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
+    a.dot = pack_operand(dout, w, spec_tr(B, H, Tq, hd), true, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6, &pq);
+  }
   a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
   a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
-  a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
+  if (!nat_only) a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
   flush_packs(pq, sw, precision == 3, NP, B * H, s);
   return hd <= 32 ? dispatch<32>(a, precision, true, s) : dispatch<64>(a, precision, true, s);
 }
