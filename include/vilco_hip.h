@@ -216,19 +216,27 @@ int vilco_relshift_bwd(const float* ds, float* dbd, float scale, int32_t B, int3
 /* drop_seed; forward and backward must be given the same (drop_p, drop_seed).                                         */
 /* ------------------------------------------------------------------------------------------ */
 int vilco_attn_supported(int32_t hd);
-/* workspace = bf16 operand planes (q, k natural; v transposed), built inside the call by the pack kernels */
+/* Output amax partials.  The hd = 64 / fp16 x2 / prefix-mask / no-bias / no-dropout kernels can leave max|x| partials of
+ * their outputs (one float per workgroup) for the operand pack of the next product (vilco_pack_item.amax), which then
+ * skips its amax launch.  Returns how many floats the o / dq buffer (key_side = 0, T = Tq) or the dk / dv buffers
+ * (key_side = 1, T = Tk) must hold, or 0 when this configuration does not emit them (pass null then). */
+int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_t hd, int32_t mode, int32_t precision,
+                              int32_t has_bias, float drop_p, int32_t key_side);
+/* workspace = 16-bit operand planes (q, k natural; v transposed, or natural on the hd = 64 fast path), built inside
+ * the call by the pack kernels; o_amax / d*_amax: see vilco_attn_amax_parts (null = not wanted) */
 size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
                    int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
-                   uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
+                   uint32_t drop_seed, float* o_amax, void* workspace, size_t workspace_bytes, void* stream);
 size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 /* dq/dk/dv are overwritten; dbias (optional, [B,H,Tq,Tk]) receives dS.  Deterministic (no atomics). */
 int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, const float* o, const float* lse, const float* dout,
                    float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
                    int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
-                   uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
+                   uint32_t drop_seed, float* dq_amax, float* dk_amax, float* dv_amax, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Elementwise / reduction glue of TransformerBlock.forward (blocks.py:561-593).                 */

@@ -84,11 +84,12 @@ SIGNATURES = {
     "vilco_relshift_bwd": (C.c_int, [c_fp, c_fp, f32, i32, i32, i32, c_fp]),
     "vilco_attn_supported": (C.c_int, [i32]),
     "vilco_attn_fwd_workspace": (sz, [i32, i32, i32, i32, i32, i32]),
+    "vilco_attn_amax_parts": (i32, [i32, i32, i32, i32, i32, i32, i32, f32, i32]),
     "vilco_attn_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, i32, i32, i32, f32,
-                                 C.c_uint32, c_fp, sz, c_fp]),
+                                 C.c_uint32, c_fp, c_fp, sz, c_fp]),
     "vilco_attn_bwd_workspace": (sz, [i32, i32, i32, i32, i32, i32]),
     "vilco_attn_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32,
-                                 i32, i32, i32, f32, i32, i32, i32, f32, C.c_uint32, c_fp, sz, c_fp]),
+                                 i32, i32, i32, f32, i32, i32, i32, f32, C.c_uint32, c_fp, c_fp, c_fp, c_fp, sz, c_fp]),
     "vilco_scale_add_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
     "vilco_colsum_workspace": (sz, [i64, i32]),
     "vilco_scale_add_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, i32,

@@ -195,6 +195,9 @@ struct AttnArgs {
   // dropout on the attention probabilities (modeling_xlnet_x.py:308, blocks.py:226): keep iff hash(seed, (bh*Tq+i)*Tk+j) >= thresh
   uint32_t drop_thresh, drop_seed;
   float drop_inv_keep;
+  // optional max|x| partials of the outputs (one per workgroup), left for the operand pack of the next product
+  // (vilco_pack_item.amax); written by the hd = 64 fast kernels only (vilco_attn_amax_parts)
+  float* am_o; float* am_dq; float* am_dk; float* am_dv;
 };
 
 // registers holding the B-operand fragments of this wave's 16 query rows (all k-steps, all parts)
@@ -474,6 +477,16 @@ __device__ __forceinline__ f32x4 mfma3h(const bf16x8 (&a)[2], const bf16x8 (&b)[
 }
 
 constexpr int F64_Q = 128;       // queries per workgroup of the fast path
+
+// max over the workgroup of a per-thread value -> out[linear block id] (smem: the kernel's LDS, free again after a barrier)
+__device__ __forceinline__ void block_amax_out(float m, float* out, float* smem_f) {
+  m = wave_max(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem_f[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    out[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = fmaxf(fmaxf(smem_f[0], smem_f[1]), fmaxf(smem_f[2], smem_f[3]));
+}
 constexpr int RS64 = 80;                 // LDS row stride (elements) of a natural [64 rows][64 d] tile
 constexpr int PL64 = 64 * RS64;          // elements per part
 
@@ -692,6 +705,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
   if (nfull < ntiles) tile(nfull, false, std::true_type{});
 
   // finish: lane holds query q0 + 16 g + (lane & 15), channels di*16 + 4*g4 + r
+  float am = 0.f;
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     float l = l_run[g];
@@ -702,12 +716,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
       const float inv = (l > 0.f ? 1.f / l : 0.f) * sc.iv;
       float* og = a.o + ((long)b * a.Tq + qi) * a.C + h * HDP;
 #pragma unroll
-      for (int di = 0; di < 4; ++di)
-        *reinterpret_cast<float4*>(og + di * 16 + g4 * 4) =
-            make_float4(oacc[g][di][0] * inv, oacc[g][di][1] * inv, oacc[g][di][2] * inv, oacc[g][di][3] * inv);
+      for (int di = 0; di < 4; ++di) {
+        const float4 v = make_float4(oacc[g][di][0] * inv, oacc[g][di][1] * inv, oacc[g][di][2] * inv, oacc[g][di][3] * inv);
+        *reinterpret_cast<float4*>(og + di * 16 + g4 * 4) = v;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
       if (a.lse && g4 == 0) a.lse[(long)bh * a.Tq + qi] = 0.69314718055994530942f * (m_run[g] + __builtin_amdgcn_logf(l) - 15.f);
     }
   }
+  if (a.am_o) block_amax_out(am, a.am_o, reinterpret_cast<float*>(smem_raw));
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dBias)
@@ -1093,17 +1110,21 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
   if (nfull < ntiles) tile(nfull, false, std::true_type{});
 
   const float oscale = a.scale * ds_unscale * sc.ik;
+  float am = 0.f;
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const int qi = q0 + 16 * g + (lane & 15);
     if (qi < a.Tq) {
       float* gq = a.dq + ((long)b * a.Tq + qi) * a.C + h * HDP;
 #pragma unroll
-      for (int di = 0; di < 4; ++di)
-        *reinterpret_cast<float4*>(gq + di * 16 + g4 * 4) =
-            make_float4(dqacc[g][di][0] * oscale, dqacc[g][di][1] * oscale, dqacc[g][di][2] * oscale, dqacc[g][di][3] * oscale);
+      for (int di = 0; di < 4; ++di) {
+        const float4 v = make_float4(dqacc[g][di][0] * oscale, dqacc[g][di][1] * oscale, dqacc[g][di][2] * oscale, dqacc[g][di][3] * oscale);
+        *reinterpret_cast<float4*>(gq + di * 16 + g4 * 4) = v;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
     }
   }
+  if (a.am_dq) block_amax_out(am, a.am_dq, reinterpret_cast<float*>(smem_raw));
 }
 
 // ------------------------------------------------------------------------------------------ backward dK / dV, hd = 64 fast path
@@ -1278,6 +1299,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
   }
 
   // lane: key = k0 + wave*16 + (lane & 15), channels di*16 + 4 g4 + r
+  float amk = 0.f, amv = 0.f;
   if (key < a.Tk) {
     float* gk = a.dk + ((long)b * a.Tk + key) * a.C + h * HDP;
     float* gv = a.dv + ((long)b * a.Tk + key) * a.C + h * HDP;
@@ -1285,10 +1307,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int d = di * 16 + g4 * 4;
-      *reinterpret_cast<float4*>(gk + d) = make_float4(dkacc[di][0] * ksc, dkacc[di][1] * ksc, dkacc[di][2] * ksc, dkacc[di][3] * ksc);
-      *reinterpret_cast<float4*>(gv + d) = make_float4(dvacc[di][0] * vsc, dvacc[di][1] * vsc, dvacc[di][2] * vsc, dvacc[di][3] * vsc);
+      const float4 vk = make_float4(dkacc[di][0] * ksc, dkacc[di][1] * ksc, dkacc[di][2] * ksc, dkacc[di][3] * ksc);
+      const float4 vv = make_float4(dvacc[di][0] * vsc, dvacc[di][1] * vsc, dvacc[di][2] * vsc, dvacc[di][3] * vsc);
+      *reinterpret_cast<float4*>(gk + d) = vk;
+      *reinterpret_cast<float4*>(gv + d) = vv;
+      amk = fmaxf(fmaxf(amk, fmaxf(fabsf(vk.x), fabsf(vk.y))), fmaxf(fabsf(vk.z), fabsf(vk.w)));
+      amv = fmaxf(fmaxf(amv, fmaxf(fabsf(vv.x), fabsf(vv.y))), fmaxf(fabsf(vv.z), fabsf(vv.w)));
     }
   }
+  if (a.am_dk) block_amax_out(amk, a.am_dk, reinterpret_cast<float*>(smem_raw));
+  if (a.am_dv) block_amax_out(amv, a.am_dv, reinterpret_cast<float*>(smem_raw));
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
@@ -1732,6 +1760,16 @@ extern "C" int vilco_lab_attn_read(unsigned long long* out) {
 
 extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 64 && (hd % 4) == 0; }
 
+extern "C" int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_t hd, int32_t mode, int32_t precision,
+                                         int32_t has_bias, float drop_p, int32_t key_side) {
+  AttnArgs a = {};
+  a.hd = hd; a.mode = mode; a.drop_thresh = vilco_drop_threshold_host(drop_p);
+  if (has_bias) a.bias = reinterpret_cast<const float*>(&a);      // only its nullness is looked at
+  if (B <= 0 || H <= 0 || T <= 0 || !fast64(a, precision)) return 0;
+  const long n = (long)((T + (key_side ? 63 : F64_Q - 1)) / (key_side ? 64 : F64_Q)) * H * B;
+  return n <= 8192 ? (int32_t)n : 0;
+}
+
 extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
   const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
   return (size_t)(planes_bytes(spec_nat(B, H, Tq, HDP), NP) + planes_bytes(spec_nat(B, H, Tk, HDP), NP) +
@@ -1741,7 +1779,7 @@ extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int
 extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                               const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
                               int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
-                              uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream) {
+                              uint32_t drop_seed, float* o_amax, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision, window);
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
@@ -1756,6 +1794,8 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.lse = lse; a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode; a.window = window;
   a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
+  if (o_amax && !fast64(a, precision)) return VILCO_ERR_UNSUPPORTED;      // see vilco_attn_amax_parts
+  a.am_o = o_amax;
   unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
   ScaleWs sw;
   if (precision == 3) {
@@ -1789,7 +1829,8 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
                               const int32_t* kv_len, const float* o, const float* lse, const float* dout,
                               float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
                               int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
-                              uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream) {
+                              uint32_t drop_seed, float* dq_amax, float* dk_amax, float* dv_amax, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision, window);
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
@@ -1808,6 +1849,8 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode; a.window = window;
   a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
   a.dout = dout; a.delta = delta; a.o_in = o; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
+  if ((dq_amax || dk_amax || dv_amax) && !fast64(a, precision)) return VILCO_ERR_UNSUPPORTED;      // see vilco_attn_amax_parts
+  a.am_dq = dq_amax; a.am_dk = dk_amax; a.am_dv = dv_amax;
   ScaleWs sw;
   if (precision == 3) {
     const float* const xs[4] = {q, k, v, dout};

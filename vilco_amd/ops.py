@@ -777,6 +777,13 @@ def flash_supported(hd):
     return bool(_lib.load().vilco_attn_supported(int(hd)))
 
 
+def _attn_amax_parts(B, H, T, hd, mode, bias, drop, key_side):
+    """partials the fused kernels leave for the packs of their outputs (0: this configuration does not emit them)"""
+    if not produce_amax:
+        return 0
+    return int(_lib.load().vilco_attn_amax_parts(B, H, T, hd, int(mode), _precision, int(bias is not None), float(drop[0]), key_side))
+
+
 def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode, drop=(0.0, 0), window=0):
     lib = _lib.load()
     B, Tq, Cn = q.shape
@@ -785,9 +792,13 @@ def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode, drop=(0.0, 0), window=0):
     lse = torch.empty(B, H, Tq, dtype=torch.float32, device=q.device)
     nws = lib.vilco_attn_fwd_workspace(B, H, Tq, Tk, Cn // H, _precision)
     ws = _ws(nws, q.device)
+    na = _attn_amax_parts(B, H, Tq, Cn // H, mode, bias, drop, 0)
+    am = torch.empty(na, dtype=torch.float32, device=q.device) if na else None
     _lib.check(lib.vilco_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
                                   lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
-                                  int(drop[1]), ws.data_ptr(), nws, _stream()))
+                                  int(drop[1]), _p(am), ws.data_ptr(), nws, _stream()))
+    if na:
+        _FlashAttention.last_amax = (am, na)
     return o, lse
 
 
@@ -799,16 +810,25 @@ def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, dr
     dbias = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=q.device) if want_dbias else None
     nws = lib.vilco_attn_bwd_workspace(B, H, Tq, Tk, Cn // H, _precision)
     ws = _ws(nws, q.device)
+    nq = 0 if want_dbias else _attn_amax_parts(B, H, Tq, Cn // H, mode, bias, drop, 0)
+    nk = 0 if want_dbias else _attn_amax_parts(B, H, Tk, Cn // H, mode, bias, drop, 1)
+    am = torch.empty(nq + 2 * nk, dtype=torch.float32, device=q.device) if nq and nk else None
+    aq, ak, av = (am[:nq], am[nq:nq + nk], am[nq + nk:]) if am is not None else (None, None, None)
     _lib.check(lib.vilco_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
                                   lse.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                   _p(dbias), B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
-                                  int(drop[1]), ws.data_ptr(), nws, _stream()))
+                                  int(drop[1]), _p(aq), _p(ak), _p(av), ws.data_ptr(), nws, _stream()))
+    if am is not None:
+        _tag_amax(dq, aq, nq)
+        _tag_amax(dk, ak, nk)
+        _tag_amax(dv, av, nk)
     return dq, dk, dv, dbias
 
 
 class _FlashAttention(torch.autograd.Function):
     """fused attention (vilco_attn_fwd / vilco_attn_bwd): scores never reach HBM; backward recomputes P
     from (q, k, lse)."""
+    last_amax = None        # (partials, count) the forward kernel left for the pack of its output, or None
 
     @staticmethod
     def forward(ctx, q, k, v, kv_len, H, scale, mode, drop_p=0.0, window=0):
@@ -833,7 +853,12 @@ def attention(q, k, v, kv_len, n_head, scale=None, mode=MASK_KEYS, drop_p=0.0, w
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1] // n_head)
     if use_flash and flash_supported(q.shape[-1] // n_head):
-        return _FlashAttention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode), float(drop_p), int(window))
+        _FlashAttention.last_amax = None
+        o = _FlashAttention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode), float(drop_p), int(window))
+        if _FlashAttention.last_amax is not None:        # left by the fused kernel for the pack of the output projection
+            _tag_amax(o, *_FlashAttention.last_amax)
+            _FlashAttention.last_amax = None
+        return o
     if mode == MASK_LOCAL:
         raise NotImplementedError("local-window attention needs the fused kernels (head dim <= 64, multiple of 4)")
     if drop_p > 0.0:
