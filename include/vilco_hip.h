@@ -105,6 +105,10 @@ typedef struct vilco_gemm_desc {
   /* the mask of vilco_dropout(p, seed) at element index m*N + n.  Needs ldc == N, batch 1.  0: none.                     */
   float drop_p;
   uint32_t drop_seed;
+  /* optional: the call leaves vilco_gemm_amax_parts(desc) partial maxima of |C| (as stored, after the whole epilogue)  */
+  /* here -- one per workgroup of the kernel that writes C -- for the operand pack of the next product                  */
+  /* (vilco_pack_item.amax), which then needs no pass of its own over C.  NULL: not wanted.                             */
+  float* amax_out;
 } vilco_gemm_desc;
 
 size_t vilco_gemm_workspace(const vilco_gemm_desc* d);
@@ -112,6 +116,8 @@ int vilco_gemm(const vilco_gemm_desc* d, void* stream);
 
 /* Timing of the MFMA kernel alone (not the packs, not the split-K reduce): between begin and end every vilco_gemm   */
 /* brackets its main kernel with HIP events on the caller's stream; end waits for them and returns the sum.          */
+/* floats written to desc->amax_out by vilco_gemm(desc) (depends on the tile / split-K plan); 0: not available */
+int32_t vilco_gemm_amax_parts(const vilco_gemm_desc* desc);
 int vilco_gemm_profile_begin(void);
 int vilco_gemm_profile_end(double* kernel_ms, int64_t* launches);
 /* per-launch records of the last begin/end bracket (measurement tooling, tools/gemm_shapes.py): desc[i*10 + 0..9] =
@@ -222,21 +228,30 @@ int vilco_attn_supported(int32_t hd);
  * (key_side = 1, T = Tk) must hold, or 0 when this configuration does not emit them (pass null then). */
 int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_t hd, int32_t mode, int32_t precision,
                               int32_t has_bias, float drop_p, int32_t key_side);
+/* Input amax partials (precision 3): max|x| partials of q / k / v / dout already on the device, e.g. left by the GEMM   */
+/* that produced them (vilco_gemm_desc.amax_out).  A tensor with a NULL pointer or a count of 0 gets its own amax pass. */
+typedef struct vilco_attn_amax_in {
+  const float* q; int32_t nq;
+  const float* k; int32_t nk;
+  const float* v; int32_t nv;
+  const float* dout; int32_t ndo;       /* backward only */
+} vilco_attn_amax_in;
 /* workspace = 16-bit operand planes (q, k natural; v transposed, or natural on the hd = 64 fast path), built inside
- * the call by the pack kernels; o_amax / d*_amax: see vilco_attn_amax_parts (null = not wanted) */
+ * the call by the pack kernels; amax_in (may be null): see above; o_amax / d*_amax: see vilco_attn_amax_parts (null = not wanted) */
 size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
                    int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
-                   uint32_t drop_seed, float* o_amax, void* workspace, size_t workspace_bytes, void* stream);
+                   uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* o_amax, void* workspace,
+                   size_t workspace_bytes, void* stream);
 size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 /* dq/dk/dv are overwritten; dbias (optional, [B,H,Tq,Tk]) receives dS.  Deterministic (no atomics). */
 int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, const float* o, const float* lse, const float* dout,
                    float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
                    int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
-                   uint32_t drop_seed, float* dq_amax, float* dk_amax, float* dv_amax, void* workspace,
-                   size_t workspace_bytes, void* stream);
+                   uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* dq_amax, float* dk_amax, float* dv_amax,
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Elementwise / reduction glue of TransformerBlock.forward (blocks.py:561-593).                 */

@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("a_planes", c_fp), ("b_planes", c_fp),
         ("band", i32), ("bandT", i32),
         ("drop_p", f32), ("drop_seed", C.c_uint32),
+        ("amax_out", c_fp),
     ]
 
 
@@ -46,6 +47,11 @@ class LossDesc(C.Structure):
                 ("B", i32), ("R", i32), ("C", i32), ("L", i32), ("Nmax", i32),
                 ("center_radius", f32), ("label_smoothing", f32), ("momentum", f32), ("loss_weight", f32),
                 ("al_weight", f32), ("use_al", i32)]
+
+
+class AttnAmaxIn(C.Structure):
+    """Mirror of `vilco_attn_amax_in`."""
+    _fields_ = [("q", c_fp), ("nq", i32), ("k", c_fp), ("nk", i32), ("v", c_fp), ("nv", i32), ("dout", c_fp), ("ndo", i32)]
 
 
 class PackItem(C.Structure):
@@ -61,6 +67,7 @@ SIGNATURES = {
     "vilco_sync_timeouts_read": (C.c_int, []),
     "vilco_gemm_workspace": (sz, [C.POINTER(GemmDesc)]),
     "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "vilco_gemm_amax_parts": (i32, [C.POINTER(GemmDesc)]),
     "vilco_gemm_profile_begin": (C.c_int, []),
     "vilco_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vilco_gemm_profile_records": (C.c_int64, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int64]),
@@ -86,10 +93,11 @@ SIGNATURES = {
     "vilco_attn_fwd_workspace": (sz, [i32, i32, i32, i32, i32, i32]),
     "vilco_attn_amax_parts": (i32, [i32, i32, i32, i32, i32, i32, i32, f32, i32]),
     "vilco_attn_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, i32, i32, i32, f32,
-                                 C.c_uint32, c_fp, c_fp, sz, c_fp]),
+                                 C.c_uint32, C.POINTER(AttnAmaxIn), c_fp, c_fp, sz, c_fp]),
     "vilco_attn_bwd_workspace": (sz, [i32, i32, i32, i32, i32, i32]),
     "vilco_attn_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32,
-                                 i32, i32, i32, f32, i32, i32, i32, f32, C.c_uint32, c_fp, c_fp, c_fp, c_fp, sz, c_fp]),
+                                 i32, i32, i32, f32, i32, i32, i32, f32, C.c_uint32, C.POINTER(AttnAmaxIn), c_fp, c_fp, c_fp, c_fp, sz,
+                                 c_fp]),
     "vilco_scale_add_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
     "vilco_colsum_workspace": (sz, [i64, i32]),
     "vilco_scale_add_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, i32,

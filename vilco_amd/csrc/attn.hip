@@ -1699,6 +1699,7 @@ long planes_bytes(const PlaneSpec& sp, int NP) { return up(sp.elems_per_part * N
 struct ScaleWs {
   float* parts[4] = {nullptr, nullptr, nullptr, nullptr};
   int n[4] = {0, 0, 0, 0};
+  bool ext[4] = {false, false, false, false};     // partials supplied by the caller (vilco_attn_amax_in): no amax pass
   float* out = nullptr;
   AmaxArgs am;
   int nops = 0;
@@ -1717,6 +1718,14 @@ ScaleWs plan_amax(unsigned char* region, const float* const (&x)[4], const int (
     w.n[i] = w.am.op[i].nblocks;
   }
   return w;
+}
+
+void use_external_amax(ScaleWs& sw, const vilco_attn_amax_in* in, int nops) {
+  if (!in) return;
+  const float* p[4] = {in->q, in->k, in->v, in->dout};
+  const int n[4] = {in->nq, in->nk, in->nv, in->ndo};
+  for (int i = 0; i < nops; ++i)
+    if (p[i] && n[i] > 0) { sw.parts[i] = const_cast<float*>(p[i]); sw.n[i] = n[i]; sw.ext[i] = true; }
 }
 
 // all queued packs of one attention call: [amax +] natural packs in one launch, transposing packs in another
@@ -1738,10 +1747,14 @@ void flush_packs(PackQueue& pq, ScaleWs& sw, bool f16, int NP, int nbatch, hipSt
       d.amax = sw.parts[j]; d.inv_scale = sw.out + 2 * j;
       fa[nf] = d; fm[nf] = sw.am.op[j]; ++nf;
     }
+    for (int j = 0; j < sw.nops; ++j) ok = ok && !sw.ext[j];
     if (ok && dispatch_pack_fused(NP, fa, fm, nf, nbatch, s, VILCO_SITE_ATTNPACK)) {
       for (int i = 0; i < pq.nt; ++i) pq.t.a[i].namax = fa[0].namax;      // every operand got gx * nbatch partials
     } else {
-      launch_amax(sw.am, sw.nops, s);
+      AmaxArgs am;
+      int nam = 0;
+      for (int j = 0; j < sw.nops; ++j) if (!sw.ext[j]) am.op[nam++] = sw.am.op[j];
+      if (nam) launch_amax(am, nam, s);
       if (pq.n) dispatch_pack_multi(NP, pq.a, pq.n, s, nbatch);
     }
   } else if (pq.n) {
@@ -1779,7 +1792,8 @@ extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int
 extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* bias,
                               const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
                               int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
-                              uint32_t drop_seed, float* o_amax, void* workspace, size_t workspace_bytes, void* stream) {
+                              uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* o_amax, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision, window);
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
@@ -1802,6 +1816,7 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
     const float* const xs[4] = {q, k, v, nullptr};
     const int Ts[4] = {Tq, Tk, Tk, 0};
     sw = plan_amax(wsb, xs, Ts, 3, B, H * hd);
+    use_external_amax(sw, amax_in, 3);
     a.sc = reinterpret_cast<const AttnScales*>(sw.out);
   }
   float* so = sw.out;
@@ -1829,8 +1844,8 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
                               const int32_t* kv_len, const float* o, const float* lse, const float* dout,
                               float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
                               int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
-                              uint32_t drop_seed, float* dq_amax, float* dk_amax, float* dv_amax, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* dq_amax, float* dk_amax,
+                              float* dv_amax, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision, window);
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
@@ -1856,6 +1871,7 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
     const float* const xs[4] = {q, k, v, dout};
     const int Ts[4] = {Tq, Tk, Tk, Tq};
     sw = plan_amax(wsb, xs, Ts, 4, B, H * hd);
+    use_external_amax(sw, amax_in, 4);
     a.sc = reinterpret_cast<const AttnScales*>(sw.out);
   }
   float* so = sw.out;

@@ -75,6 +75,7 @@ struct GArgs {
   int band, bandT;          // XLNet relative-position band (vilco_gemm_desc.band)
   uint32_t drop_thresh, drop_seed;   // fused output dropout (vilco_gemm_desc.drop_p): keep iff hash(seed, m*N+n) >= thresh
   float drop_inv_keep;
+  float* amax_out;          // optional: max|stored value| per workgroup (vilco_gemm_desc.amax_out)
   Epi e;
 };
 
@@ -83,7 +84,7 @@ __device__ __forceinline__ long row_off(const PlaneOp& o, int r) {
   return (long)(r / o.seqT) * o.seq_stride + (long)(r % o.seqT) * o.row_stride;
 }
 
-__device__ __forceinline__ void store_out(const GArgs& g, long idx, int n, float acc, bool valid) {
+__device__ __forceinline__ float store_out(const GArgs& g, long idx, int n, float acc, bool valid) {
   const Epi& e = g.e;
   float v = e.alpha * acc;
   if (e.bias) v += e.bias[n];
@@ -96,10 +97,11 @@ __device__ __forceinline__ void store_out(const GArgs& g, long idx, int n, float
   if (e.residual && (valid || !e.res_masked)) v += e.residual[idx];
   if (e.beta != 0.f) v += e.beta * g.cfinal[idx];
   g.cfinal[idx] = v;
+  return fabsf(v);
 }
 
 // 4 consecutive columns of one row (vec_out only)
-__device__ __forceinline__ void store_out4(const GArgs& g, long idx, int n, const f32x4& acc, bool valid) {
+__device__ __forceinline__ float store_out4(const GArgs& g, long idx, int n, const f32x4& acc, bool valid) {
   const Epi& e = g.e;
   f32x4 v = acc * e.alpha;
   if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
@@ -121,6 +123,7 @@ __device__ __forceinline__ void store_out4(const GArgs& g, long idx, int n, cons
   if (e.residual && (valid || !e.res_masked)) v += *reinterpret_cast<const f32x4*>(e.residual + idx);
   if (e.beta != 0.f) v += *reinterpret_cast<const f32x4*>(g.cfinal + idx) * e.beta;
   *reinterpret_cast<f32x4*>(g.cfinal + idx) = v;
+  return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
 template <bool F16>
@@ -431,6 +434,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   float* cp = g.c + (partial ? (long)ks * g.split_stride : 0);
   float* stg = reinterpret_cast<float*>(smem_raw) + wave * (16 * EPI_LD);
   const int n = n0 + wn * 64 + (lane & 15) * 4;
+  float am = 0.f;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -451,11 +455,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
           for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[idx + e] = v[e];
       } else {
         const bool valid = g.e.row_len ? (m % g.e.rowT) < g.e.row_len[m / g.e.rowT] : true;
-        if (g.vec_out) store_out4(g, idx, n, v, valid);
+        if (g.vec_out) am = fmaxf(am, store_out4(g, idx, n, v, valid));
         else
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) store_out(g, idx + e, n + e, v[e], valid);
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) am = fmaxf(am, store_out(g, idx + e, n + e, v[e], valid));
       }
+    }
+  }
+  if (g.amax_out && !partial) {     // max|C| of this tile for the operand pack of the next product (one float per workgroup)
+    am = wave_max(am);
+    __syncthreads();                // every wave is done with its staging rows
+    float* red = reinterpret_cast<float*>(smem_raw);
+    if (lane == 0) red[wave] = am;
+    __syncthreads();
+    if (tid == 0) {
+      float m = red[0];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+      g.amax_out[((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m;
     }
   }
   STAMPX(3);
@@ -465,6 +482,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
   const long per = (long)g.M * g.N;
   const long total = per * nz;
+  float am = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int z = (int)(i / per);
     const long mn = i % per;
@@ -475,7 +493,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
     for (int k = 0; k < g.ksplit; ++k) s += g.c[(long)k * g.split_stride + idx];
     bool valid = true;
     if (g.e.row_len) valid = (m % g.e.rowT) < g.e.row_len[m / g.e.rowT];
-    store_out(g, idx, n, s, valid);
+    am = fmaxf(am, store_out(g, idx, n, s, valid));
+  }
+  if (g.amax_out) {
+    __shared__ float red[4];
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) g.amax_out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   }
 }
 
@@ -633,6 +658,24 @@ struct ProfState {
 };
 ProfState& prof() { static ProfState p; return p; }
 }  // namespace
+
+// number of max|C| partials a vilco_gemm call with this descriptor writes to desc->amax_out (0: too many -- do not ask)
+static long amax_out_parts(const vilco_gemm_desc* d, const Plan& p) {
+  const long nz = (long)d->batch_outer * d->batch_inner;
+  if (p.ksplit > 1) {
+    long blocks = ((long)d->M * d->N * nz + 255) / 256;
+    return blocks > 2048 ? 2048 : blocks;
+  }
+  const long n = (long)((d->N + BN - 1) / BN) * ((d->M + p.BM - 1) / p.BM) * nz;
+  return n <= 8192 ? n : 0;
+}
+
+extern "C" int32_t vilco_gemm_amax_parts(const vilco_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->band == 1) return 0;      // band 1 leaves tiles unwritten
+  Plan p;
+  make_plan(d, p);
+  return (int32_t)amax_out_parts(d, p);
+}
 
 extern "C" int vilco_gemm_profile_begin(void) {
   ProfState& p = prof();
@@ -871,6 +914,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
               vilco_aligned(d->residual, 16);
   g.c = p.ksplit > 1 ? parts : d->C;
   g.cfinal = d->C;
+  g.amax_out = d->band == 1 ? nullptr : d->amax_out;
   g.e = Epi{d->alpha, d->beta, d->bias, d->preact, d->act, d->row_len, d->rowT, d->colscale, d->residual,
             d->res_masked};
   const int nz = d->batch_outer * d->batch_inner;

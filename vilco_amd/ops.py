@@ -137,9 +137,10 @@ def dropout(x, p, training, site="dropout"):
 def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), sB=(0, 0),
          sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
          bias=None, preact=None, act=ACT_NONE, row_len=None, rowT=0, colscale=None, residual=None,
-         res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0, drop=(0.0, 0)):
+         res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0, drop=(0.0, 0), want_amax=False):
     """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements.  a_planes / b_planes: operands
-    already packed by `pack` (the fp32 tensor may then be None)."""
+    already packed by `pack` (the fp32 tensor may then be None).  want_amax: the call writes ALL of Cc, which goes on
+    into another product -- the kernel leaves max|C| partials and Cc is tagged with them (`_tag_amax`)."""
     lib = _lib.load()
     d = GemmDesc()
     d.A = None if A is None else A.data_ptr() + 4 * offA
@@ -169,7 +170,15 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     nbytes = lib.vilco_gemm_workspace(C.byref(d))      # bf16 operand planes + split-K partials
     ws = torch.empty(nbytes, dtype=torch.uint8, device=Cc.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    parts, n = None, 0
+    if want_amax and produce_amax and d.precision == 3:
+        n = int(lib.vilco_gemm_amax_parts(C.byref(d)))
+        if n > 0:
+            parts = torch.empty(n, dtype=torch.float32, device=Cc.device)
+            d.amax_out = parts.data_ptr()
     _lib.check(lib.vilco_gemm(C.byref(d), _stream()))
+    if parts is not None:
+        _tag_amax(Cc, parts, n)
 
 
 # ---- amax partials left by the producing kernel.  The fp16 x2 planes need max|x| of the whole tensor before anything can be
@@ -301,6 +310,7 @@ def colsum(x2d):
 
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) * rowmask.  x [..., K] token-major, W [N, K] (conv1x1 / nn.Linear weight)."""
+    last_amax = (None, 0)
 
     @staticmethod
     def forward(ctx, x, w, b, act, lens, T, drop_p=0.0, drop_site="dropout"):
@@ -320,7 +330,8 @@ class _Linear(torch.autograd.Function):
                 px, pw = pack_many([(x, M, K), (w, N, K)])
         ctx.drop = _new_drop(drop_site, drop_p, y.shape)      # nn.Dropout after the layer, fused into the epilogue
         gemm(x, w, y, M, N, K, 1, 1, K, K, N, bias=b, preact=pre, act=act, row_len=lens,
-             rowT=T or 0, a_planes=px, b_planes=pw, drop=ctx.drop)
+             rowT=T or 0, a_planes=px, b_planes=pw, drop=ctx.drop, want_amax=True)
+        _Linear.last_amax = _amax_of(y)
         ctx.act, ctx.T = act, T
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, pre if act == ACT_GELU else (y if act == ACT_RELU else None), lens, px, pw)
@@ -344,7 +355,7 @@ class _Linear(torch.autograd.Function):
             pz = pack(dz, M, N, prec)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=prec, a_planes=pz, b_planes=pw)   # dX = dZ W     (NN)
+            gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=prec, a_planes=pz, b_planes=pw, want_amax=True)   # dX = dZ W     (NN)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(prec, M), a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
@@ -356,7 +367,12 @@ def linear(x, w, b=None, act=ACT_NONE, lens=None, T=None, drop_p=0.0, drop_site=
     With a ReLU (output saved as the activation witness) the dropout stays a separate op."""
     if drop_p > 0.0 and act == ACT_RELU:
         return dropout(_Linear.apply(x, w, b, act, lens, T, 0.0, drop_site), drop_p, True, drop_site)
-    return _Linear.apply(x, w, b, act, lens, T, float(drop_p), drop_site)
+    _Linear.last_amax = (None, 0)
+    y = _Linear.apply(x, w, b, act, lens, T, float(drop_p), drop_site)
+    if _Linear.last_amax[0] is not None:            # max|y| partials left by the GEMM epilogue
+        _tag_amax(y, *_Linear.last_amax)
+    _Linear.last_amax = (None, 0)
+    return y
 
 
 class _LinearKN(torch.autograd.Function):
@@ -784,6 +800,23 @@ def _attn_amax_parts(B, H, T, hd, mode, bias, drop, key_side):
     return int(_lib.load().vilco_attn_amax_parts(B, H, T, hd, int(mode), _precision, int(bias is not None), float(drop[0]), key_side))
 
 
+def _attn_amax_in(q, k, v, do=None):
+    """partials the producers of q / k / v / dO left (GEMM epilogues): the attention call then skips its amax pass"""
+    if _precision != 3:
+        return None
+    a = _lib.AttnAmaxIn()
+    keep = []
+    for name, t in (("q", q), ("k", k), ("v", v), ("dout", do)):
+        if t is None:
+            continue
+        parts, n = _amax_of(t)
+        if parts is not None:
+            setattr(a, name, parts.data_ptr())
+            setattr(a, "n" + ("do" if name == "dout" else name), n)
+            keep.append(parts)
+    return (a, keep) if keep else None
+
+
 def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode, drop=(0.0, 0), window=0):
     lib = _lib.load()
     B, Tq, Cn = q.shape
@@ -794,9 +827,10 @@ def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode, drop=(0.0, 0), window=0):
     ws = _ws(nws, q.device)
     na = _attn_amax_parts(B, H, Tq, Cn // H, mode, bias, drop, 0)
     am = torch.empty(na, dtype=torch.float32, device=q.device) if na else None
+    ain = _attn_amax_in(q, k, v)
     _lib.check(lib.vilco_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
                                   lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
-                                  int(drop[1]), _p(am), ws.data_ptr(), nws, _stream()))
+                                  int(drop[1]), C.byref(ain[0]) if ain else None, _p(am), ws.data_ptr(), nws, _stream()))
     if na:
         _FlashAttention.last_amax = (am, na)
     return o, lse
@@ -814,10 +848,12 @@ def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, dr
     nk = 0 if want_dbias else _attn_amax_parts(B, H, Tk, Cn // H, mode, bias, drop, 1)
     am = torch.empty(nq + 2 * nk, dtype=torch.float32, device=q.device) if nq and nk else None
     aq, ak, av = (am[:nq], am[nq:nq + nk], am[nq + nk:]) if am is not None else (None, None, None)
+    ain = _attn_amax_in(q, k, v, do)
     _lib.check(lib.vilco_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
                                   lse.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                   _p(dbias), B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
-                                  int(drop[1]), _p(aq), _p(ak), _p(av), ws.data_ptr(), nws, _stream()))
+                                  int(drop[1]), C.byref(ain[0]) if ain else None, _p(aq), _p(ak), _p(av), ws.data_ptr(), nws,
+                                  _stream()))
     if am is not None:
         _tag_amax(dq, aq, nq)
         _tag_amax(dk, ak, nk)
