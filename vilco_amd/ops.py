@@ -203,11 +203,19 @@ def _amax_of(x):
     return tag[0], tag[1]
 
 
+_pack_cache = os.environ.get("VILCO_PACK_CACHE", "1") != "0"
+
+
 def pack(x, rows, cols, precision=None):
     """One pass over the fp32 row-major matrix x[rows][cols] -> 16-bit operand planes (a uint8 tensor) that every
-    product the tensor appears in consumes, in either orientation (vilco_pack, include/vilco_hip.h)."""
+    product the tensor appears in consumes, in either orientation (vilco_pack, include/vilco_hip.h).  The planes are
+    remembered on the tensor: an activation that feeds several layers (XLNet's h -> q, k, v) is packed once."""
     lib = _lib.load()
     prec = _precision if precision is None else int(precision)
+    key = (int(rows), int(cols), prec, x._version)
+    hit = getattr(x, "_vilco_planes", None) if _pack_cache else None
+    if hit is not None and hit[1] == key:
+        return hit[0]
     nbytes = lib.vilco_pack_bytes(int(rows), int(cols), prec)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     parts, n = _amax_of(x) if prec == 3 else (None, 0)
@@ -219,6 +227,8 @@ def pack(x, rows, cols, precision=None):
         it.planes, it.planes_bytes, it.nbatch, it.batch_stride, it.relshift = buf.data_ptr(), nbytes, 1, 0, 0
         it.amax, it.namax = parts.data_ptr(), n
         _lib.check(lib.vilco_pack_many(C.byref(it), 1, prec, _stream()))
+    if _pack_cache:
+        x._vilco_planes = (buf, key)
     return buf
 
 
