@@ -165,3 +165,39 @@ def nlq_backbone_inputs():
     txt = torch.randn(2, NLQ_CT, NLQ_L, generator=g)
     tmask = (torch.arange(NLQ_L)[None, :] < torch.tensor([NLQ_L - 4, NLQ_L])[:, None]).unsqueeze(1)
     return vid * vmask, vmask, txt * tmask, tmask
+
+
+# ------------------------------------------------------------------------------------------ NLQ meta-architecture case
+NLQ_M_T, NLQ_M_LEVELS = 96, 4
+
+
+def nlq_model_cfg():
+    """kwargs of NLQ's LocPointTransformer (NLQ/libs/modeling/meta_archs.py:345-380) for a small model: the backbone of
+    nlq_backbone_cfg() (arch (2,1,1,1,2): 4 pyramid levels, windows 9,9,-1,-1), one query class, label smoothing 0.1"""
+    return dict(
+        backbone_type='convTransformer', fpn_type='identity', backbone_arch=(2, 1, 1, 1, 2), scale_factor=2,
+        input_vid_dim=NLQ_CV, input_txt_dim=NLQ_CT, max_seq_len=NLQ_M_T, max_buffer_len_factor=4.0, n_head=NLQ_H,
+        n_mha_win_size=[NLQ_WIN, NLQ_WIN, -1, -1], embd_kernel_size=3, embd_dim=NLQ_C, embd_with_ln=True, fpn_dim=NLQ_C,
+        fpn_with_ln=True, fpn_start_level=0, head_dim=NLQ_C, regression_range=[(0, 4), (2, 8), (4, 16), (8, 10000)],
+        head_num_layers=3, head_kernel_size=3, head_with_ln=True, use_abs_pe=True, use_rel_pe=False, num_classes=1,
+        train_cfg=dict(center_sample='radius', center_sample_radius=1.5, loss_weight=1.0, cls_prior_prob=0.01,
+                       init_loss_norm=200, clip_grad_l2norm=1.0, head_empty_cls=[], dropout=0.0, droppath=0.0,
+                       label_smoothing=0.1),
+        test_cfg=dict(pre_nms_thresh=0.001, pre_nms_topk=2000, iou_threshold=0.1, min_score=0.001, max_seg_num=5,
+                      nms_method='soft', nms_sigma=0.75, duration_thresh=0.001, multiclass_nms=True, ext_score_file=None,
+                      voting_thresh=0.9),
+        cl_cfg=dict(name='mem', memory_size=10, adv_lambda=0, type_sampling='icarl', prompt_pool=False, pool_size=10,
+                    topk=4, length=20, embed_dim=NLQ_CT, narration_ssl=False, narration_dim=NLQ_CT, ssl_factor=0.03,
+                    use_adapter=False, adapt_blocks=[], reg_lambda=0))
+
+
+def nlq_model_batch():
+    """two query / clip pairs: video features [C, t], query tokens [Ct, L], segments on the feature grid, one-hot labels"""
+    g = torch.Generator().manual_seed(4321)
+    out = []
+    for i, (t, L, segs) in enumerate(((NLQ_M_T, 9, [[10.0, 31.5]]), (NLQ_M_T - 23, 6, [[3.0, 9.25], [40.0, 66.0]]))):
+        out.append({'video_id': 'q%d' % i, 'feats': torch.randn(NLQ_CV, t, generator=g),
+                    'query_feats': torch.randn(NLQ_CT, L, generator=g), 'segments': torch.tensor(segs),
+                    'one_hot_labels': torch.ones(len(segs), 1), 'fps': 30.0, 'duration': 60.0 + i,
+                    'feat_stride': 16.043, 'feat_num_frames': 16.043})
+    return out

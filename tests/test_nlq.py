@@ -154,3 +154,77 @@ def test_local_attention_full_size_equals_dense_masked(dev):
     k2[:, 1000:1100] += 5.0                                    # keys 1000..1099 are outside every window of queries < 980
     o2 = ops.attention(q.detach(), k2, v.detach(), lens, H, mode=ops.MASK_LOCAL, window=w)
     assert torch.equal(o2[:, :980], o.detach()[:, :980])
+
+
+# ------------------------------------------------------------------------------------------------------- meta-architecture
+# tests/golden/nlq_model.pt: the reference's NLQ LocPointTransformer (heads, label assignment, losses, decode, soft-NMS are
+# the imported meta_archs.py / nms.py; tests/golden/make_golden_nlq_model.py) on two query / clip pairs.
+def _gold_model():
+    return torch.load(os.path.join(HERE, "golden", "nlq_model.pt"), weights_only=False)
+
+
+def test_oracle_meta_arch_matches_reference():
+    from oracle import nlq_oracle as N
+    g, cfg = _gold_model(), cases.nlq_model_cfg()
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in g['state'].items()}
+    losses, norm = N.forward_losses(p, cfg, cases.nlq_model_batch())
+    for k, w in g['losses'].items():
+        assert abs(float(losses[k]) - w) <= 2e-5 * max(abs(w), 1e-3), (k, float(losses[k]), w)
+    assert abs(norm - g['loss_normalizer']) <= 1e-6 * g['loss_normalizer']
+    losses['final_loss'].backward()
+    worst = max((rel_err(p[k].grad, w, 1e-7), k) for k, w in g['grads'].items() if not k.endswith(NOISE))
+    assert worst[0] < 5e-4, worst
+    from vilco_amd.utils.nms import batched_nms            # the reference's post-processing call (:1361) on the oracle's decode
+    tc = cfg['test_cfg']
+    for x, e in zip(cases.nlq_model_batch(), g['eval']):
+        with torch.no_grad():
+            masks, cls, reg = N.forward_network({k: v.detach() for k, v in p.items()}, cfg, [x], False)
+        for a, b in zip(cls, e['cls_logits']):
+            assert rel_err(a, b) < 1e-5
+        for a, b in zip(reg, e['offsets']):
+            assert rel_err(a, b, 1e-6) < 1e-5
+        segs, scores, labels = N.decode(cfg, masks, cls, reg)
+        assert segs.shape[0] > tc['max_seg_num']             # the case's scores survive the pre-NMS threshold
+
+
+def test_meta_arch_registry_and_state_dict_keys():
+    import vilco_amd.modeling_nlq as nlq
+    m = nlq.make_meta_arch('LocPointTransformer', **cases.nlq_model_cfg())
+    want = _gold_model()['state']
+    assert sorted(m.state_dict().keys()) == sorted(want.keys())
+    for k, v in m.state_dict().items():
+        assert v.shape == want[k].shape, k
+    m.load_state_dict(want, strict=True)
+
+
+@pytest.mark.gpu
+def test_meta_arch_training_step_and_inference_vs_reference_golden(dev):
+    """losses, every parameter gradient, raw head outputs and the decoded + soft-NMS'd moments of the HIP model"""
+    import vilco_amd.modeling_nlq as nlq
+    g, cfg = _gold_model(), cases.nlq_model_cfg()
+    model = nlq.make_meta_arch('LocPointTransformer', **cfg)
+    model.load_state_dict(g['state'], strict=True)
+    model = model.to(dev).train()
+    losses = model([dict(x) for x in cases.nlq_model_batch()], is_training=True)
+    for k, w in g['losses'].items():
+        assert abs(float(losses[k]) - w) <= TOL * max(abs(w), 1e-3), (k, float(losses[k]), w)
+    assert abs(model.loss_normalizer - g['loss_normalizer']) <= 1e-5 * g['loss_normalizer']
+    losses['final_loss'].backward()
+    params = dict(model.named_parameters())
+    assert set(params) == set(g['state']) - {k for k in g['state'] if k not in params}
+    worst = max((rel_err(params[k].grad, w, 1e-7), k) for k, w in g['grads'].items() if not k.endswith(NOISE))
+    assert worst[0] < TOL, worst
+    model.eval()
+    for x, e in zip(cases.nlq_model_batch(), g['eval']):
+        with torch.no_grad():
+            cls, off, masks = model([dict(x)], is_training=False, get_emb=True)
+            res = model([dict(x)], is_training=False)[0]
+        for a, b in zip(cls, e['cls_logits']):
+            assert rel_err(a, b) < TOL
+        for a, b in zip(off, e['offsets']):
+            assert rel_err(a, b, 1e-6) < TOL
+        for a, b in zip(masks, e['masks']):
+            assert torch.equal(a.cpu(), b)
+        assert res['segments'].shape == e['segments'].shape
+        assert rel_err(res['scores'], e['scores']) < TOL and rel_err(res['segments'], e['segments']) < TOL
+        assert torch.equal(res['labels'].cpu(), e['labels'])
