@@ -73,14 +73,22 @@ __device__ __forceinline__ void split4(const float (&v)[4], bf16x4 (&part)[3]) {
   }
 }
 
-// fp16 x2 parts of values the caller has already scaled into fp16 range (pack.h fmt 1)
+// fp16 x2 parts of values the caller has already scaled into fp16 range (pack.h fmt 1): h0 = fp16(v) by the packed
+// convert (round to nearest even), h1 = fp16(v - h0) by ONE mixed-precision FMA per value, which reads the fp16 half in
+// place, subtracts in fp32 and rounds (instead of convert-back, subtract, convert)
 __device__ __forceinline__ void split4h(const float (&v)[4], bf16x4 (&part)[3]) {
-  f16x4 h0, h1;
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 h0, h1;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const _Float16 h = (_Float16)v[e];
-    h0[e] = h;
-    h1[e] = (_Float16)(v[e] - (float)h);
+  for (int e = 0; e < 4; e += 2) {
+    const f16x2 hp = {(_Float16)v[e], (_Float16)v[e + 1]};
+    const uint32_t hpu = __builtin_bit_cast(uint32_t, hp);
+    uint32_t lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hpu), "v"(v[e]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hpu), "v"(v[e + 1]));
+    h0[e >> 1] = hpu;
+    h1[e >> 1] = lo;
   }
   part[0] = __builtin_bit_cast(bf16x4, h0);
   part[1] = __builtin_bit_cast(bf16x4, h1);
