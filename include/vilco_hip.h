@@ -329,9 +329,9 @@ int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, co
 /* vilco_layernorm_bwd on (dh, x, mean1, rstd1).                                                                    */
 /* ------------------------------------------------------------------------------------------ */
 int vilco_qkv_pre_supported(int32_t C);
-/* amax_parts (may be NULL): three device arrays of vilco_qkv_pre_amax_parts(B, T, C, stride) floats that receive the        */
+/* amax_parts (may be NULL): three device arrays of vilco_qkv_pre_amax_parts(B, T, stride) floats that receive the        */
 /* partial maxima of |q|, |k|, |v| (0 = too many partials: not emitted).                                                 */
-int vilco_qkv_pre_amax_parts(int32_t B, int32_t T, int32_t C, int32_t stride);
+int vilco_qkv_pre_amax_parts(int32_t B, int32_t T, int32_t stride);
 int vilco_qkv_pre_fwd(const float* x, const float* ln1_g, const float* ln1_b, const float* const* w,
                       const float* const* gam, const float* const* bet, const int32_t* len, float* h,
                       float* const* y, float* mean1, float* rstd1, float* const* mean, float* const* rstd,

@@ -225,149 +225,6 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
     }
 }
 
-// Forward, fourth version (C = 256 * NG known at compile time): the S (TB - 1) + 3 input rows of a wave are loaded ONCE,
-// all at once (NR * NG independent 16-byte loads in flight per lane: one memory latency per wave instead of one per
-// chunk and pass), and stay in registers, where they become h in place; the convs are evaluated on the fly in two
-// sweeps (statistics, then normalise + write) and never stored.  Two-pass (exact) statistics for the input rows,
-// shifted one-pass sums for the conv outputs as in version 3.
-template <int TB, int S, int NG>
-__global__ __launch_bounds__(256) void qkv_pre_fwd_reg_kernel(QkvArgs a) {
-  constexpr int NR = S * (TB - 1) + 3;
-  const int lane = threadIdx.x & 63;
-  const int groups = (a.Tout + TB - 1) / TB;
-  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= (long)a.B * groups) return;                 // whole waves only: no barrier below
-  const int b = (int)(wid / groups), t0 = (int)(wid % groups) * TB;
-  const int C = a.C, T = a.T;
-  const float invC = 1.f / (float)C;
-  const int len = a.len[b];
-  const int r0 = S * t0 - 1;
-  const float* xb = a.x + (long)b * T * C + lane * 4;
-
-  float4 x[NR][NG];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const int t = r0 + r;
-    const bool ok = t >= 0 && t < T;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) x[r][g] = ok ? ldg4(xb + (long)t * C + g * 256) : f4(0.f);
-  }
-  // LayerNorm 1 statistics, then h in place (rows outside [0, T) stay zero: the conv's padding)
-  float mu[NR], rs[NR];
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    float s = 0.f;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) s += hsum(x[r][g]);
-    mu[r] = wave_sum(s) * invC;
-    float q = 0.f;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const float d0 = x[r][g].x - mu[r], d1 = x[r][g].y - mu[r], d2 = x[r][g].z - mu[r], d3 = x[r][g].w - mu[r];
-      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-    rs[r] = 1.0f / sqrtf(wave_sum(q) * invC + a.eps1);
-    const int t = r0 + r;
-    if (lane == 0 && a.mean1 && r >= 1 && r <= S * TB && t < T) { a.mean1[(long)b * T + t] = mu[r]; a.rstd1[(long)b * T + t] = rs[r]; }
-  }
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const float4 g1 = a.g1 ? ldg4(a.g1 + g * 256 + lane * 4) : f4(1.f);
-    const float4 b1 = a.b1 ? ldg4(a.b1 + g * 256 + lane * 4) : f4(0.f);
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int t = r0 + r;
-      if (t < 0 || t >= T) continue;
-      float4& v = x[r][g];
-      v.x = (v.x - mu[r]) * rs[r] * g1.x + b1.x; v.y = (v.y - mu[r]) * rs[r] * g1.y + b1.y;
-      v.z = (v.z - mu[r]) * rs[r] * g1.z + b1.z; v.w = (v.w - mu[r]) * rs[r] * g1.w + b1.w;
-      if (a.h && r >= 1 && r <= S * TB) *reinterpret_cast<float4*>(a.h + ((long)b * T + t) * C + g * 256 + lane * 4) = v;
-    }
-    asm volatile("" ::: "memory");          // keep the parameter loads of chunk g + 1 below this point (registers)
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // conv j of chunk g for token i out of the register rows: w[c][3] of 4 consecutive channels = 12 floats
-  auto conv = [&](const float4& wa, const float4& wb, const float4& wc, int g, int i) {
-    const int t = t0 + i;
-    if (!(t < a.Tout && S * t < len)) return f4(0.f);
-    const float4 &p = x[S * i][g], &q = x[S * i + 1][g], &n = x[S * i + 2][g];
-    float4 c;
-    c.x = wa.x * p.x + wa.y * q.x + wa.z * n.x;
-    c.y = wa.w * p.y + wb.x * q.y + wb.y * n.y;
-    c.z = wb.z * p.z + wb.w * q.z + wc.x * n.z;
-    c.w = wc.y * p.w + wc.z * q.w + wc.w * n.w;
-    return c;
-  };
-  // sweep 1: statistics of the conv outputs
-  float cm[3][TB], cr[3][TB];
-  {
-    float k[3][TB], s1[3][TB], s2[3][TB];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int i = 0; i < TB; ++i) { k[j][i] = 0.f; s1[j][i] = 0.f; s2[j][i] = 0.f; }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float* wp = a.w[j] + (g * 256 + lane * 4) * 3;
-        const float4 wa = ldg4(wp), wb = ldg4(wp + 4), wc = ldg4(wp + 8);
-#pragma unroll
-        for (int i = 0; i < TB; ++i) {
-          const float4 c = conv(wa, wb, wc, g, i);
-          if (g == 0) k[j][i] = __shfl(c.x, 0, 64);
-          const float d0 = c.x - k[j][i], d1 = c.y - k[j][i], d2 = c.z - k[j][i], d3 = c.w - k[j][i];
-          s1[j][i] += (d0 + d1) + (d2 + d3);
-          s2[j][i] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int i = 0; i < TB; ++i) {
-        const float m = wave_sum(s1[j][i]) * invC, q = wave_sum(s2[j][i]) * invC;
-        cm[j][i] = k[j][i] + m;
-        cr[j][i] = 1.0f / sqrtf(fmaxf(q - m * m, 0.f) + a.eps);
-        const int t = t0 + i;
-        if (lane == 0 && a.mean[j] && t < a.Tout) { a.mean[j][(long)b * a.Tout + t] = cm[j][i]; a.rstd[j][(long)b * a.Tout + t] = cr[j][i]; }
-      }
-  }
-  // sweep 2: normalise and write
-  float omax[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float* wp = a.w[j] + (g * 256 + lane * 4) * 3;
-      const float4 wa = ldg4(wp), wb = ldg4(wp + 4), wc = ldg4(wp + 8);
-      const float4 gm = a.gam[j] ? ldg4(a.gam[j] + g * 256 + lane * 4) : f4(1.f);
-      const float4 bt = a.bet[j] ? ldg4(a.bet[j] + g * 256 + lane * 4) : f4(0.f);
-#pragma unroll
-      for (int i = 0; i < TB; ++i) {
-        const int t = t0 + i;
-        if (t >= a.Tout) continue;
-        const float4 c = conv(wa, wb, wc, g, i);
-        float4 o;
-        o.x = (c.x - cm[j][i]) * cr[j][i] * gm.x + bt.x; o.y = (c.y - cm[j][i]) * cr[j][i] * gm.y + bt.y;
-        o.z = (c.z - cm[j][i]) * cr[j][i] * gm.z + bt.z; o.w = (c.w - cm[j][i]) * cr[j][i] * gm.w + bt.w;
-        omax[j] = fmaxf(fmaxf(omax[j], fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-        *reinterpret_cast<float4*>(a.y[j] + ((long)b * a.Tout + t) * C + g * 256 + lane * 4) = o;
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-    if (a.amax[j]) {
-      const float m = wave_max(omax[j]);
-      if (lane == 0) a.amax[j][wid] = m;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------- backward, rows
 struct QkvBwdArgs {
   const float* h;            // [B][T][C]  (LN1 output, saved or recomputed)
@@ -587,22 +444,9 @@ int forced_tb() {
   return forced;
 }
 
-static bool reg_path_on();
-
-template <int NG, int TB>
-void launch_fwd_reg(const QkvArgs& a, hipStream_t s) {
-  const long waves = (long)a.B * ((a.Tout + TB - 1) / TB);
-  if (a.stride == 1) hipLaunchKernelGGL((qkv_pre_fwd_reg_kernel<TB, 1, NG>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((qkv_pre_fwd_reg_kernel<TB, 2, NG>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
-}
-
 bool launch_fwd(const QkvArgs& a, hipStream_t s) {
   if (a.C % 256 != 0) return false;
   const int forced = forced_tb();
-  if (!forced && reg_path_on()) {          // rows in registers: the channel counts of the shipped configs (D = 1024, C = 2304)
-    if (a.C == 1024) { launch_fwd_reg<4, 2>(a, s); return true; }
-    if (a.C == 2304) { launch_fwd_reg<9, 1>(a, s); return true; }        // one token per wave (108 registers of rows)
-  }
   if (a.stride == 1) {
     int tb = forced ? forced : 2;
     if (tb >= 4) launch_fwd_tb<4, 1>(a, s);
@@ -616,17 +460,9 @@ bool launch_fwd(const QkvArgs& a, hipStream_t s) {
   return true;
 }
 
-static bool reg_path_on() {
-  static const bool on = [] { const char* e = getenv("VILCO_QKV_REG"); return !(e && e[0] == '0'); }();
-  return on;
-}
-// tokens per wave of the forward kernel launch_fwd picks (the per-wave amax partials are counted with it)
-static int fwd_tokens_per_wave(int C) { return (!forced_tb() && reg_path_on() && C == 2304) ? 1 : 2; }
-
-extern "C" int vilco_qkv_pre_amax_parts(int32_t B, int32_t T, int32_t C, int32_t stride) {
+extern "C" int vilco_qkv_pre_amax_parts(int32_t B, int32_t T, int32_t stride) {
   if (B <= 0 || T <= 0 || (stride != 1 && stride != 2)) return 0;
-  const int tb = fwd_tokens_per_wave(C);
-  const long waves = (long)B * ((T / stride + tb - 1) / tb);
+  const long waves = (long)B * ((T / stride + 1) / 2);          // TB = 2 tokens per wave, both strides (launch_fwd)
   return waves <= 4096 ? (int)waves : 0;                        // more partials than that cost the packs more than an amax launch
 }
 
@@ -644,7 +480,7 @@ extern "C" int vilco_qkv_pre_fwd(const float* x, const float* ln1_g, const float
   for (int j = 0; j < 3; ++j) {
     if (!w[j] || !y[j]) return VILCO_ERR_BADARG;
     a.w[j] = w[j]; a.gam[j] = gam[j]; a.bet[j] = bet[j]; a.y[j] = y[j]; a.mean[j] = mean[j]; a.rstd[j] = rstd[j];
-    a.amax[j] = (amax_parts && !forced_tb() && vilco_qkv_pre_amax_parts(B, T, C, stride) > 0) ? amax_parts[j] : nullptr;
+    a.amax[j] = (amax_parts && !forced_tb() && vilco_qkv_pre_amax_parts(B, T, stride) > 0) ? amax_parts[j] : nullptr;
   }
   a.B = B; a.T = T; a.Tout = T / stride; a.C = C; a.stride = stride; a.seg = 0;
   a.eps1 = eps1; a.eps = eps;

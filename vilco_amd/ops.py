@@ -1184,7 +1184,7 @@ class _QkvPre(torch.autograd.Function):
         stats1 = torch.empty(2, B * T, dtype=torch.float32, device=dev)
         stats = torch.empty(6, B * To, dtype=torch.float32, device=dev)
         means, rstds = [stats[2 * j] for j in range(3)], [stats[2 * j + 1] for j in range(3)]
-        npart = lib.vilco_qkv_pre_amax_parts(B, T, Cn, int(stride)) if (produce_amax and _precision == 3) else 0
+        npart = lib.vilco_qkv_pre_amax_parts(B, T, int(stride)) if (produce_amax and _precision == 3) else 0
         parts = torch.empty(3, npart, dtype=torch.float32, device=dev) if npart > 0 else None
         _lib.check(lib.vilco_qkv_pre_fwd(x.data_ptr(), _p(g1), _p(b1), _ptr3([wq, wk, wv]), _ptr3([gq, gk, gv]),
                                          _ptr3([bq, bk, bv]), lens.data_ptr(), _p(h), _ptr3(ys), stats1[0].data_ptr(),
