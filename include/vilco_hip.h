@@ -254,6 +254,22 @@ int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* 
                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Candidate decode of PtTransformer.inference_single_video (MQ meta_archs.py:1594-1692, NLQ meta_archs.py:1253-1338)   */
+/* for ONE clip, all L pyramid levels in one call: per level sigmoid(logit) > pre_nms_thresh on the valid positions,  */
+/* the pre_nms_topk highest of those (exact; ties at the cut admitted in index order), segment = (t - off_l * stride,   */
+/* t + off_r * stride), kept when longer than duration_thresh.  logits [R][C], offsets [R][2] (the regression head's    */
+/* relu(Scale_l(x))), points [R][4] = (t, lo, hi, stride) share one row layout; level l owns rows level_row0[l] ..      */
+/* level_row0[l] + level_len[l] - 1 (level_len = valid length of the clip at that level).  Outputs: the candidates of    */
+/* level 0, then level 1, ... (inside a level in index order -- every consumer orders by score itself), out_total[0] =   */
+/* how many; capacity L * topk rows.  L <= 64.                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+size_t vilco_decode_workspace(int32_t L, int32_t topk);
+int vilco_decode(const float* logits, const float* offsets, const float* points, const int32_t* level_row0,
+                 const int32_t* level_len, int32_t C, int32_t L, int32_t topk, float pre_nms_thresh,
+                 float duration_thresh, float* out_segs, float* out_scores, int64_t* out_labels,
+                 int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Elementwise / reduction glue of TransformerBlock.forward (blocks.py:561-593).                 */
 /* ------------------------------------------------------------------------------------------ */
 /* out = a * (mask_a ? m : 1) + colscale[c] * rowscale[b] * bval ; colscale/rowscale/len optional */

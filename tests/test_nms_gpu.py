@@ -89,3 +89,55 @@ def test_batched_nms(dev, soft, multiclass):
     assert np.array_equal(gc.numpy(), wc)
     np.testing.assert_allclose(gs.numpy(), ws, rtol=1e-6)
     np.testing.assert_allclose(gsc.numpy(), wsc, rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------- decode
+def _decode_ref(cls_list, off_list, pts_list, masks, thresh, topk, dur, C):
+    """inference_single_video (meta_archs.py:1594-1692) restated with plain tensor ops on the host"""
+    out = []
+    for cls_i, off_i, pts_i, m in zip(cls_list, off_list, pts_list, masks):
+        prob = (cls_i.sigmoid() * m.unsqueeze(-1)).flatten()
+        keep = prob > thresh
+        prob, idx = prob[keep], keep.nonzero(as_tuple=True)[0]
+        k = min(topk, idx.size(0))
+        prob, order = prob.sort(descending=True)
+        prob, idx = prob[:k], idx[order[:k]]
+        pt, lab = torch.div(idx, C, rounding_mode='floor'), torch.fmod(idx, C)
+        o, p = off_i[pt], pts_i[pt]
+        left, right = p[:, 0] - o[:, 0] * p[:, 3], p[:, 0] + o[:, 1] * p[:, 3]
+        ok = (right - left) > dur
+        out.append((torch.stack((left, right), -1)[ok], prob[ok], lab[ok]))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("topk", [5000, 37, 1])
+def test_decode_matches_tensor_expression_path(dev, topk):
+    """vilco_decode = threshold -> exact top-k -> decode -> duration filter, per level, as SETS with equal scores and
+    segments (the kernel keeps index order inside a level, the reference score order; scores are tie-free here)"""
+    from vilco_amd import ops
+    torch.manual_seed(11)
+    C, lens_full, valid = 7, [96, 48, 24, 12], [96, 41, 24, 0]
+    cls = [torch.randn(t, C) * 2.5 - 3.0 for t in lens_full]
+    off = [torch.rand(t, 2) * 3.0 for t in lens_full]
+    off[0][5] = 0.0                                                  # a zero-length segment: fails the duration filter
+    pts = [torch.stack((torch.arange(t) * 2.0 ** l, torch.zeros(t), torch.full((t,), 1e4), torch.full((t,), 2.0 ** l)), -1)
+           for l, t in enumerate(lens_full)]
+    masks = [torch.arange(t) < v for t, v in zip(lens_full, valid)]
+    want = _decode_ref(cls, off, pts, masks, 0.05, topk, 0.05, C)
+    row0 = torch.tensor([sum(lens_full[:i]) for i in range(4)], dtype=torch.int32, device=dev)
+    segs, scores, labels = ops.decode(torch.cat(cls).to(dev), torch.cat(off).to(dev), torch.cat(pts).to(dev), row0,
+                                      torch.tensor(valid, dtype=torch.int32, device=dev), topk, 0.05, 0.05)
+    segs, scores, labels = segs.cpu(), scores.cpu(), labels.cpu()
+    assert scores.shape[0] == sum(w[1].shape[0] for w in want)
+    lo = 0
+    for ws, wp, wl in want:                                          # level slabs in level order
+        n = wp.shape[0]
+        gs, gp, gl = segs[lo:lo + n], scores[lo:lo + n], labels[lo:lo + n]
+        lo += n
+        if n == 0:
+            continue
+        og, ow = torch.argsort(gp, descending=True), torch.argsort(wp, descending=True)
+        assert torch.allclose(gp[og], wp[ow], rtol=2e-6, atol=0) and torch.equal(gl[og], wl[ow])
+        assert torch.allclose(gs[og], ws[ow], rtol=1e-6, atol=1e-6)
+    assert (want[1][1].shape[0] > 0) and (topk != 1 or all(w[1].shape[0] <= 1 for w in want))

@@ -841,7 +841,17 @@ class PtTransformer(nn.Module):
     @torch.no_grad()
     def inference_single_video(self, points, fpn_masks, out_cls_logits, out_offsets, lb_logits_per_vid=None,
                                rb_logits_per_vid=None, candidate_label=None, cls_preds_per_vid=None):
-        """threshold -> top-k -> decode per level (meta_archs.py:1594-1692), all on the device."""
+        """threshold -> top-k -> decode per level (meta_archs.py:1594-1692).  On the device the whole pyramid of the clip
+        is one vilco_decode call (exact top-k by radix select, one host read: the candidate count); VILCO_DEVICE_DECODE=0
+        or host tensors take the tensor-expression path below, which mirrors the reference line by line."""
+        if out_cls_logits[0].is_cuda and os.environ.get("VILCO_DEVICE_DECODE", "1") != "0":
+            lens = [int(c.shape[0]) for c in out_cls_logits]
+            row0 = torch.tensor([sum(lens[:i]) for i in range(len(lens))], dtype=torch.int32, device=out_cls_logits[0].device)
+            level_len = torch.stack([m.sum() for m in fpn_masks]).to(torch.int32)
+            segs, scores, labels = ops.decode(torch.cat(out_cls_logits).float().contiguous(), torch.cat(out_offsets).float().contiguous(),
+                                              torch.cat(points).float().contiguous(), row0, level_len, self.test_pre_nms_topk,
+                                              self.test_pre_nms_thresh, self.test_duration_thresh)
+            return {'segments': segs, 'scores': scores, 'labels': labels}
         segs_all, scores_all, cls_all = [], [], []
         for cls_i, off_i, pts_i, mask_i in zip(out_cls_logits, out_offsets, points, fpn_masks):
             prob = (cls_i.sigmoid() * mask_i.unsqueeze(-1)).flatten()

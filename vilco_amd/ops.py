@@ -1155,6 +1155,29 @@ def mq_loss(logits, offsets, level_scale, gauss, tables, level_len, gt, loss_nor
                          loss_norm, cfg)
 
 
+# ---------------------------------------------------------------------------------------- inference decode
+def decode(logits, offsets, points, level_row0, level_len, topk, pre_nms_thresh, duration_thresh):
+    """vilco_decode: threshold -> exact top-k -> segment decode -> duration filter of one clip's pyramid (all levels, one
+    launch) -> (segments [n, 2], scores [n], labels [n] int64); ONE host read (n)."""
+    lib = _lib.load()
+    R, Cn = logits.shape
+    L = int(level_row0.numel())
+    cap = L * int(topk)
+    dev = logits.device
+    segs = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+    scores = torch.empty(cap, dtype=torch.float32, device=dev)
+    labels = torch.empty(cap, dtype=torch.int64, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    nws = lib.vilco_decode_workspace(L, int(topk))
+    ws = _ws(nws, dev)
+    _lib.check(lib.vilco_decode(logits.data_ptr(), offsets.data_ptr(), points.data_ptr(), level_row0.data_ptr(),
+                                level_len.data_ptr(), int(Cn), L, int(topk), float(pre_nms_thresh), float(duration_thresh),
+                                segs.data_ptr(), scores.data_ptr(), labels.data_ptr(), total.data_ptr(), ws.data_ptr(), nws,
+                                _stream()))
+    n = int(total.item())
+    return segs[:n], scores[:n], labels[:n]
+
+
 # ---------------------------------------------------------------------------------------- fused ln1 -> q/k/v pre-projection
 def qkv_pre_supported(Cn):
     return bool(_lib.load().vilco_qkv_pre_supported(int(Cn)))
