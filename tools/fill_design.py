@@ -8,7 +8,8 @@ r = d["roofline"]
 stats = os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 ng = sum(int(x["Calls"]) for x in rows if "gemm_pp_kernel" in x["Name"])
-ns = max(1, round(ng / 324))
+gps = int(r.get("launches_per_step", 321))      # GEMM launches per step, counted live by bench.py
+ns = max(1, round(ng / gps))
 gemm_avg = sum(float(x["TotalDurationNs"]) for x in rows if "gemm_pp_kernel" in x["Name"]) / ng / 1e3
 table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_table.py"), stats, str(ns), "22"],
                        capture_output=True, text=True).stdout.strip().splitlines()
@@ -18,7 +19,8 @@ side = {x["config"]: x for x in d.get("side_configs", [])}
 rep = {
     "@MS@": "%.1f" % d["ms_per_step"], "@CPS@": "%.1f" % d["value"], "@CPU@": "%.2f" % d["cpu_baseline"]["value"],
     "@B8@": "%.1f" % d["larger_batch"]["clips_per_s"], "@GUS@": "%.1f" % r["avg_launch_us"], "@GTF@": "%.0f" % r["achieved"],
-    "@GFRAC@": "%.3f" % r["frac"], "@RUS@": "%.1f" % gemm_avg,
+    "@GFRAC@": "%.3f" % r["frac"], "@RUS@": "%.1f" % gemm_avg, "@GPS@": str(gps),
+    "@GTFLOP@": "%.2f" % (r["algorithmic_gflop_per_launch"] * gps / 1e3),
     "@TABLE@": "| kernel | launches / step | ms / step | avg µs | share |\n|---|---|---|---|---|\n" + "\n".join(body) +
                "\n\n(" + head + ")",
     "@LAUNCHES@": launches,

@@ -1,4 +1,4 @@
-# kernel-stats profile of a short bench.py run; the step count of the trace is taken from the GEMM launch count (324 / step)
+# kernel-stats profile of a short bench.py run; the step count of the trace is taken from the GEMM launch count (GEMMS_PER_STEP, default 321 at config P)
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ps
@@ -7,7 +7,8 @@ cp /tmp/ps/s_kernel_stats.csv $R/gpurun_out/${TAG:-step}_kernel_stats.csv
 NS=$(python3 - <<'PY'
 import csv
 n = sum(int(r['Calls']) for r in csv.DictReader(open('/tmp/ps/s_kernel_stats.csv')) if 'gemm_pp_kernel' in r['Name'])
-print(max(1, round(n / 324)))
+import os
+print(max(1, round(n / int(os.environ.get('GEMMS_PER_STEP', '321')))))
 PY
 )
 python3 $R/tools/step_table.py /tmp/ps/s_kernel_stats.csv $NS ${ROWS:-24}

@@ -59,8 +59,9 @@ class XLNetRelativeAttention(nn.Module):
 
     def forward_tm(self, h, pos_emb, lens):
         """h [B,T,D] token-major, pos_emb [2T, D], lens int32 [B] -> LayerNorm(attn_out + h)."""
-        q_w = ops.linear_kn(h, self.q, self.r_w_bias)        # q + r_w_bias (content stream)
-        q_r = ops.linear_kn(h, self.q, self.r_r_bias)        # q + r_r_bias (position stream)
+        q = ops.linear_kn(h, self.q)                         # ONE projection; the reference's two streams differ by a bias
+        q_w = q + self.r_w_bias.view(1, 1, -1)               # q + r_w_bias (content stream, modeling_xlnet_x.py:284)
+        q_r = q + self.r_r_bias.view(1, 1, -1)               # q + r_r_bias (position stream, :287)
         k = ops.linear_kn(h, self.k)
         v = ops.linear_kn(h, self.v)
         k_r = ops.linear_kn(pos_emb, self.r)                 # [2T, H*hd] ([B, 2T, H*hd] under dropout)
