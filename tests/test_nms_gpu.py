@@ -141,3 +141,22 @@ def test_decode_matches_tensor_expression_path(dev, topk):
         assert torch.allclose(gp[og], wp[ow], rtol=2e-6, atol=0) and torch.equal(gl[og], wl[ow])
         assert torch.allclose(gs[og], ws[ow], rtol=1e-6, atol=1e-6)
     assert (want[1][1].shape[0] > 0) and (topk != 1 or all(w[1].shape[0] <= 1 for w in want))
+
+
+@pytest.mark.gpu
+def test_decode_edge_cases(dev):
+    """nothing above the threshold; a level of length zero; exact ties at the top-k cut (admitted in index order)"""
+    from vilco_amd import ops
+    C, T = 3, 16
+    pts = torch.stack((torch.arange(T).float(), torch.zeros(T), torch.full((T,), 1e4), torch.ones(T)), -1).to(dev)
+    off = torch.ones(T, 2, device=dev)
+    row0 = torch.zeros(1, dtype=torch.int32, device=dev)
+    full = torch.tensor([T], dtype=torch.int32, device=dev)
+    segs, scores, labels = ops.decode(torch.full((T, C), -20.0, device=dev), off, pts, row0, full, 10, 0.001, 0.001)
+    assert segs.shape == (0, 2) and scores.numel() == 0 and labels.numel() == 0
+    segs, scores, labels = ops.decode(torch.zeros(T, C, device=dev), off, pts, row0, torch.zeros(1, dtype=torch.int32, device=dev),
+                                      10, 0.001, 0.001)
+    assert scores.numel() == 0
+    segs, scores, labels = ops.decode(torch.zeros(T, C, device=dev), off, pts, row0, full, 7, 0.001, 0.001)     # 48 ties at 0.5
+    assert scores.numel() == 7 and bool((scores == 0.5).all())
+    assert labels.cpu().tolist() == [0, 1, 2, 0, 1, 2, 0] and segs[:, 0].cpu().tolist() == [-1.0, -1.0, -1.0, 0.0, 0.0, 0.0, 1.0]

@@ -510,3 +510,30 @@ def test_linear_fused_dropout(dev, act, M, N, K):
     y2.backward(g)
     for a, c in zip(got, (y2.detach(), x.grad, w.grad, b.grad)):
         assert rel(a, c) < 2e-6
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H,lens", [(2, 128, 128, 2, [128, 1]), (1, 129, 257, 1, [200]), (3, 31, 77, 2, [77, 64, 5]),
+                                            (2, 640, 640, 4, [640, 333]), (1, 2, 3, 1, [3])])
+def test_attention_hd64_fast_path(dev, B, Tq, Tk, H, lens):
+    """the hd = 64 kernels (attn_fwd64 / attn_bwd_dq64 / attn_bwd_dkdv64: 128-query workgroups, P and dS in registers,
+    transposing LDS reads, amax partials of every output) at tile-edge shapes: query counts that are not multiples of
+    128 / 32, key counts that are not multiples of 64, a single valid key, cross-attention shapes"""
+    from vilco_amd import ops
+    torch.manual_seed(17)
+    C = H * 64
+    q, k, v = torch.randn(B, Tq, C) * 1.5, torch.randn(B, Tk, C) * 0.7, torch.randn(B, Tk, C) * 20
+    lt = torch.tensor(lens, dtype=torch.int32)
+    run_pair(lambda q, k, v: ops.attention(q, k, v, lt.to(dev), H, 0.125),
+             lambda q, k, v: _attn_ref(q, k, v, lt, H, 0.125), dict(q=q, k=k, v=v), dev, TOL_GEMM)
+    # the partials the kernels leave for the next operand pack equal the true maxima
+    qd, kd, vd = [t.to(dev).requires_grad_(True) * 1.0 for t in (q, k, v)]      # non-leaf: a hook sees the gradient tensor itself
+    got = {}
+    for name, t in (("q", qd), ("k", kd), ("v", vd)):
+        t.register_hook(lambda g, name=name: got.__setitem__(name, g))
+    o = ops.attention(qd, kd, vd, lt.to(dev), H, 0.125)
+    parts, n = ops._amax_of(o)
+    assert parts is not None and abs(float(parts[:n].max()) - float(o.abs().max())) == 0.0
+    o.backward(torch.randn_like(o))
+    for name in ("q", "k", "v"):
+        parts, n = ops._amax_of(got[name])
+        assert parts is not None and abs(float(parts[:n].max()) - float(got[name].abs().max())) == 0.0, name
