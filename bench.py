@@ -291,8 +291,14 @@ def main():
         from vilco_amd.dist import GradReducer
         reducer = GradReducer(model)
 
+    params = [p for p in model.parameters()] if not dry else None
+
     def step():
-        model.zero_grad(set_to_none=True)
+        if params is not None:
+            for p in params:                      # == model.zero_grad(set_to_none=True) without the module-tree walk (1.5 ms)
+                p.grad = None
+        else:
+            model.zero_grad(set_to_none=True)
         if reducer is not None:
             reducer.begin()
         fwd_bwd()

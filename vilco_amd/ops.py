@@ -53,7 +53,15 @@ def get_precision():
     return _precision
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """raw handle of the CURRENT stream of the current device (honours `torch.cuda.stream(...)` contexts).  Asked ~330
+    times per step: the private accessor is 10x cheaper than building a torch.cuda.Stream object each time (3 ms of host
+    time per P step, tools/cpu_overhead.py)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
