@@ -10,4 +10,9 @@ VILCO_BENCH_SETTLE_S=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format
 VILCO_BENCH_SETTLE_S=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --no-cpu-baseline --no-targets --extra-batch 0 --steps 2 --warmup 1 > /dev/null 2>&1
 python3 $R/tools/pmc_summary.py /tmp/pf/f_counter_collection.csv $R/gpurun_out/${TAG}_pmc_fetch.json > /dev/null
 python3 $R/tools/pmc_summary.py /tmp/pw/w_counter_collection.csv $R/gpurun_out/${TAG}_pmc_write.json > /dev/null
+# extras cited in DESIGN.md: per-shape GEMM table, target-kernel kernel stats, attention instruction mix
+cd $R
+python3 tools/gemm_shapes.py 3 > gpurun_out/${TAG}_gemm_shapes.txt 2>/dev/null
+TAG=${TAG}_targets bash tools/prof_targets.sh > /dev/null 2>&1
+bash tools/prof_attn_pmc.sh > gpurun_out/${TAG}_attn_insts.txt 2>&1
 ls -la $R/gpurun_out | grep ${TAG}
