@@ -27,6 +27,14 @@ rep = {
     "@CFG1@": "%.1f" % side["cfg1"]["clips_per_s"] if "cfg1" in side else "n/a",
     "@CFGW@": "%.1f" % side["W"]["clips_per_s"] if "W" in side else "n/a",
 }
+tg = d.get("targets", {})
+q = tg.get("qkv_pre_projection", {}).get("measured", [])
+c = tg.get("cross_attention", {}).get("measured", [])
+if len(q) >= 2 and len(c) >= 2:
+    rep.update({"@T2A@": "%.1f" % (q[0]["GBps"] / 1e3), "@T2AF@": "%.0f %%" % (100 * q[0]["hbm_frac"]),
+                "@T2BF@": "%.0f %%" % (100 * q[1]["hbm_frac"]), "@T2U@": "%.1f" % (q[0]["unfused_GBps_same_algorithmic_bytes"] / 1e3),
+                "@T1A@": "%.0f" % c[0]["fwd_tflops"], "@T1B@": "%.0f" % c[1]["fwd_tflops"],
+                "@T1AF@": "%.1f %%" % (100 * c[0]["fwd_mfma_issue_frac"]), "@T1BF@": "%.1f %%" % (100 * c[1]["fwd_mfma_issue_frac"])})
 t = open(os.path.join(ROOT, "tools", "design_s5.tmpl")).read()
 for k, v in rep.items():
     t = t.replace(k, v)
