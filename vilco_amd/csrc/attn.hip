@@ -520,6 +520,9 @@ __device__ unsigned long long vilco_lab_attn_stamps[64 * 8];
 #define ASTAMP(i) do {} while (0)
 #endif
 
+// XL: XLNet's relative attention (mask mode 3: additive position scores read unshifted from bd[b,h,i,Tq-i+j], the XLNet
+// mask -- keys >= kv_len masked except the diagonal --, dropout on the probabilities): same kernel, three more steps
+template <bool XL>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) {
   constexpr int HDP = 64, BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -531,9 +534,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
   const int bh = b * a.H + h;
   const int q0 = blockIdx.x * F64_Q + wave * 32;
   const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
-  const int kend = len < a.Tk ? len : a.Tk;
+  const int kend = XL ? a.Tk : (len < a.Tk ? len : a.Tk);       // XL: every key tile is visited (the diagonal is always visible)
   const int ntiles = (kend + BKV - 1) / BKV;
   const AttnScales sc = *a.sc;
+  const int bias_ld = a.Tq + a.Tk;
+  const float* bias = XL ? a.bias + ((long)bh * a.Tq) * bias_ld : nullptr;
   const float c2 = a.scale * sc.iq * sc.ik * 1.44269504088896340736f;      // log2-domain score = acc * c2
   const __bf16* kbase = a.kn.p + (long)bh * a.kn.batch_stride;
   const __bf16* vbase = a.vn.p + (long)bh * a.vn.batch_stride;
@@ -627,7 +632,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
       s[0][mi] = c0; s[1][mi] = c1;
     }
     ASTAMP(2);
-    if constexpr (MASKED) {
+    if constexpr (MASKED && !XL) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -638,9 +643,23 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       // scores to the log2 domain, then the row maximum over this lane's 16 keys and the 4 lanes of the query
+      [[maybe_unused]] const int qi_g = q0 + 16 * g + (lane & 15);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        const f32x2 a01 = f32x2{s[g][mi][0], s[g][mi][1]} * c2v, a23 = f32x2{s[g][mi][2], s[g][mi][3]} * c2v;
+        f32x2 a01 = f32x2{s[g][mi][0], s[g][mi][1]} * c2v, a23 = f32x2{s[g][mi][2], s[g][mi][3]} * c2v;
+        if constexpr (XL) {
+          const int jb = k0 + mi * 16 + g4 * 4;
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (qi_g < a.Tq) bias4(bv, bias, qi_g, jb, bias_ld, a);                     // scale * bd[i][Tq - i + j]
+          a01 += f32x2{bv[0], bv[1]} * 1.44269504088896340736f;
+          a23 += f32x2{bv[2], bv[3]} * 1.44269504088896340736f;
+          if constexpr (MASKED) {                                                     // keys >= kv_len except the diagonal, keys >= Tk
+            if ((jb + 0 >= len && jb + 0 != qi_g) || jb + 0 >= a.Tk) a01[0] = -INFINITY;
+            if ((jb + 1 >= len && jb + 1 != qi_g) || jb + 1 >= a.Tk) a01[1] = -INFINITY;
+            if ((jb + 2 >= len && jb + 2 != qi_g) || jb + 2 >= a.Tk) a23[0] = -INFINITY;
+            if ((jb + 3 >= len && jb + 3 != qi_g) || jb + 3 >= a.Tk) a23[1] = -INFINITY;
+          }
+        }
         s[g][mi] = f32x4{a01[0], a01[1], a23[0], a23[1]};
       }
       float mx = fmaxf(fmaxf(s[g][0][0], s[g][0][1]), fmaxf(s[g][0][2], s[g][0][3]));
@@ -648,9 +667,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
       for (int mi = 1; mi < 4; ++mi) mx = fmaxf(mx, fmaxf(fmaxf(s[g][mi][0], s[g][mi][1]), fmaxf(s[g][mi][2], s[g][mi][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[g], mx);             // finite: every tile holds at least one valid key
-      const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
-      const float off = 15.f - m_new;                      // P is formed as P * 2^15 (fp16 range)
+      const float m_new = fmaxf(m_run[g], mx);             // finite (prefix masks: every tile holds at least one valid key)
+      const bool dead = XL && m_new == -INFINITY;          // XL: a row can have seen only masked keys so far
+      const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m_run[g] - m_new);
+      const float off = dead ? 0.f : 15.f - m_new;         // P is formed as P * 2^15 (fp16 range)
       const f32x2 offv = {off, off};
       f32x2 psum = {0.f, 0.f};
 #pragma unroll
@@ -660,8 +680,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
         for (int e = 0; e < 8; e += 2) {
           const f32x2 sv = {s[g][2 * ks + (e >> 2)][e & 3], s[g][2 * ks + (e >> 2)][(e & 3) + 1]};
           const f32x2 arg = sv + offv;                     // v_pk_add_f32
-          const f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-          psum += p;                                       // v_pk_add_f32
+          f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+          psum += p;                                       // v_pk_add_f32 (the denominator is over the undropped probabilities)
+          if constexpr (XL) {
+            if (a.drop_thresh) {
+              const int j = k0 + (2 * ks + (e >> 2)) * 16 + g4 * 4 + (e & 3);
+              p[0] *= drop_keep(a, bh, qi_g, j);
+              p[1] *= drop_keep(a, bh, qi_g, j + 1);
+            }
+          }
           const f16x2 hp = {(_Float16)p[0], (_Float16)p[1]};                 // v_cvt_pk_f16_f32 (round to nearest even)
           const uint32_t hpu = __builtin_bit_cast(uint32_t, hp);
           uint32_t lo;                                     // second part = fp16(p - h0): the mixed-precision FMA reads the
@@ -708,9 +735,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
   };
 
   if (ntiles > 0) gload(0);
-  const int nfull = kend / BKV;                     // tiles with all 64 keys valid
+  const int nfull = (XL ? (len < a.Tk ? len : a.Tk) : kend) / BKV;      // tiles with all 64 keys valid
   for (int t = 0; t < nfull; ++t) tile(t, t + 1 < ntiles, std::false_type{});
-  if (nfull < ntiles) tile(nfull, false, std::true_type{});
+  for (int t = nfull; t < ntiles; ++t) tile(t, t + 1 < ntiles, std::true_type{});
 
   // finish: lane holds query q0 + 16 g + (lane & 15), channels di*16 + 4*g4 + r
   float am = 0.f;
@@ -721,7 +748,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
     l += __shfl_xor(l, 32, 64);
     const int qi = q0 + 16 * g + (lane & 15);
     if (qi < a.Tq) {
-      const float inv = (l > 0.f ? 1.f / l : 0.f) * sc.iv;
+      const float inv = (l > 0.f ? 1.f / l : 0.f) * sc.iv * (XL ? a.drop_inv_keep : 1.f);
       float* og = a.o + ((long)b * a.Tq + qi) * a.C + h * HDP;
 #pragma unroll
       for (int di = 0; di < 4; ++di) {
@@ -1576,6 +1603,12 @@ bool fwd64_enabled();
 inline bool fast64(const AttnArgs& a, int precision) {
   return precision == 3 && a.hd == 64 && !a.bias && !a.dbias && (a.mode == 0 || a.mode == 2) && !a.drop_thresh && fwd64_enabled();
 }
+bool xl64_enabled();
+// XLNet's relative attention (unshifted position scores as bias, XLNet mask, optional dropout) at hd = 64: attn_fwd64_kernel<true>
+inline bool fast64_xl_fwd(const AttnArgs& a, int precision) {
+  return precision == 3 && a.hd == 64 && a.bias && a.mode == 3 && a.Tq == a.Tk && fwd64_enabled() && xl64_enabled();
+}
+bool xl64_enabled() { static const bool on = [] { const char* e = getenv("VILCO_ATTN_XL_FAST"); return !(e && e[0] == '0'); }(); return on; }
 bool fwd64_enabled() { static const bool on = [] { const char* e = getenv("VILCO_ATTN_FAST"); return !(e && e[0] == '0'); }(); return on; }
 
 template <int HDP, int NP, bool F16 = false>
@@ -1586,10 +1619,15 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
 #ifdef VILCO_LAB_ATTN
       if (const char* e = getenv("VILCO_LAB_ATTN_LDS")) {       // lab: pad the LDS request to limit workgroups per CU
         lds = (size_t)atoi(e);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       }
 #endif
-      hipLaunchKernelGGL(attn_fwd64_kernel, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), lds, s, a);
+      hipLaunchKernelGGL(attn_fwd64_kernel<false>, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), lds, s, a);
+      return vilco_launch_status();
+    }
+    if (fast64_xl_fwd(a, 3)) {
+      const size_t lds = 2 * 2 * PL64 * sizeof(__bf16);
+      hipLaunchKernelGGL(attn_fwd64_kernel<true>, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), lds, s, a);
       return vilco_launch_status();
     }
   }
@@ -1832,7 +1870,7 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   PackQueue pq;
   a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
   a.kn = pack_operand(k, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
-  if (fast64(a, precision))       // the hd = 64 fast kernel reads V from its natural planes (transposing LDS reads)
+  if (fast64(a, precision) || fast64_xl_fwd(a, precision))       // the hd = 64 fast kernels read V from its natural planes (transposing LDS reads)
     a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
   else
     a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
