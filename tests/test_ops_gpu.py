@@ -537,3 +537,24 @@ def test_attention_hd64_fast_path(dev, B, Tq, Tk, H, lens):
     for name in ("q", "k", "v"):
         parts, n = ops._amax_of(got[name])
         assert parts is not None and abs(float(parts[:n].max()) - float(got[name].abs().max())) == 0.0, name
+
+
+@pytest.mark.parametrize("M,N,K,act", [(4608, 1024, 1024, 0), (300, 200, 96, 2), (154, 1024, 4096, 0), (2304, 4096, 1024, 2)])
+def test_gemm_output_amax_partials(dev, M, N, K, act):
+    """vilco_gemm_desc.amax_out: the partial maxima the MFMA kernel's epilogue (or the split-K reduce) leaves equal
+    max|C| of the stored output exactly, for tiled, ragged and split-K plans, with and without an activation"""
+    from vilco_amd import ops
+    torch.manual_seed(M + N)
+    A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+    bias = torch.randn(N, device=dev)
+    C = torch.empty(M, N, device=dev)
+    pre = torch.empty_like(C) if act == 2 else None
+    ops.gemm(A, B, C, M, N, K, 1, 1, K, K, N, bias=bias, preact=pre, act=act, want_amax=True)
+    parts, n = ops._amax_of(C)
+    assert parts is not None and n > 0
+    assert float(parts[:n].max()) == float(C.abs().max())
+    # an in-place edit invalidates the tag (and the remembered operand planes)
+    planes = ops.pack(C, M, N)
+    assert ops.pack(C, M, N) is planes
+    C.mul_(2.0)
+    assert ops._amax_of(C)[0] is None and ops.pack(C, M, N) is not planes
