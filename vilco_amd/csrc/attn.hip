@@ -539,6 +539,24 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
   const AttnScales sc = *a.sc;
   const int bias_ld = a.Tq + a.Tk;
   const float* bias = XL ? a.bias + ((long)bh * a.Tq) * bias_ld : nullptr;
+  // XL: the position scores of a key tile (this wave's 32 query rows x 64 keys, 256 B per row at a 4-byte aligned
+  // offset of the unshifted matrix) are fetched straight into LDS one tile ahead (global_load_lds_dword: one row per
+  // instruction, no registers), so the fetch -- bandwidth-bound, ~11 k cycles per tile when waited for in place -- runs
+  // under the previous tile's MFMAs.  Rows are wave-private: no workgroup barrier is involved.
+  constexpr int RSBF = 68;                                   // floats per staged row (272 B: 16-byte aligned, 4 banks per row)
+  float* sBias = reinterpret_cast<float*>(sV + 2 * PL64) + wave * 32 * RSBF;
+  [[maybe_unused]] auto bias_dma = [&](int k0) {
+    int j = k0 + lane;
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+      int qi = q0 + r;
+      qi = qi < a.Tq ? qi : a.Tq - 1;
+      int pcol = a.Tq - qi + j;
+      pcol = pcol < bias_ld ? pcol : bias_ld - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + (long)qi * bias_ld + pcol),
+                                       (__attribute__((address_space(3))) void*)(sBias + r * RSBF), 4, 0, 0);
+    }
+  };
   const float c2 = a.scale * sc.iq * sc.ik * 1.44269504088896340736f;      // log2-domain score = acc * c2
   const __bf16* kbase = a.kn.p + (long)bh * a.kn.batch_stride;
   const __bf16* vbase = a.vn.p + (long)bh * a.vn.batch_stride;
@@ -632,6 +650,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
       s[0][mi] = c0; s[1][mi] = c1;
     }
     ASTAMP(2);
+    if constexpr (XL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile's position scores have landed
     if constexpr (MASKED && !XL) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -649,10 +668,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
         f32x2 a01 = f32x2{s[g][mi][0], s[g][mi][1]} * c2v, a23 = f32x2{s[g][mi][2], s[g][mi][3]} * c2v;
         if constexpr (XL) {
           const int jb = k0 + mi * 16 + g4 * 4;
-          float bv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (qi_g < a.Tq) bias4(bv, bias, qi_g, jb, bias_ld, a);                     // scale * bd[i][Tq - i + j]
-          a01 += f32x2{bv[0], bv[1]} * 1.44269504088896340736f;
-          a23 += f32x2{bv[2], bv[3]} * 1.44269504088896340736f;
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + (16 * g + (lane & 15)) * RSBF + mi * 16 + g4 * 4);   // bd[i][Tq - i + j]
+          const float bsc = a.scale * 1.44269504088896340736f;
+          a01 += f32x2{bv[0], bv[1]} * bsc;
+          a23 += f32x2{bv[2], bv[3]} * bsc;
           if constexpr (MASKED) {                                                     // keys >= kv_len except the diagonal, keys >= Tk
             if ((jb + 0 >= len && jb + 0 != qi_g) || jb + 0 >= a.Tk) a01[0] = -INFINITY;
             if ((jb + 1 >= len && jb + 1 != qi_g) || jb + 1 >= a.Tk) a01[1] = -INFINITY;
@@ -708,6 +727,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
       }
     }
     ASTAMP(3);
+    if constexpr (XL) {
+      if (more) {                                   // next tile's position scores: this wave has read its rows (LDS queue in order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bias_dma(k0 + BKV);
+      }
+    }
     // O^T[d][q] += V^T P^T, V^T fragments by transposing reads of the natural tile (keys in the order P sits in the registers)
     bf16x8 vf[2][2];
 #pragma unroll
@@ -735,6 +760,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
   };
 
   if (ntiles > 0) gload(0);
+  if constexpr (XL) { if (ntiles > 0) bias_dma(0); }
   const int nfull = (XL ? (len < a.Tk ? len : a.Tk) : kend) / BKV;      // tiles with all 64 keys valid
   for (int t = 0; t < nfull; ++t) tile(t, t + 1 < ntiles, std::false_type{});
   for (int t = nfull; t < ntiles; ++t) tile(t, t + 1 < ntiles, std::true_type{});
@@ -1626,7 +1652,9 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
       return vilco_launch_status();
     }
     if (fast64_xl_fwd(a, 3)) {
-      const size_t lds = 2 * 2 * PL64 * sizeof(__bf16);
+      const size_t lds = 2 * 2 * PL64 * sizeof(__bf16) + 4 * 32 * 68 * sizeof(float);
+      static const bool oncexl = [] { set_lds(&attn_fwd64_kernel<true>, 2 * 2 * PL64 * sizeof(__bf16) + 4 * 32 * 68 * sizeof(float)); return true; }();
+      (void)oncexl;
       hipLaunchKernelGGL(attn_fwd64_kernel<true>, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), lds, s, a);
       return vilco_launch_status();
     }
