@@ -985,6 +985,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 // operand of dQ^T += K^T dS^T (lane 4q+p of a 16-lane group points at key row q / channels 4p..4p+3 and receives channel
 // i's four keys; the two reads of a fragment take keys 32 ks + 4 g4 + {0..3} and + 16, the order dS sits in the
 // registers).  No transposed K planes, no transposed tile in LDS.
+// XL: XLNet's relative attention as in attn_fwd64_kernel<true> (position scores prefetched into LDS by LDS-DMA, XLNet
+// mask, probability dropout) plus the dS store the position-term gradients are derived from (a.dbias, [B,H,Tq,Tk])
+template <bool XL>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs a) {
   constexpr int HDP = 64, BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -999,12 +1002,29 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
   const int bh = b * a.H + h;
   const int q0 = blockIdx.x * F64_Q + wave * 32;
   const int len = a.mode == 2 ? a.Tk : a.kv_len[b];
-  const int kend = len < a.Tk ? len : a.Tk;
+  const int kend = XL ? a.Tk : (len < a.Tk ? len : a.Tk);
   const int ntiles = (kend + BKV - 1) / BKV;
   const long row_bh = (long)bh * a.Tq;
   const AttnScales sc = *a.sc;
   const float c2 = a.scale * sc.iq * sc.ik * 1.44269504088896340736f;      // log2-domain score = acc * c2
-  const float ds_unscale = DS_INV * sc.ido * sc.iv;                         // dS = dS' * this
+  const float ds_unscale = DS_INV * sc.ido * sc.iv * (XL ? a.drop_inv_keep : 1.f);      // dS = dS' * this
+  const int bias_ld = a.Tq + a.Tk;
+  const float* bias = XL ? a.bias + row_bh * bias_ld : nullptr;
+  float* dbias = XL ? a.dbias + row_bh * a.Tk : nullptr;
+  constexpr int RSBF = 68;                                   // see attn_fwd64_kernel
+  float* sBias = reinterpret_cast<float*>(sV + 2 * PL64) + wave * 32 * RSBF;
+  [[maybe_unused]] auto bias_dma = [&](int k0) {
+    const int j = k0 + lane;
+#pragma unroll 4
+    for (int r = 0; r < 32; ++r) {
+      int qi = q0 + r;
+      qi = qi < a.Tq ? qi : a.Tq - 1;
+      int pcol = a.Tq - qi + j;
+      pcol = pcol < bias_ld ? pcol : bias_ld - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + (long)qi * bias_ld + pcol),
+                                       (__attribute__((address_space(3))) void*)(sBias + r * RSBF), 4, 0, 0);
+    }
+  };
   const __bf16* knb = a.kn.p + (long)bh * a.kn.batch_stride;
   const __bf16* vnb = a.vn.p + (long)bh * a.vn.batch_stride;
   const int g4 = lane >> 4;
@@ -1038,6 +1058,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
     delta_i += __shfl_xor(delta_i, 32, 64);
     if (g4 == 0 && qi < a.Tq) a.delta[row_bh + qi] = delta_i;
     dlt[g] = (delta_i * sc.sdo) * sc.sv;                   // plane units; never form sdO * sV (see attn_bwd_dq_kernel)
+    if constexpr (XL) dlt[g] /= a.drop_inv_keep;           // dS = inv_keep P (M dP - (1-p) delta)
   }
 
   f32x4 dqacc[2][4];
@@ -1082,6 +1103,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
     __syncthreads();
     if (more) gload(k0 + BKV);
 
+    if constexpr (XL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile's position scores have landed (the K / V prefetch too)
     bf16x8 dsf[2][2][2];                            // [group][32-key half][part]: dS^T B fragments, built in registers
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
@@ -1114,7 +1136,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
           d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, oa0, d0, 0, 0, 0);
           d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0h, ob0, d1, 0, 0, 0);
         }
-        if constexpr (MASKED) {
+        if constexpr (MASKED && !XL) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (k0 + mi * 16 + g4 * 4 + r >= kend) { s0[r] = -INFINITY; s1[r] = -INFINITY; }
@@ -1124,14 +1146,36 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const f32x2 lv = {-lse2[g], -lse2[g]}, dv = {-dlt[g], -dlt[g]};
+        [[maybe_unused]] const int qi_g = q0 + 16 * g + (lane & 15);
         u32x4 h0, h1;
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           const f32x2 sv = {s[g][e >> 2][e & 3], s[g][e >> 2][(e & 3) + 1]};
-          const f32x2 pv = {dp[g][e >> 2][e & 3], dp[g][e >> 2][(e & 3) + 1]};
-          const f32x2 arg = sv * c2v + lv;                 // v_pk_fma_f32
+          f32x2 pv = {dp[g][e >> 2][e & 3], dp[g][e >> 2][(e & 3) + 1]};
+          f32x2 arg = sv * c2v + lv;                       // v_pk_fma_f32
+          [[maybe_unused]] const int j = k0 + (2 * kh + (e >> 2)) * 16 + g4 * 4 + (e & 3);
+          if constexpr (XL) {
+            const float* bp = sBias + (16 * g + (lane & 15)) * RSBF + (j - k0);
+            const float bsc = a.scale * 1.44269504088896340736f;
+            arg += f32x2{bp[0], bp[1]} * bsc;                                     // + scale * bd[i][Tq - i + j]
+            if constexpr (MASKED) {
+              if ((j >= len && j != qi_g) || j >= a.Tk) arg[0] = -INFINITY;
+              if ((j + 1 >= len && j + 1 != qi_g) || j + 1 >= a.Tk) arg[1] = -INFINITY;
+            }
+            if (a.drop_thresh) {                                                   // dP of a dropped probability is zero
+              pv[0] *= drop_keep(a, bh, qi_g, j);
+              pv[1] *= drop_keep(a, bh, qi_g, j + 1);
+            }
+          }
           const f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};      // P * 2^-22
           const f32x2 d = p * (pv + dv);                   // dS' = P (dP - delta) 2^-22, |dS'| < 2^15
+          if constexpr (XL) {                              // dS of this pair for the position-term gradients
+            if (qi_g < a.Tq) {
+              float* dst = dbias + (long)qi_g * a.Tk + j;
+              if (j + 1 < a.Tk) { *reinterpret_cast<float2*>(dst) = make_float2(d[0] * ds_unscale, d[1] * ds_unscale); }
+              else if (j < a.Tk) dst[0] = d[0] * ds_unscale;
+            }
+          }
           const f16x2 hp = {(_Float16)d[0], (_Float16)d[1]};
           const uint32_t hpu = __builtin_bit_cast(uint32_t, hp);
           uint32_t lo;
@@ -1142,6 +1186,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
         }
         dsf[g][kh][0] = __builtin_bit_cast(bf16x8, h0);
         dsf[g][kh][1] = __builtin_bit_cast(bf16x8, h1);
+      }
+    }
+    if constexpr (XL) {
+      if (more) {                                   // next tile's position scores (this wave has read its rows: LDS queue in order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bias_dma(k0 + BKV);
       }
     }
     // dQ^T[d][q] += K^T dS^T, K^T fragments by transposing reads of the natural tile
@@ -1166,9 +1216,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
   };
 
   if (ntiles > 0) gload(0);
-  const int nfull = kend / BKV;
+  if constexpr (XL) { if (ntiles > 0) bias_dma(0); }
+  const int nfull = (XL ? (len < a.Tk ? len : a.Tk) : kend) / BKV;
   for (int t = 0; t < nfull; ++t) tile(t, t + 1 < ntiles, std::false_type{});
-  if (nfull < ntiles) tile(nfull, false, std::true_type{});
+  for (int t = nfull; t < ntiles; ++t) tile(t, t + 1 < ntiles, std::true_type{});
 
   const float oscale = a.scale * ds_unscale * sc.ik;
   float am = 0.f;
@@ -1692,9 +1743,19 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
   if (fast) {
     if constexpr (HDP == 64 && NP == 2 && F16) {
       constexpr size_t l64 = 2 * 2 * PL64 * sizeof(__bf16);
-      hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), l64, s, a);
+      hipLaunchKernelGGL(attn_bwd_dq64_kernel<false>, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), l64, s, a);
       hipLaunchKernelGGL(attn_bwd_dkdv64_kernel, gk, dim3(ATT_THREADS), l64, s, a);
       return vilco_launch_status();
+    }
+  }
+  bool xl_dq = false;                               // XLNet's relative attention: dQ + dS on the fast-path structure
+  if constexpr (HDP == 64 && NP == 2 && F16) xl_dq = fast64_xl_fwd(a, 3) && a.dbias != nullptr;
+  if (xl_dq) {
+    if constexpr (HDP == 64 && NP == 2 && F16) {
+      constexpr size_t lxl = 2 * 2 * PL64 * sizeof(__bf16) + 4 * 32 * 68 * sizeof(float);
+      static const bool oncexl = [] { set_lds(&attn_bwd_dq64_kernel<true>, 2 * 2 * PL64 * sizeof(__bf16) + 4 * 32 * 68 * sizeof(float)); return true; }();
+      (void)oncexl;
+      hipLaunchKernelGGL(attn_bwd_dq64_kernel<true>, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), lxl, s, a);
     }
   } else if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16, true>), gq, dim3(ATT_THREADS), lq, s, a);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16, false>), gq, dim3(ATT_THREADS), lq, s, a);
