@@ -1246,6 +1246,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
 // dV^T += dO^T P and dK^T += Q^T dS: P and dS never leave the registers.  The Q and dO tiles sit in LDS once,
 // natural layout (row stride 80), read by 16-byte fragment reads for S / dP and by the transposing ds_read_b64_tr_b16
 // for the dO^T / Q^T operands -- no transposed planes of q and dO are packed for this path.
+// XL: XLNet's relative attention.  The position scores of a (64-query tile, this workgroup's 64 keys) pair are 64 rows of
+// 256 B in the unshifted matrix; they are fetched by LDS-DMA (16 rows per wave) one tile ahead into a double-buffered
+// [64 q][68] LDS image that all four waves read (lane = key, 16 queries per lane and tile: scalar LDS reads).
+template <bool XL>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArgs a) {
   constexpr int HDP = 64, BQ = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1270,7 +1274,24 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
   const int fbn = (lane & 15) * RS64 + g4 * 8;
   const int fbt = (4 * g4 + ((lane & 15) >> 2)) * RS64 + 4 * (lane & 3);
   const int key = k0 + wave * 16 + (lane & 15);
-  const float koff = key < kend ? 0.f : -INFINITY;       // a masked key: every probability of this lane is exp2(-inf) = 0
+  const float koff = (XL || key < kend) ? 0.f : -INFINITY;       // a masked key: every probability of this lane is exp2(-inf) = 0
+  const int bias_ld = a.Tq + a.Tk;
+  const float* bias = XL ? a.bias + row_bh * bias_ld : nullptr;
+  constexpr int RSBF = 68;
+  float* sBias = reinterpret_cast<float*>(sdO + 2 * PL64);     // [2 stages][64 q][RSBF]
+  [[maybe_unused]] auto bias_dma = [&](int q0, int stage) {     // this wave's 16 query rows of the tile
+    int jcol = k0 + lane;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+      int qi = q0 + wave * 16 + r;
+      qi = qi < a.Tq ? qi : a.Tq - 1;
+      int pcol = a.Tq - qi + jcol;
+      pcol = pcol < bias_ld ? pcol : bias_ld - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + (long)qi * bias_ld + pcol),
+                                       (__attribute__((address_space(3))) void*)(sBias + (stage * 64 + __builtin_amdgcn_readfirstlane(wave) * 16 + r) * RSBF), 4, 0, 0);
+    }
+  };
+  const bool xl_edge = XL && (k0 + 64 > len || k0 + 64 > a.Tk);      // some key of this workgroup is beyond kv_len / Tk
 
   QFrag<HDP, 2> kf, vf;                                     // B fragments of this wave's 16 keys (rows >= Tk read as zero)
   load_qfrag<HDP, 2>(kf, a.kn, a.kn.p + (long)bh * a.kn.batch_stride, k0 + wave * 16, lane);
@@ -1316,14 +1337,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
   const f16x8 v0h[2] = {__builtin_bit_cast(f16x8, vf.f[0][0]), __builtin_bit_cast(f16x8, vf.f[1][0])};
   const f16x8 v1h[2] = {__builtin_bit_cast(f16x8, vf.f[0][1]), __builtin_bit_cast(f16x8, vf.f[1][1])};
 
-  const int nq = k0 < kend ? (a.Tq + BQ - 1) / BQ : 0;     // every key of this tile masked: the gradients are zero
+  const int nq = (XL || k0 < kend) ? (a.Tq + BQ - 1) / BQ : 0;     // every key of this tile masked: the gradients are zero
   if (nq > 0) gload(0);
+  if constexpr (XL) { if (nq > 0) bias_dma(0, 0); }
   for (int t = 0; t < nq; ++t) {
     const int q0 = t * BQ;
-    __syncthreads();                                // previous tile fully consumed
+    if constexpr (XL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of tile t's position scores has landed
+    __syncthreads();                                // previous tile fully consumed (and every wave's DMA rows visible)
     lstore();
     __syncthreads();
-    if (t + 1 < nq) gload(q0 + BQ);
+    if (t + 1 < nq) {
+      gload(q0 + BQ);
+      if constexpr (XL) bias_dma(q0 + BQ, (t + 1) & 1);        // stage (t+1)&1 was last read in tile t-1: before the barrier above
+    }
+    [[maybe_unused]] const float* sB = sBias + (t & 1) * 64 * RSBF;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {                // 32 queries at a time: one k-step of the dV / dK products
       // lse and delta of this lane's 8 queries (16 bb + 4 g4 + r of this half); queries >= Tq: 0 (see gload)
@@ -1375,12 +1402,30 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
         // P 2^15 = exp2(acc c2 - lse log2(e) + 15 [+ -inf for a masked key])
         const f32x2 lv = {__builtin_fmaf(la, -1.44269504088896340736f, 15.f) + koff, __builtin_fmaf(lb, -1.44269504088896340736f, 15.f) + koff};
         const f32x2 sv = {s[bb][r], s[bb][r + 1]};
-        const f32x2 arg = sv * c2v + lv;
-        const f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+        f32x2 arg = sv * c2v + lv;
+        [[maybe_unused]] const int qa = q0 + 32 * kh + 16 * bb + 4 * g4 + r;        // this pair's queries qa, qa + 1
+        [[maybe_unused]] float keep0 = 1.f, keep1 = 1.f;
+        if constexpr (XL) {
+          const int ql = 32 * kh + 16 * bb + 4 * g4 + r, jj = wave * 16 + (lane & 15);
+          const float bsc = a.scale * 1.44269504088896340736f;
+          arg += f32x2{sB[ql * RSBF + jj], sB[(ql + 1) * RSBF + jj]} * bsc;          // + scale * bd[i][Tq - i + j]
+          if (xl_edge) {
+            if ((key >= len && key != qa) || key >= a.Tk) arg[0] = -INFINITY;
+            if ((key >= len && key != qa + 1) || key >= a.Tk) arg[1] = -INFINITY;
+          }
+          // a query row beyond Tq has zero Q / dO rows and lse = 0, but the position score of the clamped row is added:
+          // keep its probability out (2^15 * 2^score would leave the fp16 range and meet the zeros as inf * 0)
+          if (qa >= a.Tq) arg[0] = -INFINITY;
+          if (qa + 1 >= a.Tq) arg[1] = -INFINITY;
+          if (a.drop_thresh) { keep0 = drop_keep(a, bh, qa, key); keep1 = drop_keep(a, bh, qa + 1, key); }
+        }
+        f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
         // (dP - delta) 2^-37, delta brought to plane units one scale at a time (see attn_bwd_dq_kernel)
-        const f32x2 dv = {(da * sc.sdo) * sc.sv, (db * sc.sdo) * sc.sv};
-        const f32x2 pv = {dp[bb][r], dp[bb][r + 1]};
+        f32x2 dv = {(da * sc.sdo) * sc.sv, (db * sc.sdo) * sc.sv};
+        f32x2 pv = {dp[bb][r], dp[bb][r + 1]};
+        if constexpr (XL) { dv = dv / f32x2{a.drop_inv_keep, a.drop_inv_keep}; pv = pv * f32x2{keep0, keep1}; }
         const f32x2 d = p * ((pv - dv) * t37v);
+        if constexpr (XL) p = p * f32x2{keep0, keep1};       // dV sees the dropped probabilities
         const f16x2 hp = {(_Float16)p[0], (_Float16)p[1]}, hd = {(_Float16)d[0], (_Float16)d[1]};
         const uint32_t hpu = __builtin_bit_cast(uint32_t, hp), hdu = __builtin_bit_cast(uint32_t, hd);
         uint32_t lp, ld;
@@ -1415,7 +1460,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
   if (key < a.Tk) {
     float* gk = a.dk + ((long)b * a.Tk + key) * a.C + h * HDP;
     float* gv = a.dv + ((long)b * a.Tk + key) * a.C + h * HDP;
-    const float ksc = a.scale * (DS_INV * sc.ido * sc.iv) * sc.iq, vsc = P_INV * sc.ido;
+    const float ik = XL ? a.drop_inv_keep : 1.f;
+    const float ksc = a.scale * (DS_INV * sc.ido * sc.iv) * sc.iq * ik, vsc = P_INV * sc.ido * ik;
 #pragma unroll
     for (int di = 0; di < 4; ++di) {
       const int d = di * 16 + g4 * 4;
@@ -1744,7 +1790,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     if constexpr (HDP == 64 && NP == 2 && F16) {
       constexpr size_t l64 = 2 * 2 * PL64 * sizeof(__bf16);
       hipLaunchKernelGGL(attn_bwd_dq64_kernel<false>, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), l64, s, a);
-      hipLaunchKernelGGL(attn_bwd_dkdv64_kernel, gk, dim3(ATT_THREADS), l64, s, a);
+      hipLaunchKernelGGL(attn_bwd_dkdv64_kernel<false>, gk, dim3(ATT_THREADS), l64, s, a);
       return vilco_launch_status();
     }
   }
@@ -1756,6 +1802,11 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
       static const bool oncexl = [] { set_lds(&attn_bwd_dq64_kernel<true>, 2 * 2 * PL64 * sizeof(__bf16) + 4 * 32 * 68 * sizeof(float)); return true; }();
       (void)oncexl;
       hipLaunchKernelGGL(attn_bwd_dq64_kernel<true>, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), lxl, s, a);
+      constexpr size_t lkx = 2 * 2 * PL64 * sizeof(__bf16) + 2 * 64 * 68 * sizeof(float);
+      static const bool oncekx = [] { set_lds(&attn_bwd_dkdv64_kernel<true>, 2 * 2 * PL64 * sizeof(__bf16) + 2 * 64 * 68 * sizeof(float)); return true; }();
+      (void)oncekx;
+      hipLaunchKernelGGL(attn_bwd_dkdv64_kernel<true>, gk, dim3(ATT_THREADS), lkx, s, a);
+      return vilco_launch_status();
     }
   } else if (a.drop_thresh) hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16, true>), gq, dim3(ATT_THREADS), lq, s, a);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NP, F16, false>), gq, dim3(ATT_THREADS), lq, s, a);
@@ -2013,7 +2064,7 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   __bf16* w = reinterpret_cast<__bf16*>(wsb + ATT_SCALE_BYTES);
   PackQueue pq;
   // the hd = 64 fast kernels read every operand from its natural planes only (transposing LDS reads)
-  const bool nat_only = fast64(a, precision);
+  const bool nat_only = fast64(a, precision) || (fast64_xl_fwd(a, precision) && a.dbias != nullptr);
   a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
   a.don = pack_operand(dout, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6, &pq);
   if (!nat_only) {
