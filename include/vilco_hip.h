@@ -109,6 +109,10 @@ typedef struct vilco_gemm_desc {
   /* here -- one per workgroup of the kernel that writes C -- for the operand pack of the next product                  */
   /* (vilco_pack_item.amax), which then needs no pass of its own over C.  NULL: not wanted.                             */
   float* amax_out;
+  /* optional (precision 3, operands the call packs itself -- A / B given as fp32): max|x| partials of the WHOLE operand  */
+  /* tensor already on the device, left by the kernel that produced it; the call then skips its amax pass over it.      */
+  const float* a_amax; int32_t a_namax;
+  const float* b_amax; int32_t b_namax;
 } vilco_gemm_desc;
 
 size_t vilco_gemm_workspace(const vilco_gemm_desc* d);

@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("band", i32), ("bandT", i32),
         ("drop_p", f32), ("drop_seed", C.c_uint32),
         ("amax_out", c_fp),
+        ("a_amax", c_fp), ("a_namax", i32), ("b_amax", c_fp), ("b_namax", i32),
     ]
 
 

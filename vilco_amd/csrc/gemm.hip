@@ -861,12 +861,19 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (f16 && (packA || packB)) {
     // k-contiguous operands: amax + pack in one launch each (grid barrier, pack.h); transposing packs keep the amax launch
     AmaxOp ma = amax_view(pa, p.a_tr, p.a_nbo, scales), mb = amax_view(pb, p.b_tr, p.b_nbo, scales + AMAX_MAX_BLOCKS);
-    if (packA && !p.a_tr) doneA = dispatch_pack_fused(p.NP, &pa, &ma, 1, p.a_nbo * p.a_nbi, s, VILCO_SITE_GEMMPACK);
-    if (packB && !p.b_tr) doneB = dispatch_pack_fused(p.NP, &pb, &mb, 1, p.b_nbo * p.b_nbi, s, VILCO_SITE_GEMMPACK);
+    if (packA && !p.a_tr && !d->a_amax) doneA = dispatch_pack_fused(p.NP, &pa, &ma, 1, p.a_nbo * p.a_nbi, s, VILCO_SITE_GEMMPACK);
+    if (packB && !p.b_tr && !d->b_amax) doneB = dispatch_pack_fused(p.NP, &pb, &mb, 1, p.b_nbo * p.b_nbi, s, VILCO_SITE_GEMMPACK);
     AmaxArgs am;
     int nops = 0;
-    if (!doneA) { am.op[nops++] = ma; pa.namax = ma.nblocks; }
-    if (!doneB) { am.op[nops++] = mb; pb.namax = mb.nblocks; }
+    // partials left by the producer of A / B (vilco_gemm_desc.a_amax / b_amax) replace the amax pass over that operand
+    if (!doneA) {
+      if (d->a_amax && d->a_namax > 0) { pa.amax = d->a_amax; pa.namax = d->a_namax; }
+      else { am.op[nops++] = ma; pa.namax = ma.nblocks; }
+    }
+    if (!doneB) {
+      if (d->b_amax && d->b_namax > 0) { pb.amax = d->b_amax; pb.namax = d->b_namax; }
+      else { am.op[nops++] = mb; pb.namax = mb.nblocks; }
+    }
     if (nops) launch_amax(am, nops, s);
   }
   if (!doneA) dispatch_pack(p.NP, pa, p.a_tr, p.a_nbo * p.a_nbi, s);

@@ -145,7 +145,8 @@ def dropout(x, p, training, site="dropout"):
 def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), sB=(0, 0),
          sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
          bias=None, preact=None, act=ACT_NONE, row_len=None, rowT=0, colscale=None, residual=None,
-         res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0, drop=(0.0, 0), want_amax=False):
+         res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0, drop=(0.0, 0), want_amax=False,
+         a_amax=None, b_amax=None):
     """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements.  a_planes / b_planes: operands
     already packed by `pack` (the fp32 tensor may then be None).  want_amax: the call writes ALL of Cc, which goes on
     into another product -- the kernel leaves max|C| partials and Cc is tagged with them (`_tag_amax`)."""
@@ -178,6 +179,10 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     nbytes = lib.vilco_gemm_workspace(C.byref(d))      # bf16 operand planes + split-K partials
     ws = torch.empty(nbytes, dtype=torch.uint8, device=Cc.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    for pre, am in (("a", a_amax), ("b", b_amax)):          # (partials, count) of an operand this call packs itself
+        if am is not None and am[0] is not None and d.precision in (3, 4):
+            setattr(d, pre + "_amax", am[0].data_ptr())
+            setattr(d, pre + "_namax", int(am[1]))
     parts, n = None, 0
     if want_amax and produce_amax and d.precision == 3:
         n = int(lib.vilco_gemm_amax_parts(C.byref(d)))
@@ -474,7 +479,7 @@ class _Conv3(torch.autograd.Function):
         wp, pwp = _cached(w, "conv3_fwd", lambda: _conv3_weight(w, (Cout, 3, Cin), 0, (Cin * 3, 1, 3), Cout, 3 * Cin))
         y = torch.empty(B, T, Cout, dtype=torch.float32, device=x.device)
         gemm(x, wp, y, B * T, Cout, 3 * Cin, 1, 1, Cin, 3 * Cin, Cout, tap=TAP_A, tapC=Cin, tapT=T,
-             bias=b, row_len=lens, rowT=T, b_planes=pwp)
+             bias=b, row_len=lens, rowT=T, b_planes=pwp, a_amax=_amax_of(x))
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, lens)
         return y
@@ -496,11 +501,11 @@ class _Conv3(torch.autograd.Function):
             wt, pwt = _cached(w, "conv3_dx", lambda: _conv3_weight(w, (Cin, 3, Cout), 2, (3, -1, Cin * 3), Cin, 3 * Cout))
             dx = torch.empty_like(x)
             gemm(dz, wt, dx, B * T, Cin, 3 * Cout, 1, 1, Cout, 3 * Cout, Cin, tap=TAP_A, tapC=Cout,
-                 tapT=T, b_planes=pwt)
+                 tapT=T, b_planes=pwt, a_amax=_amax_of(dz))
         if ctx.needs_input_grad[1]:
             dwp = torch.empty(Cout, 3 * Cin, dtype=torch.float32, device=x.device)
             gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
-                 tapT=T, precision=_dw_prec(_precision, B * T))
+                 tapT=T, precision=_dw_prec(_precision, B * T), a_amax=_amax_of(dz), b_amax=_amax_of(x))
             dw = permute3(dwp, (Cout, Cin, 3), 0, (3 * Cin, 1, Cin))
         return dx, dw, db, None
 
