@@ -229,7 +229,8 @@ int vilco_attn_supported(int32_t hd);
 /* Output amax partials.  The hd = 64 / fp16 x2 / prefix-mask / no-bias / no-dropout kernels can leave max|x| partials of
  * their outputs (one float per workgroup) for the operand pack of the next product (vilco_pack_item.amax), which then
  * skips its amax launch.  Returns how many floats the o / dq buffer (key_side = 0, T = Tq) or the dk / dv buffers
- * (key_side = 1, T = Tk) must hold, or 0 when this configuration does not emit them (pass null then). */
+ * (key_side = 1, T = Tk) must hold, or 0 when this configuration does not emit them (pass null then).  has_bias = 2
+ * asks for the dS (dbias) partials of XLNet's relative attention (mask mode 3, Tq = Tk = T, key_side 0: dbias_amax). */
 int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_t hd, int32_t mode, int32_t precision,
                               int32_t has_bias, float drop_p, int32_t key_side);
 /* Input amax partials (precision 3): max|x| partials of q / k / v / dout already on the device, e.g. left by the GEMM   */
@@ -255,7 +256,7 @@ int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* 
                    float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
                    int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                    uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* dq_amax, float* dk_amax, float* dv_amax,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   float* dbias_amax, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Candidate decode of PtTransformer.inference_single_video (MQ meta_archs.py:1594-1692, NLQ meta_archs.py:1253-1338)   */

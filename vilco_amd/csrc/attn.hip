@@ -205,7 +205,7 @@ struct AttnArgs {
   float drop_inv_keep;
   // optional max|x| partials of the outputs (one per workgroup), left for the operand pack of the next product
   // (vilco_pack_item.amax); written by the hd = 64 fast kernels only (vilco_attn_amax_parts)
-  float* am_o; float* am_dq; float* am_dk; float* am_dv;
+  float* am_o; float* am_dq; float* am_dk; float* am_dv; float* am_ds;
 };
 
 // registers holding the B-operand fragments of this wave's 16 query rows (all k-steps, all parts)
@@ -1094,6 +1094,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
     }
   };
   const f32x2 c2v = {c2, c2};
+  [[maybe_unused]] float am_ds = 0.f;               // XL: max |dS| this thread stored (for the relshift pack's scale)
 
   auto tile = [&](int t, bool more, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
@@ -1172,8 +1173,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
           if constexpr (XL) {                              // dS of this pair for the position-term gradients
             if (qi_g < a.Tq) {
               float* dst = dbias + (long)qi_g * a.Tk + j;
-              if (j + 1 < a.Tk) { *reinterpret_cast<float2*>(dst) = make_float2(d[0] * ds_unscale, d[1] * ds_unscale); }
-              else if (j < a.Tk) dst[0] = d[0] * ds_unscale;
+              const float v0 = d[0] * ds_unscale, v1 = d[1] * ds_unscale;
+              if (j + 1 < a.Tk) { *reinterpret_cast<float2*>(dst) = make_float2(v0, v1); am_ds = fmaxf(am_ds, fmaxf(fabsf(v0), fabsf(v1))); }
+              else if (j < a.Tk) { dst[0] = v0; am_ds = fmaxf(am_ds, fabsf(v0)); }
             }
           }
           const f16x2 hp = {(_Float16)d[0], (_Float16)d[1]};
@@ -1237,6 +1239,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
     }
   }
   if (a.am_dq) block_amax_out(am, a.am_dq, reinterpret_cast<float*>(smem_raw));
+  if constexpr (XL) { if (a.am_ds) block_amax_out(am_ds, a.am_ds, reinterpret_cast<float*>(smem_raw)); }
 }
 
 // ------------------------------------------------------------------------------------------ backward dK / dV, hd = 64 fast path
@@ -1964,6 +1967,12 @@ extern "C" int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_
   AttnArgs a = {};
   a.hd = hd; a.mode = mode; a.drop_thresh = vilco_drop_threshold_host(drop_p);
   if (has_bias) a.bias = reinterpret_cast<const float*>(&a);      // only its nullness is looked at
+  if (has_bias == 2) {           // the dS (dbias) partials of XLNet's relative attention: attn_bwd_dq64_kernel<true>, one per workgroup
+    a.Tq = a.Tk = T;
+    if (B <= 0 || H <= 0 || T <= 0 || key_side || !fast64_xl_fwd(a, precision)) return 0;
+    const long nx = (long)((T + F64_Q - 1) / F64_Q) * H * B;
+    return nx <= 8192 ? (int32_t)nx : 0;
+  }
   if (B <= 0 || H <= 0 || T <= 0 || !fast64(a, precision)) return 0;
   const long n = (long)((T + (key_side ? 63 : F64_Q - 1)) / (key_side ? 64 : F64_Q)) * H * B;
   return n <= 8192 ? (int32_t)n : 0;
@@ -2031,7 +2040,7 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
                               float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
                               int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                               uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* dq_amax, float* dk_amax,
-                              float* dv_amax, void* workspace, size_t workspace_bytes, void* stream) {
+                              float* dv_amax, float* dbias_amax, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision, window);
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
@@ -2052,6 +2061,8 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   a.dout = dout; a.delta = delta; a.o_in = o; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
   if ((dq_amax || dk_amax || dv_amax) && !fast64(a, precision)) return VILCO_ERR_UNSUPPORTED;      // see vilco_attn_amax_parts
   a.am_dq = dq_amax; a.am_dk = dk_amax; a.am_dv = dv_amax;
+  if (dbias_amax && !(fast64_xl_fwd(a, precision) && dbias)) return VILCO_ERR_UNSUPPORTED;       // XLNet fast path only (has_bias = 2)
+  a.am_ds = dbias_amax;
   ScaleWs sw;
   if (precision == 3) {
     const float* const xs[4] = {q, k, v, dout};

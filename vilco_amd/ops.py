@@ -252,10 +252,14 @@ def pack_many(items, precision=None, nbatch=1, relshift=False):
     lib = _lib.load()
     prec = _precision if precision is None else int(precision)
     arr = (_lib.PackItem * len(items))()
-    bufs = []
+    bufs, keep = [], []
     for it, (x, rows, cols) in zip(arr, items):
         it.src, it.rows, it.cols, it.ld = x.data_ptr(), int(rows), int(cols), int(cols)
         it.nbatch, it.batch_stride, it.relshift = int(nbatch), int(rows) * int(cols), int(bool(relshift))
+        parts, n = _amax_of(x) if prec == 3 else (None, 0)       # max|x| partials left by the producer of the whole tensor
+        if parts is not None:
+            it.amax, it.namax = parts.data_ptr(), n
+            keep.append(parts)
         nbytes = lib.vilco_pack_item_bytes(C.byref(it), prec)
         buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         it.planes, it.planes_bytes = buf.data_ptr(), nbytes
@@ -872,11 +876,17 @@ def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, dr
     am = torch.empty(nq + 2 * nk, dtype=torch.float32, device=q.device) if nq and nk else None
     aq, ak, av = (am[:nq], am[nq:nq + nk], am[nq + nk:]) if am is not None else (None, None, None)
     ain = _attn_amax_in(q, k, v, do)
+    nds = 0
+    if want_dbias and bias is not None and produce_amax and _precision == 3 and mode == MASK_XLNET_REL and Tq == Tk:
+        nds = int(lib.vilco_attn_amax_parts(B, H, Tq, Cn // H, int(mode), _precision, 2, float(drop[0]), 0))
+    ads = torch.empty(nds, dtype=torch.float32, device=q.device) if nds else None
     _lib.check(lib.vilco_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
                                   lse.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                   _p(dbias), B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
-                                  int(drop[1]), C.byref(ain[0]) if ain else None, _p(aq), _p(ak), _p(av), ws.data_ptr(), nws,
-                                  _stream()))
+                                  int(drop[1]), C.byref(ain[0]) if ain else None, _p(aq), _p(ak), _p(av), _p(ads), ws.data_ptr(),
+                                  nws, _stream()))
+    if ads is not None:
+        _tag_amax(dbias, ads, nds)
     if am is not None:
         _tag_amax(dq, aq, nq)
         _tag_amax(dk, ak, nk)
