@@ -11,11 +11,9 @@ inference), same state_dict keys and the attributes / methods train_cl.py reads.
 (backbone, neck, heads) runs token-major on libvilco_hip.so; label assignment and the loss
 reductions are [4536 x N] / [#valid x ncls] device tensor expressions under autograd.
 """
-import copy
 import math
 import os
 
-import numpy as np
 import torch
 from torch import nn
 from torch.nn import functional as F

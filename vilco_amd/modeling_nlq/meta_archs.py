@@ -19,7 +19,6 @@ import os
 import torch
 from torch import nn
 
-from .. import ops
 from ..cl_methods import Prompt
 from ..modeling import meta_archs as mq
 from ..modeling.models import make_generator, make_neck
