@@ -268,7 +268,8 @@ def _attn_ref(q, k, v, lens, H, scale, xl=False):
 
 @pytest.mark.parametrize("flash", [True, False])
 @pytest.mark.parametrize("B,Tq,Tk,H,hd", [(2, 64, 64, 4, 16), (2, 40, 77, 4, 16), (1, 130, 130, 2, 64), (2, 32, 5, 4, 8),
-                                          (2, 200, 157, 3, 32), (1, 96, 300, 2, 64), (1, 64, 64, 2, 128)])
+                                          (2, 200, 157, 3, 32), (1, 96, 300, 2, 64), (1, 64, 64, 2, 128), (2, 200, 157, 2, 128),
+                                          (1, 130, 300, 1, 96), (2, 77, 77, 3, 72)])
 def test_attention(dev, B, Tq, Tk, H, hd, flash):
     from vilco_amd import ops
     ops.use_flash = flash
@@ -300,7 +301,7 @@ def test_attention_precision_modes(dev, mode, tol):
 
 
 @pytest.mark.parametrize("flash,T,hd", [(True, 48, 16), (False, 48, 16), (True, 100, 64), (False, 100, 64),
-                                         (True, 576, 64)])     # 576: several key tiles, band GEMM + relshift pack
+                                         (True, 576, 64), (True, 100, 128)])     # 576: several key tiles, band GEMM + relshift pack
 def test_rel_attention(dev, flash, T, hd):
     """XLNet core vs the published formula incl. rel_shift_bnij (modeling_xlnet_x.py:256-320)."""
     from vilco_amd import ops
@@ -372,7 +373,7 @@ def test_dropout_op(dev):
     assert not torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("T,hd", [(100, 16), (130, 64)])
+@pytest.mark.parametrize("T,hd", [(100, 16), (130, 64), (130, 128)])
 def test_attention_prob_dropout(dev, T, hd):
     """attention with dropout on the probabilities == reference attention with the same mask (fwd + grads)."""
     from vilco_amd import ops
@@ -422,17 +423,19 @@ def test_attention_zero_upstream_gradient(dev):
 
 
 def test_attention_randomized_shapes(dev):
-    """40 seeded random problems (ragged lengths, every head dim 4..64 that is a multiple of 4, cross-attention shapes,
+    """48 seeded random problems (ragged lengths, head dims 4..128 that are multiples of 4, cross-attention shapes,
     with / without probability dropout, both fp32-equivalent precisions) against an fp64 reference: forward and all
     three gradients."""
     from vilco_amd import ops
     rng = np.random.RandomState(1234)
-    for case in range(40):
+    for case in range(48):
         B, H = int(rng.randint(1, 4)), int(rng.randint(1, 5))
-        hd = int(rng.choice([4, 8, 12, 16, 24, 32, 40, 48, 64]))
+        hd = int(rng.choice([4, 8, 12, 16, 24, 32, 40, 48, 64])) if case < 40 else int(rng.choice([68, 96, 100, 128]))
         Tq, Tk = int(rng.randint(1, 300)), int(rng.randint(1, 300))
         p = float(rng.choice([0.0, 0.0, 0.15, 0.5]))
         prec = str(rng.choice(["f16x2", "f16x2", "split3"]))
+        if hd > 64:
+            prec = "f16x2"                      # bf16 x3 above hd 64 has no fused kernels (LDS), hence no dropout
         torch.manual_seed(1000 + case)
         C = H * hd
         q = torch.randn(B, Tq, C, device=dev, requires_grad=True)

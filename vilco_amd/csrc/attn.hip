@@ -183,6 +183,9 @@ __device__ __forceinline__ f32x4 mfma_parts(const bf16x8 (&a)[3], const bf16x8 (
 // into fp16 range by fixed powers of two: P <= 1 is stored as P * 2^15, and dS = P (dP - delta) as dS * 2^-22 sdO sV,
 // which is < 2^15 because |dP|, |delta| <= hd * amax(dO) * amax(V) with hd <= 64 and amax * s < 2^15.
 constexpr float P_SCALE = 32768.f, P_INV = 1.f / 32768.f, DS_SCALE = 1.f / 4194304.f, DS_INV = 4194304.f;
+// the general kernels at head dims 65..128: |dP| <= hd * 2^30 doubles, so dS carries one more power of two (2^-23)
+template <int HDP> constexpr float ds_scale() { return HDP > 64 ? 0.5f * DS_SCALE : DS_SCALE; }
+template <int HDP> constexpr float ds_inv() { return HDP > 64 ? 2.f * DS_INV : DS_INV; }
 struct AttnScales { float iq, sq, ik, sk, iv, sv, ido, sdo; };    // {1/s, s} of q, k, v, dO (pack.h order)
 
 struct AttnArgs {
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
   if (F16) sc = *a.sc;
   const float qk_scale = F16 ? a.scale * sc.iq * sc.ik : a.scale;
   // fp16 x2: dp stays in plane units (dP * sdO * sV), delta is brought there, and dS' = P (dp - delta') * 2^-22
-  const float ds_unscale = (F16 ? DS_INV * sc.ido * sc.iv : 1.f) * a.drop_inv_keep;       // dS = dS' * this
+  const float ds_unscale = (F16 ? ds_inv<HDP>() * sc.ido * sc.iv : 1.f) * a.drop_inv_keep;       // dS = dS' * this
 
   QFrag<HDP, NP> qf, dof;
   load_qfrag<HDP, NP>(qf, a.qn, a.qn.p + (long)bh * a.qn.batch_stride, q0, lane);
@@ -926,7 +929,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
         const float p = (x == -INFINITY) ? 0.f : fast_exp(x - lse);
         const float dpr = (!DROP || ((keep_bits >> (mi * 4 + r)) & 1u)) ? dp[r] : 0.f;
         ds[r] = p * (dpr - dlt);
-        if (F16) ds[r] *= DS_SCALE;
+        if (F16) ds[r] *= ds_scale<HDP>();
       }
       if (dbias && qi < a.Tq) {
         if (jb + 4 <= a.Tk) {
@@ -1515,7 +1518,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
   AttnScales sc = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   if (F16) sc = *a.sc;
   const float qk_scale = F16 ? a.scale * sc.iq * sc.ik : a.scale;
-  const float ds_unscale = (F16 ? DS_INV * sc.ido * sc.iv : 1.f) * a.drop_inv_keep;
+  const float ds_unscale = (F16 ? ds_inv<HDP>() * sc.ido * sc.iv : 1.f) * a.drop_inv_keep;
 
   {
     TileStage<HDP, BKV, NP> st;
@@ -1657,7 +1660,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
         const float mf = (!DROP || ((keep_bits >> (nj * 4 + r)) & 1u)) ? 1.f : 0.f;
         ds[r] = p[r] * (dp[r] * mf - dl4[r]);
         p[r] *= mf;                                      // dV sees the dropped probabilities
-        if (F16) { ds[r] *= DS_SCALE; p[r] *= P_SCALE; }
+        if (F16) { ds[r] *= ds_scale<HDP>(); p[r] *= P_SCALE; }
       }
       bf16x4 pp[3], dd[3];
       split4s<NP, F16>(p, pp);
@@ -1832,7 +1835,8 @@ int dispatch(const AttnArgs& a, int precision, bool bwd, hipStream_t s) {
 int check_common(int B, int H, int Tq, int Tk, int hd, int mode, int precision, int window = 0) {
   if (B < 0 || H <= 0 || Tq < 0 || Tk < 0 || hd <= 0) return VILCO_ERR_BADARG;
   if (mode < 0 || mode > 4 || precision < 0 || precision > 3 || (mode == 4 && (window < 0 || Tq != Tk))) return VILCO_ERR_BADARG;
-  if (hd > 64 || (hd % 4) != 0) return VILCO_ERR_UNSUPPORTED;      // head dims 4..64 (P: 64, tests: 8, 16, 32)
+  if (hd > 128 || (hd % 4) != 0) return VILCO_ERR_UNSUPPORTED;      // head dims 4..128 (P: 64, cfg1: 128, tests: 8, 16, 32)
+  if (hd > 64 && precision == 2) return VILCO_ERR_UNSUPPORTED;      // three bf16 planes of a 128-wide tile exceed the 160 KB LDS (dkdv)
   return VILCO_OK;
 }
 
@@ -1960,7 +1964,7 @@ extern "C" int vilco_lab_attn_read(unsigned long long* out) {
 }
 #endif
 
-extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 64 && (hd % 4) == 0; }
+extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 128 && (hd % 4) == 0; }
 
 extern "C" int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_t hd, int32_t mode, int32_t precision,
                                          int32_t has_bias, float drop_p, int32_t key_side) {
@@ -1979,7 +1983,7 @@ extern "C" int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_
 }
 
 extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
-  const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
+  const int HDP = hd <= 32 ? 32 : (hd <= 64 ? 64 : 128), NP = np_of(precision);
   return (size_t)(planes_bytes(spec_nat(B, H, Tq, HDP), NP) + planes_bytes(spec_nat(B, H, Tk, HDP), NP) +
                   planes_bytes(spec_tr(B, H, Tk, hd), NP) + 1024 + ATT_SCALE_BYTES);
 }
@@ -1998,7 +2002,7 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   if (Tk == 0) return VILCO_ERR_BADARG;
   if (!workspace || workspace_bytes < vilco_attn_fwd_workspace(B, H, Tq, Tk, hd, precision)) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
+  const int HDP = hd <= 32 ? 32 : (hd <= 64 ? 64 : 128), NP = np_of(precision);
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.lse = lse; a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode; a.window = window;
@@ -2024,11 +2028,11 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   else
     a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
   flush_packs(pq, sw, precision == 3, NP, B * H, s);
-  return hd <= 32 ? dispatch<32>(a, precision, false, s) : dispatch<64>(a, precision, false, s);
+  return hd <= 32 ? dispatch<32>(a, precision, false, s) : (hd <= 64 ? dispatch<64>(a, precision, false, s) : dispatch<128>(a, precision, false, s));
 }
 
 extern "C" size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
-  const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
+  const int HDP = hd <= 32 ? 32 : (hd <= 64 ? 64 : 128), NP = np_of(precision);
   long bytes = 2 * planes_bytes(spec_nat(B, H, Tq, HDP), NP) + 2 * planes_bytes(spec_tr(B, H, Tq, hd), NP) +
                2 * planes_bytes(spec_nat(B, H, Tk, HDP), NP) + planes_bytes(spec_tr(B, H, Tk, hd), NP);
   bytes += up((long)B * H * (Tq > 0 ? Tq : 1) * 4, 256) + 1024 + ATT_SCALE_BYTES;
@@ -2050,7 +2054,7 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   if (Tk == 0) return VILCO_ERR_BADARG;
   if (!workspace || workspace_bytes < vilco_attn_bwd_workspace(B, H, Tq, Tk, hd, precision)) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int HDP = hd <= 32 ? 32 : 64, NP = np_of(precision);
+  const int HDP = hd <= 32 ? 32 : (hd <= 64 ? 64 : 128), NP = np_of(precision);
   unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
   float* delta = reinterpret_cast<float*>(wsb);
   wsb += up((long)B * H * Tq * 4, 256);
@@ -2086,5 +2090,5 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
   if (!nat_only) a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
   flush_packs(pq, sw, precision == 3, NP, B * H, s);
-  return hd <= 32 ? dispatch<32>(a, precision, true, s) : dispatch<64>(a, precision, true, s);
+  return hd <= 32 ? dispatch<32>(a, precision, true, s) : (hd <= 64 ? dispatch<64>(a, precision, true, s) : dispatch<128>(a, precision, true, s));
 }
