@@ -336,6 +336,15 @@ int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, co
                      const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks, int32_t chunk,
                      const float* lr, const float* wd, int32_t ngroups, float beta1, float beta2, float eps,
                      float momentum, const float* tensor_step, const float* norm_coef, void* stream);
+/* the same, and chunk_amax[c] (device float[nchunks], or null) = max|p| of the UPDATED parameter over chunk c: the   */
+/* chunks of one tensor are consecutive, so chunk_amax + first_chunk(t) with count chunks(t) is a vilco_pack_item.amax */
+/* for next step's pack of weight t -- the optimizer produces the scale of the fp16 x2 weight planes, the pack skips   */
+/* its own amax pass over the weight.                                                                                  */
+int vilco_optim_step_amax(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                          const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks, int32_t chunk,
+                          const float* lr, const float* wd, int32_t ngroups, float beta1, float beta2, float eps,
+                          float momentum, const float* tensor_step, const float* norm_coef, float* chunk_amax,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* q/k/v pre-projection of MaskedMHCA fused with the block's first LayerNorm (MQ/libs/modeling/blocks.py:561-563 */

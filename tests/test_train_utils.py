@@ -112,6 +112,49 @@ def test_fused_optimizer_duplicate_param_uses_clipped_grad(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["AdamW", "SGD"])
+def test_optimizer_leaves_weight_amax_for_the_packs(dev, kind):
+    """the update kernels emit max|p| per chunk (vilco_optim_step_amax); FusedOptimizer tags every matrix parameter with
+    its slice; the weight pack built from the tag is bit-identical to the pack that runs its own amax pass; a
+    parameter stepped twice carries the partials of its LAST update; any later write invalidates the tag"""
+    import warnings
+    from vilco_amd import ops
+    from vilco_amd.utils.train_utils import FusedOptimizer
+    torch.manual_seed(3)
+    shapes = [(1024, 512), (70,), (96, 40, 3), (3, 5)]
+    ps = [(torch.randn(s) * (10.0 ** i)).to(dev).requires_grad_(True) for i, s in enumerate(shapes)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt = FusedOptimizer([{"params": [ps[0], ps[1], ps[2], ps[2]], "weight_decay": 0.05},
+                              {"params": [ps[3]], "weight_decay": 0.0}], lr=1e-2, kind=kind)
+    for step in range(2):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        opt.step(clip_grad_l2norm=1.0)
+        for p in ps:
+            tag = getattr(p, "_vilco_wamax", None)
+            if p.dim() < 2:
+                assert tag is None
+                continue
+            parts, n = ops._weight_amax(p)
+            assert n == -(-p.numel() // 16384) and parts.numel() == n
+            assert float(parts.max()) == float(p.detach().abs().max()), (step, tuple(p.shape))
+        w = ps[0]
+        rows, cols = w.shape
+        tagged = ops.weight_planes(w, rows, cols)
+        plain = ops.pack(w.detach().clone(), rows, cols)
+        # buffer = [1024 amax partials | {1/s, s} | pad to 4608 B | planes]: same scale, same planes
+        assert torch.equal(tagged[4096:4104], plain[4096:4104]) and torch.equal(tagged[4608:], plain[4608:])
+    assert ops._weight_amax(ps[0][:512])[0] is None              # a slice of the parameter: the owner's maximum is not its own
+    ops.weights_changed()                                        # somebody wrote parameter memory behind our back
+    assert ops._weight_amax(ps[0])[0] is None
+    opt.step()
+    with torch.no_grad():
+        ps[0].mul_(2.0)                                          # an in-place edit moves the version counter
+    assert ops._weight_amax(ps[0])[0] is None
+
+
+@pytest.mark.gpu
 def test_train_step_runs_and_descends(dev):
     """three iterations of the glue on a golden-size model: loss decreases with a plain AdamW schedule"""
     from parity_util import golden_inputs, load_golden, build_hip_model, golden_cfg

@@ -26,6 +26,9 @@ rep = {
     "@LAUNCHES@": launches,
     "@CFG1@": "%.1f" % side["cfg1"]["clips_per_s"] if "cfg1" in side else "n/a",
     "@CFGW@": "%.1f" % side["W"]["clips_per_s"] if "W" in side else "n/a",
+    "@OPTMS@": "%.1f" % d["optimizer_step"]["ms"], "@OPTTB@": "%.1f" % (d["optimizer_step"]["hbm_GBps"] / 1e3),
+    "@ITMS@": "%.1f" % d["optimizer_step"].get("train_iteration_ms_measured", float("nan")),
+    "@ITCPS@": "%.1f" % d["optimizer_step"].get("train_iteration_clips_per_s", float("nan")),
 }
 tg = d.get("targets", {})
 q = tg.get("qkv_pre_projection", {}).get("measured", [])

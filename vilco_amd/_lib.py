@@ -118,6 +118,8 @@ SIGNATURES = {
     "vilco_grad_norm": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, f32, c_fp, c_fp, c_fp]),
     "vilco_optim_step": (C.c_int, [i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), i32,
                                    f32, f32, f32, f32, c_fp, c_fp, c_fp]),
+    "vilco_optim_step_amax": (C.c_int, [i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), i32,
+                                        f32, f32, f32, f32, c_fp, c_fp, c_fp, c_fp]),
     "vilco_qkv_pre_supported": (C.c_int, [i32]),
     "vilco_qkv_pre_amax_parts": (C.c_int, [i32, i32, i32]),
     "vilco_qkv_pre_fwd": (C.c_int, [c_fp, c_fp, c_fp, C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), c_fp, c_fp,

@@ -65,7 +65,18 @@ struct Hyper {
 };
 
 // torch.optim.AdamW (decoupled weight decay): p *= 1 - lr*wd ; m,v EMA ; p -= lr/bias1 * m / (sqrt(v)/sqrt(bias2) + eps)
-__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(MultiArgs a, Hyper h, const float* __restrict__ coef) {
+// chunk_amax (optional): max|p| of the UPDATED parameter over each chunk -- the optimizer is the producer of next step's
+// weights, so the fp16 x2 weight packs take their per-tensor scale from these partials instead of re-reading the weight
+__device__ __forceinline__ void emit_chunk_amax(float mx, float* __restrict__ chunk_amax) {
+  __shared__ float red[OPT_THREADS / 64];
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_amax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(MultiArgs a, Hyper h, const float* __restrict__ coef,
+                                                            float* __restrict__ chunk_amax) {
   const int t = a.chunk_tensor[blockIdx.x];
   const long off = a.chunk_off[blockIdx.x];
   float* p = reinterpret_cast<float*>(a.ptrs[t]) + off;
@@ -80,6 +91,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(MultiArgs a, Hyper h
   const float stp = h.tstep[t];
   const float step_size = lr / (1.f - powf(h.beta1, stp));      // bias corrections 1 - beta^step
   const float rs2 = sqrtf(1.f - powf(h.beta2, stp));
+  float mx = 0.f;
   for (long i = threadIdx.x; i < cnt; i += OPT_THREADS) {
     const float gr = g[i] * c;
     float pv = p[i] * (1.f - lr * wd);
@@ -89,11 +101,14 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(MultiArgs a, Hyper h
     v[i] = vv;
     pv -= step_size * (mv / (sqrtf(vv) / rs2 + h.eps));
     p[i] = pv;
+    mx = fmaxf(mx, fabsf(pv));
   }
+  if (chunk_amax) emit_chunk_amax(mx, chunk_amax);
 }
 
 // torch.optim.SGD with momentum (no dampening / nesterov): g += wd*p ; buf = first ? g : mom*buf + g ; p -= lr*buf
-__global__ __launch_bounds__(OPT_THREADS) void sgd_kernel(MultiArgs a, Hyper h, const float* __restrict__ coef) {
+__global__ __launch_bounds__(OPT_THREADS) void sgd_kernel(MultiArgs a, Hyper h, const float* __restrict__ coef,
+                                                          float* __restrict__ chunk_amax) {
   const int t = a.chunk_tensor[blockIdx.x];
   const long off = a.chunk_off[blockIdx.x];
   float* p = reinterpret_cast<float*>(a.ptrs[t]) + off;
@@ -105,12 +120,17 @@ __global__ __launch_bounds__(OPT_THREADS) void sgd_kernel(MultiArgs a, Hyper h, 
   const float lr = h.lr[gi], wd = h.wd[gi];
   const float c = coef ? coef[1] : 1.f;
   const bool first = h.tstep[t] <= 1.f;          // momentum buffer starts as the first gradient
+  float mx = 0.f;
   for (long i = threadIdx.x; i < cnt; i += OPT_THREADS) {
-    float gr = g[i] * c + wd * p[i];
+    const float pv0 = p[i];
+    float gr = g[i] * c + wd * pv0;
     const float b = first ? gr : h.momentum * m[i] + gr;
     m[i] = b;
-    p[i] -= lr * b;
+    const float pv = pv0 - lr * b;
+    p[i] = pv;
+    mx = fmaxf(mx, fabsf(pv));
   }
+  if (chunk_amax) emit_chunk_amax(mx, chunk_amax);
 }
 
 // EWC / MAS penalty (MQ/libs/cl_methods/EWC.py:6-22, MAS.py:5-21) over a chunk table of (parameter, importance,
@@ -212,11 +232,11 @@ extern "C" int vilco_grad_norm(const int64_t* ptrs, const int64_t* numel, const 
   return vilco_launch_status();
 }
 
-extern "C" int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
-                                const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks,
-                                int32_t chunk, const float* lr, const float* wd, int32_t ngroups, float beta1,
-                                float beta2, float eps, float momentum, const float* tensor_step,
-                                const float* norm_coef, void* stream) {
+extern "C" int vilco_optim_step_amax(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                                     const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks,
+                                     int32_t chunk, const float* lr, const float* wd, int32_t ngroups, float beta1,
+                                     float beta2, float eps, float momentum, const float* tensor_step,
+                                     const float* norm_coef, float* chunk_amax, void* stream) {
   if (!ptrs || !numel || !chunk_tensor || !chunk_off || !group || !lr || !wd || n < 0 || nchunks < 0 || chunk <= 0)
     return VILCO_ERR_BADARG;
   if (ngroups < 1 || ngroups > 8 || !tensor_step || (kind != 0 && kind != 1)) return VILCO_ERR_BADARG;
@@ -229,7 +249,16 @@ extern "C" int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t
   MultiArgs a{reinterpret_cast<const long*>(ptrs), reinterpret_cast<const long*>(numel), chunk_tensor,
               reinterpret_cast<const long*>(chunk_off), group, n, chunk};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (kind == 0) hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, s, a, h, norm_coef);
-  else hipLaunchKernelGGL(sgd_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, s, a, h, norm_coef);
+  if (kind == 0) hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, s, a, h, norm_coef, chunk_amax);
+  else hipLaunchKernelGGL(sgd_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, s, a, h, norm_coef, chunk_amax);
   return vilco_launch_status();
+}
+
+extern "C" int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                                const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks,
+                                int32_t chunk, const float* lr, const float* wd, int32_t ngroups, float beta1,
+                                float beta2, float eps, float momentum, const float* tensor_step,
+                                const float* norm_coef, void* stream) {
+  return vilco_optim_step_amax(kind, ptrs, numel, chunk_tensor, chunk_off, group, n, nchunks, chunk, lr, wd, ngroups, beta1,
+                               beta2, eps, momentum, tensor_step, norm_coef, nullptr, stream);
 }

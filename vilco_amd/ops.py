@@ -303,9 +303,31 @@ def _cached(w, tag, build):
     return val
 
 
+def tag_weight_amax(p, parts, n):
+    """max|p| partials of parameter p left by whoever wrote it (FusedOptimizer.step: vilco_optim_step_amax); valid until
+    p's version counter or the weight generation moves.  Call after weights_changed()."""
+    p._vilco_wamax = (parts, int(n), p._version, _weight_gen[0])
+
+
+def _weight_amax(w):
+    """(partials, count) for the pack of the stored weight w -- only when w is its whole owning parameter"""
+    owner = w._base if w._base is not None else w
+    tag = getattr(owner, "_vilco_wamax", None)
+    if (tag is None or not produce_amax or _precision != 3 or tag[2] != owner._version or tag[3] != _weight_gen[0]
+            or w.numel() != owner.numel()):
+        return None, 0
+    return tag[0], tag[1]
+
+
+def _weight_src(w, src):
+    """`src` (w.detach() or a permuted image of it: the same multiset of values) carrying w's amax tag"""
+    parts, n = _weight_amax(w)
+    return src if parts is None else _tag_amax(src, parts, n)
+
+
 def weight_planes(w, rows, cols):
     """operand planes of the stored matrix w [rows][cols] (a Linear / 1x1-conv weight, an XLNet projection)"""
-    return _cached(w, ("planes", rows, cols), lambda: pack(w.detach(), rows, cols))
+    return _cached(w, ("planes", rows, cols), lambda: pack(_weight_src(w, w.detach()), rows, cols))
 
 
 def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0)):
@@ -463,7 +485,7 @@ def permute3(src, dims, off, strides):
 
 def _conv3_weight(w, dims, off, strides, rows, cols):
     """(re-laid conv weight, its operand planes or None when the conv's GEMM packs for itself)"""
-    wp = permute3(w.detach(), dims, off, strides)
+    wp = _weight_src(w, permute3(w.detach(), dims, off, strides))
     planes = pack(wp, rows, cols) if _reuse_packs else None
     return wp, planes
 

@@ -19,6 +19,7 @@ from ..modeling.blocks import AffineDropPath, LayerNorm, MaskedConv1D, Scale
 from .lr_schedulers import LinearWarmupCosineAnnealingLR, LinearWarmupMultiStepLR
 
 CHUNK = 16384
+OPT_AMAX = os.environ.get("VILCO_OPT_AMAX", "1") != "0"      # the update kernels leave max|w| per chunk for the weight packs
 
 
 def fix_random_seed(seed, include_cuda=True):
@@ -91,13 +92,17 @@ class FusedOptimizer(optim.Optimizer):
 
     def _build_plan(self, items):
         numel = [p.numel() for p, _ in items]
-        ct, co = [], []
+        ct, co, first = [], [], []
         for i, n in enumerate(numel):
+            first.append(len(ct))
             for off in range(0, n, CHUNK):
                 ct.append(i)
                 co.append(off)
+        first.append(len(ct))
         dev = items[0][0].device
-        return dict(numel=torch.tensor(numel, dtype=torch.int64, device=dev),
+        amax = torch.empty(max(len(ct), 1), dtype=torch.float32, device=dev)
+        return dict(first=first, amax=amax, amax_views=[amax[first[i]:first[i + 1]] for i in range(len(numel))],
+                    numel=torch.tensor(numel, dtype=torch.int64, device=dev),
                     chunk_tensor=torch.tensor(ct, dtype=torch.int32, device=dev),
                     chunk_off=torch.tensor(co, dtype=torch.int64, device=dev),
                     group=torch.tensor([gi for _, gi in items], dtype=torch.int32, device=dev),
@@ -112,6 +117,7 @@ class FusedOptimizer(optim.Optimizer):
         lr = (C.c_float * ng)(*[float(g['lr']) for g in self.param_groups])
         wd = (C.c_float * ng)(*[float(g['weight_decay']) for g in self.param_groups])
         g0 = self.param_groups[0]
+        emitted = {}     # id(p) -> (p, partials view, count) of the LAST pass that wrote p
         coef = None      # clip coefficient of pass 0, reused by every pass: clip_grad_norm_ scales p.grad in place
                          # (train_utils.py:343-347), so a parameter listed twice is stepped twice with the CLIPPED gradient
         for k, items in enumerate(passes):
@@ -146,12 +152,20 @@ class FusedOptimizer(optim.Optimizer):
                 self.state[p]['step'] += 1          # torch.optim keeps the step per parameter
             tstep = torch.tensor([float(self.state[p]['step']) for p, _ in items], dtype=torch.float32).to(
                 items[0][0].device, non_blocking=True)
-            _lib.check(lib.vilco_optim_step(0 if self.kind == "AdamW" else 1, ptrs.data_ptr(), plan['numel'].data_ptr(),
-                                            plan['chunk_tensor'].data_ptr(), plan['chunk_off'].data_ptr(),
-                                            plan['group'].data_ptr(), n, plan['nchunks'], CHUNK, lr, wd, ng,
-                                            g0['betas'][0], g0['betas'][1], g0['eps'], g0['momentum'], tstep.data_ptr(),
-                                            None if coef is None or clip_grad_l2norm <= 0 else coef.data_ptr(), stream))
+            # the update also leaves max|p| of every chunk it wrote: the scale of next step's fp16 x2 weight planes
+            _lib.check(lib.vilco_optim_step_amax(0 if self.kind == "AdamW" else 1, ptrs.data_ptr(), plan['numel'].data_ptr(),
+                                                 plan['chunk_tensor'].data_ptr(), plan['chunk_off'].data_ptr(),
+                                                 plan['group'].data_ptr(), n, plan['nchunks'], CHUNK, lr, wd, ng,
+                                                 g0['betas'][0], g0['betas'][1], g0['eps'], g0['momentum'], tstep.data_ptr(),
+                                                 None if coef is None or clip_grad_l2norm <= 0 else coef.data_ptr(),
+                                                 plan['amax'].data_ptr() if OPT_AMAX else None, stream))
+            first = plan['first']
+            for i, (p, _) in enumerate(items):
+                if p.dim() >= 2 and OPT_AMAX:    # matrices: the tensors that get packed
+                    emitted[id(p)] = (p, plan['amax_views'][i], first[i + 1] - first[i])
         ops.weights_changed()          # parameter memory was written behind autograd's back: cached weight planes are stale
+        for p, parts, cnt in emitted.values():
+            ops.tag_weight_amax(p, parts, cnt)
         return None
 
 
