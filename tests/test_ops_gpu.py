@@ -66,6 +66,30 @@ def test_linear(dev, M, N, K, act):
     run_pair(hip, ref, dict(x=x, w=w, b=b), dev, TOL_GEMM)
 
 
+@pytest.mark.parametrize("span_log2,bar", [(12, 2e-5), (20, 3e-4), (26, 1e-3)])
+def test_gemm_rows_of_very_different_magnitude(dev, span_log2, bar):
+    """f16x2 has ONE power-of-two scale per tensor (pack.h f16_scale_from: max|x| -> [2^14, 2^15)): an element at
+    2^-s of the tensor maximum keeps its second fp16 part only while that part is a normal fp16 number.  Rows of A
+    spread over 2^span_log2 in magnitude: the PER-ROW relative error of A W^T stays at the 22-bit level up to a
+    spread of ~2^12, below 3e-4 up to 2^20 and below the 1e-3 parity bar up to 2^26 (beyond that: `split3`, whose
+    parts carry their own exponents)."""
+    from vilco_amd import ops
+    torch.manual_seed(5)
+    M, N, K = 512, 256, 1024
+    scale = torch.pow(2.0, -torch.linspace(0, span_log2, M))[:, None]
+    a, w = torch.randn(M, K) * scale, torch.randn(N, K) / math.sqrt(K)
+    got = ops.linear(a.to(dev), w.to(dev)).cpu().double()
+    want = a.double() @ w.double().t()
+    per_row = ((got - want).abs().amax(dim=1) / want.abs().amax(dim=1))
+    assert float(per_row.max()) < bar, (span_log2, float(per_row.max()), int(per_row.argmax()))
+    ops.set_precision("split3")                          # three bf16 parts, no shared scale: rows are independent
+    try:
+        got3 = ops.linear(a.to(dev), w.to(dev)).cpu().double()
+    finally:
+        ops.set_precision(None)
+    assert float(((got3 - want).abs().amax(dim=1) / want.abs().amax(dim=1)).max()) < 2e-5
+
+
 def test_linear_unaligned_k(dev):
     from vilco_amd import ops
     x, w = torch.randn(37, 50), torch.randn(30, 50)

@@ -394,8 +394,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
         }
       }
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = quad16_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
     const bool dead = m_new == -INFINITY;
     const float alpha = dead ? 1.f : fast_exp(m_run - m_new);
@@ -417,8 +416,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4*>(myP + q * 16 * BKV + off) = pp[q];
     }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    psum = quad16_sum(psum);
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
@@ -687,8 +685,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
       float mx = fmaxf(fmaxf(s[g][0][0], s[g][0][1]), fmaxf(s[g][0][2], s[g][0][3]));
 #pragma unroll
       for (int mi = 1; mi < 4; ++mi) mx = fmaxf(mx, fmaxf(fmaxf(s[g][mi][0], s[g][mi][1]), fmaxf(s[g][mi][2], s[g][mi][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = quad16_max(mx);
       const float m_new = fmaxf(m_run[g], mx);             // finite (prefix masks: every tile holds at least one valid key)
       const bool dead = XL && m_new == -INFINITY;          // XL: a row can have seen only masked keys so far
       const float alpha = dead ? 1.f : __builtin_amdgcn_exp2f(m_run[g] - m_new);
@@ -773,8 +770,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     float l = l_run[g];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = quad16_sum(l);
     const int qi = q0 + 16 * g + (lane & 15);
     if (qi < a.Tq) {
       const float inv = (l > 0.f ? 1.f / l : 0.f) * sc.iv * (XL ? a.drop_inv_keep : 1.f);
@@ -847,8 +843,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
         }
       }
   }
-  delta_i += __shfl_xor(delta_i, 16, 64);
-  delta_i += __shfl_xor(delta_i, 32, 64);
+  delta_i = quad16_sum(delta_i);
   if ((lane >> 4) == 0 && qi < a.Tq) a.delta[row_bh + qi] = delta_i;
   const float dlt = F16 ? ((delta_i * sc.sdo) * sc.sv) / a.drop_inv_keep : delta_i / a.drop_inv_keep;
 
@@ -1057,8 +1052,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
           delta_i += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
         }
     }
-    delta_i += __shfl_xor(delta_i, 16, 64);
-    delta_i += __shfl_xor(delta_i, 32, 64);
+    delta_i = quad16_sum(delta_i);
     if (g4 == 0 && qi < a.Tq) a.delta[row_bh + qi] = delta_i;
     dlt[g] = (delta_i * sc.sdo) * sc.sv;                   // plane units; never form sdO * sV (see attn_bwd_dq_kernel)
     if constexpr (XL) dlt[g] /= a.drop_inv_keep;           // dS = inv_keep P (M dP - (1-p) delta)

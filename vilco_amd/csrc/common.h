@@ -14,16 +14,56 @@ static inline bool vilco_aligned(const void* p, size_t a) {
   return (reinterpret_cast<uintptr_t>(p) % a) == 0;
 }
 
+// Wavefront reductions, result in every lane.  Inside a row of 16 lanes the partners come through DPP operand modifiers
+// (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror: one VALU instruction per step, no LDS); the four row totals are
+// read out with v_readlane and added as scalars operands.  11 instructions and no s_waitcnt, against 6 x (ds_bpermute +
+// wait + add) for the __shfl_xor butterfly -- the kernels whose waves reduce many small statistics (LayerNorm, the fused
+// q/k/v pre-projection, the amax partials) were issue- and LDS-latency-bound on those.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float vilco_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float vilco_lane(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// op(x, x from lane ^ 16) and op(x, x from lane ^ 32) for commutative ops, through gfx950's v_permlane{16,32}_swap
+// (VALU, no LDS round trip as with ds_bpermute): swapping the odd rows / upper half of one copy of x with the even rows /
+// lower half of another leaves the two partners of every lane in the two results.
+__device__ __forceinline__ void vilco_pair16(float x, float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void vilco_pair32(float x, float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+// reductions over the four lanes {l, l^16, l^32, l^48} (the MFMA accumulator layout spreads a row over them)
+__device__ __forceinline__ float quad16_sum(float x) {
+  float a, b;
+  vilco_pair16(x, a, b); x = a + b;
+  vilco_pair32(x, a, b); return a + b;
+}
+__device__ __forceinline__ float quad16_max(float x) {
+  float a, b;
+  vilco_pair16(x, a, b); x = fmaxf(a, b);
+  vilco_pair32(x, a, b); return fmaxf(a, b);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += vilco_dpp<0xB1>(v);          // quad_perm [1,0,3,2]
+  v += vilco_dpp<0x4E>(v);          // quad_perm [2,3,0,1]
+  v += vilco_dpp<0x141>(v);         // row_half_mirror: lanes i <-> 7 - i of every 8
+  v += vilco_dpp<0x140>(v);         // row_mirror:      lanes i <-> 15 - i of every 16
+  return (vilco_lane(v, 0) + vilco_lane(v, 16)) + (vilco_lane(v, 32) + vilco_lane(v, 48));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, vilco_dpp<0xB1>(v));
+  v = fmaxf(v, vilco_dpp<0x4E>(v));
+  v = fmaxf(v, vilco_dpp<0x141>(v));
+  v = fmaxf(v, vilco_dpp<0x140>(v));
+  return fmaxf(fmaxf(vilco_lane(v, 0), vilco_lane(v, 16)), fmaxf(vilco_lane(v, 32), vilco_lane(v, 48)));
 }
 
 // Dropout keep decision of element `idx` of the stream `seed`: counter-based (no state), so forward and backward -- and,

@@ -91,26 +91,44 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
   const int r0 = S * t0 - 1;
   const float* xb = a.x + (long)b * T * C + lane * 4;
 
+  // Rows outside [0, T) are the conv's zero padding.  Their loads are issued anyway, from the clamped row, and the
+  // result is discarded: a guarded load is a branch with its own s_waitcnt, which serialises the NR row loads of a chunk
+  // (measured: NR x NG dependent round trips per pass); unconditional loads are all in flight together, and the next
+  // chunk's rows are requested before this chunk is consumed.
+  bool ok[NR];
+  const float* xr[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int t = r0 + r;
+    ok[r] = t >= 0 && t < T;
+    xr[r] = xb + (long)(t < 0 ? 0 : (t >= T ? T - 1 : t)) * C;
+  }
+  auto load_x = [&](int g, float4 (&v)[NR]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = ldg4(xr[r] + g * 256);
+  };
+
   // ---- pass 0: statistics of the input rows
   float mu[NR], rs[NR];
   {
     float k[NR], s1[NR], s2[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      const int t = r0 + r;
-      k[r] = (t >= 0 && t < T) ? a.x[((long)b * T + t) * C] : 0.f;
+      k[r] = vilco_lane(*(xr[r]), 0);         // the row's first element (lane 0's first channel)
       s1[r] = 0.f; s2[r] = 0.f;
     }
+    float4 v[NR], vn[NR];
+    load_x(0, v);
     for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) load_x(g + 1, vn);
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        const int t = r0 + r;
-        if (t < 0 || t >= T) continue;
-        const float4 v = ldg4(xb + (long)t * C + g * 256);
-        const float d0 = v.x - k[r], d1 = v.y - k[r], d2 = v.z - k[r], d3 = v.w - k[r];
+        const float d0 = v[r].x - k[r], d1 = v[r].y - k[r], d2 = v[r].z - k[r], d3 = v[r].w - k[r];
         s1[r] += (d0 + d1) + (d2 + d3);
         s2[r] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
       }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) v[r] = vn[r];
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -122,17 +140,14 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
     }
   }
 
-  // h rows of chunk g (zero outside [0, T): the conv's padding)
-  auto load_h = [&](int g, float4 (&h)[NR]) {
+  // h rows of chunk g out of its x rows (zero outside [0, T): the conv's padding)
+  auto make_h = [&](int g, const float4 (&v)[NR], float4 (&h)[NR]) {
     const float4 g1 = a.g1 ? ldg4(a.g1 + g * 256 + lane * 4) : f4(1.f);
     const float4 b1 = a.b1 ? ldg4(a.b1 + g * 256 + lane * 4) : f4(0.f);
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      const int t = r0 + r;
-      if (t < 0 || t >= T) { h[r] = f4(0.f); continue; }
-      const float4 v = ldg4(xb + (long)t * C + g * 256);
-      h[r].x = (v.x - mu[r]) * rs[r] * g1.x + b1.x; h[r].y = (v.y - mu[r]) * rs[r] * g1.y + b1.y;
-      h[r].z = (v.z - mu[r]) * rs[r] * g1.z + b1.z; h[r].w = (v.w - mu[r]) * rs[r] * g1.w + b1.w;
+      h[r].x = ok[r] ? (v[r].x - mu[r]) * rs[r] * g1.x + b1.x : 0.f; h[r].y = ok[r] ? (v[r].y - mu[r]) * rs[r] * g1.y + b1.y : 0.f;
+      h[r].z = ok[r] ? (v[r].z - mu[r]) * rs[r] * g1.z + b1.z : 0.f; h[r].w = ok[r] ? (v[r].w - mu[r]) * rs[r] * g1.w + b1.w : 0.f;
     }
   };
   // conv j of chunk g for the TB tokens: w[c][3] of 4 consecutive channels = 12 floats
@@ -159,9 +174,14 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int i = 0; i < TB; ++i) { k[j][i] = 0.f; s1[j][i] = 0.f; s2[j][i] = 0.f; }
+    float4 xv[NR], xn[NR];
+    load_x(0, xv);
     for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) load_x(g + 1, xn);
       float4 h[NR];
-      load_h(g, h);
+      make_h(g, xv, h);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) xv[r] = xn[r];
       if (a.h) {
 #pragma unroll
         for (int r = 1; r <= S * TB; ++r) {
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
         conv(j, g, h, c);
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
-          if (g == 0) k[j][i] = __shfl(c[i].x, 0, 64);
+          if (g == 0) k[j][i] = vilco_lane(c[i].x, 0);
           const float d0 = c[i].x - k[j][i], d1 = c[i].y - k[j][i], d2 = c[i].z - k[j][i], d3 = c[i].w - k[j][i];
           s1[j][i] += (d0 + d1) + (d2 + d3);
           s2[j][i] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
@@ -196,9 +216,14 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
 
   // ---- pass 2: normalise and write
   float omax[3] = {0.f, 0.f, 0.f};
+  float4 xv[NR], xn[NR];
+  load_x(0, xv);
   for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) load_x(g + 1, xn);
     float4 h[NR];
-    load_h(g, h);
+    make_h(g, xv, h);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) xv[r] = xn[r];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       float4 c[TB];
@@ -224,6 +249,16 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
       if (lane == 0) a.amax[j][wid] = m;
     }
 }
+
+// Two other forward structures were built and measured at [8, 2304, 2304] (r02; this kernel: 230 us) and removed:
+//   * rows of a 4-token tile normalised once into LDS, one token per wave: 288 us -- x is read 1.5x instead of 6x, but
+//     every wave re-loads the 17 per-channel parameter quads per token and pass;
+//   * channel-split tiles (a wave owns 256 channels of 6 tokens, rows and parameters in registers, statistics combined
+//     across the waves through LDS): 295 us -- ~55 wavefront reductions and their bookkeeping per 72 outputs of a lane
+//     make it issue-bound (5600 instructions per wave).
+// What bounds THIS kernel is real HBM traffic: rocprofv3 FETCH_SIZE / WRITE_SIZE (profiles/r02_z_targets_pmc_*.json)
+// show x fetched 3.6x (the rows a wave re-reads in passes 1 and 2 have left the 4 MB L2 of its XCD: ~14 MB of rows are in
+// flight per XCD), i.e. 1.12 GB moved for 0.68 GB of algorithmic bytes, at 4.9 TB/s.
 
 // ---------------------------------------------------------------------------------------------------- backward, rows
 struct QkvBwdArgs {
