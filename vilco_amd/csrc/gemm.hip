@@ -478,22 +478,48 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   STAMPX(3);
 }
 
-// out = epilogue(alpha * sum_s part[s])
+// out = epilogue(alpha * sum_s part[s]).  VEC (16-byte aligned rows, N % 4 == 0: the layout the MFMA kernel's own
+// 16-byte partial stores require): a thread finishes four consecutive columns, and the partials of up to four splits
+// are requested before the first one is added -- a scalar loop over the splits is one memory round trip per split.
+// The sum keeps the split order either way (bitwise the same result).
+template <bool VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
-  const long per = (long)g.M * g.N;
+  constexpr int V = VEC ? 4 : 1;
+  const int NV = g.N / V;
+  const long per = (long)g.M * NV;
   const long total = per * nz;
   float am = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int z = (int)(i / per);
     const long mn = i % per;
-    const int m = (int)(mn / g.N), n = (int)(mn % g.N);
+    const int m = (int)(mn / NV), n = (int)(mn % NV) * V;
     const int zo = z / g.batch_inner, zi = z % g.batch_inner;
     const long idx = zo * g.sCo + zi * g.sCi + (long)m * g.ldc + n;
-    float s = 0.f;
-    for (int k = 0; k < g.ksplit; ++k) s += g.c[(long)k * g.split_stride + idx];
     bool valid = true;
     if (g.e.row_len) valid = (m % g.e.rowT) < g.e.row_len[m / g.e.rowT];
-    am = fmaxf(am, store_out(g, idx, n, s, valid));
+    if (VEC) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 4 <= g.ksplit; k += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(g.c + (long)(k + u) * g.split_stride + idx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u];
+      }
+      if (k + 2 <= g.ksplit) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(g.c + (long)k * g.split_stride + idx);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(g.c + (long)(k + 1) * g.split_stride + idx);
+        s += v0; s += v1;
+        k += 2;
+      }
+      if (k < g.ksplit) s += *reinterpret_cast<const f32x4*>(g.c + (long)k * g.split_stride + idx);
+      am = fmaxf(am, store_out4(g, idx, n, s, valid));
+    } else {
+      float s = 0.f;
+      for (int k = 0; k < g.ksplit; ++k) s += g.c[(long)k * g.split_stride + idx];
+      am = fmaxf(am, store_out(g, idx, n, s, valid));
+    }
   }
   if (g.amax_out) {
     __shared__ float red[4];
@@ -955,9 +981,10 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     prof().rec.push_back(ProfRec{{d->M, d->N, d->K, nz, p.BM, p.ksplit, d->precision, p.a_km, p.b_km, p.a_tap | (p.b_tap << 4)}});
   }
   if (p.ksplit > 1) {
-    long blocks = ((long)d->M * d->N * nz + 255) / 256;
+    long blocks = ((long)d->M * d->N * nz + 255) / 256;       // == amax_out_parts(): one max|C| partial per block, either form
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, g, nz);
+    if (g.vec_out) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((int)blocks), dim3(256), 0, s, g, nz);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((int)blocks), dim3(256), 0, s, g, nz);
   }
   return vilco_launch_status();
 }

@@ -9,7 +9,9 @@ namespace {
 constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / 64;
 
-template <int NV>
+// FULL: C == 256 * NV, every lane owns NV float4 of the row -- no `c < C` guards.  A guarded load is a branch with its own
+// s_waitcnt: the NV loads of a row become NV dependent round trips (seen in the ISA; same finding as qkvpre.hip).
+template <int NV, bool FULL>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long rows, int C,
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if (c < C) {
+    if (FULL || c < C) {
       g[i] = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
       b[i] = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
-      if (c < C) {
+      if (FULL || c < C) {
         v[i] = *reinterpret_cast<const float4*>(xr + c);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
       }
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
-      if (c < C) {
+      if (FULL || c < C) {
         v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
         q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
       }
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
-      if (c < C) {
+      if (FULL || c < C) {
         float4 o;
         o.x = v[i].x * rs * g[i].x + b[i].x;
         o.y = v[i].y * rs * g[i].y + b[i].y;
@@ -92,11 +94,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 
 // dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)),  g = dy (masked by y>0 if relu)
 // per-block partial dgamma/dbeta -> ws[block][2][C]
-template <int NV>
+template <int NV, bool FULL, bool RELU>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-    float* __restrict__ dx, float* __restrict__ ws, long rows, int C, int relu,
+    float* __restrict__ dx, float* __restrict__ ws, long rows, int C,
     float* __restrict__ dgamma, float* __restrict__ dbeta, unsigned* sync) {
   __shared__ float red[LN_WAVES][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    gm[i] = (c < C && gamma) ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    gm[i] = ((FULL || c < C) && gamma) ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
     dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
-      if (c < C) {
+      if (FULL || c < C) {
         g[i] = *reinterpret_cast<const float4*>(dy + row * C + c);
-        if (relu) {
+        if (RELU) {
           const float4 yy = *reinterpret_cast<const float4*>(y + row * C + c);
           if (!(yy.x > 0.f)) g[i].x = 0.f;
           if (!(yy.y > 0.f)) g[i].y = 0.f;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
-      if (c < C) {
+      if (FULL || c < C) {
         float4 o;
         o.x = rs * (g[i].x - s1 - xh[i].x * s2);
         o.y = rs * (g[i].y - s1 - xh[i].y * s2);
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
       __syncthreads();
       *reinterpret_cast<float4*>(&red[wave][lane * 4]) = v;
       __syncthreads();
-      if (wave == 0 && c < C) {
+      if (wave == 0 && (FULL || c < C)) {
         float4 a = *reinterpret_cast<const float4*>(&red[0][lane * 4]);
 #pragma unroll
         for (int w = 1; w < LN_WAVES; ++w) {
@@ -193,8 +195,17 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (j < ncols)
-    for (int r = slice; r < nrows; r += 4) s += ws[(long)r * ncols + j];
+  if (j < ncols) {
+    int r = slice;
+    for (; r + 28 < nrows; r += 32) {       // eight rows in flight; the sum keeps the row order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws[(long)(r + 4 * u) * ncols + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; r < nrows; r += 4) s += ws[(long)r * ncols + j];
+  }
   part[slice][lane] = s;
   __syncthreads();
   if (slice == 0 && j < ncols) {
@@ -220,18 +231,40 @@ void vilco_reduce_rows(const float* ws, float* out0, float* out1, int nrows, int
                      nrows, ncols, split);
 }
 
+#define LN_CASE(N_, KERNEL, ...)                                                                              \
+  if (C == (N_) * 256) hipLaunchKernelGGL((KERNEL<N_, true>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__);      \
+  else hipLaunchKernelGGL((KERNEL<N_, false>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__);                      \
+  break;
 #define LN_DISPATCH(NVV, KERNEL, ...)                                                   \
   switch (NVV) {                                                                        \
-    case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
-    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
-    case 3: hipLaunchKernelGGL((KERNEL<3>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
-    case 5: hipLaunchKernelGGL((KERNEL<5>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
-    case 6: hipLaunchKernelGGL((KERNEL<6>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
-    case 7: case 8: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break; \
-    case 9: hipLaunchKernelGGL((KERNEL<9>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break;   \
-    case 10: case 11: case 12: hipLaunchKernelGGL((KERNEL<12>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break; \
-    default: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__); break; \
+    case 1: LN_CASE(1, KERNEL, __VA_ARGS__)                                             \
+    case 2: LN_CASE(2, KERNEL, __VA_ARGS__)                                             \
+    case 3: LN_CASE(3, KERNEL, __VA_ARGS__)                                             \
+    case 4: LN_CASE(4, KERNEL, __VA_ARGS__)                                             \
+    case 5: LN_CASE(5, KERNEL, __VA_ARGS__)                                             \
+    case 6: LN_CASE(6, KERNEL, __VA_ARGS__)                                             \
+    case 7: case 8: LN_CASE(8, KERNEL, __VA_ARGS__)                                     \
+    case 9: LN_CASE(9, KERNEL, __VA_ARGS__)                                             \
+    case 10: case 11: case 12: LN_CASE(12, KERNEL, __VA_ARGS__)                         \
+    default: LN_CASE(16, KERNEL, __VA_ARGS__)                                           \
+  }
+
+#define LN_CASE_B(N_, KERNEL, R_, ...)                                                                        \
+  if (C == (N_) * 256) hipLaunchKernelGGL((KERNEL<N_, true, R_>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__);  \
+  else hipLaunchKernelGGL((KERNEL<N_, false, R_>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__);                  \
+  break;
+#define LN_DISPATCH_B(NVV, KERNEL, R_, ...)                                             \
+  switch (NVV) {                                                                        \
+    case 1: LN_CASE_B(1, KERNEL, R_, __VA_ARGS__)                                       \
+    case 2: LN_CASE_B(2, KERNEL, R_, __VA_ARGS__)                                       \
+    case 3: LN_CASE_B(3, KERNEL, R_, __VA_ARGS__)                                       \
+    case 4: LN_CASE_B(4, KERNEL, R_, __VA_ARGS__)                                       \
+    case 5: LN_CASE_B(5, KERNEL, R_, __VA_ARGS__)                                       \
+    case 6: LN_CASE_B(6, KERNEL, R_, __VA_ARGS__)                                       \
+    case 7: case 8: LN_CASE_B(8, KERNEL, R_, __VA_ARGS__)                               \
+    case 9: LN_CASE_B(9, KERNEL, R_, __VA_ARGS__)                                       \
+    case 10: case 11: case 12: LN_CASE_B(12, KERNEL, R_, __VA_ARGS__)                   \
+    default: LN_CASE_B(16, KERNEL, R_, __VA_ARGS__)                                     \
   }
 
 extern "C" int vilco_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
@@ -278,7 +311,8 @@ extern "C" int vilco_layernorm_bwd(const float* dy, const float* x, const float*
   dim3 grid(nb);
   float* ws = reinterpret_cast<float*>(workspace);
   unsigned* sync = (dgamma && dbeta) ? vilco_sync_counter(s, VILCO_SITE_LN) : nullptr;   // nb <= 256 blocks: co-resident
-  LN_DISPATCH(nv, ln_bwd_kernel, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, (int)relu, dgamma, dbeta, sync)
+  if (relu) { LN_DISPATCH_B(nv, ln_bwd_kernel, true, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync) }
+  else { LN_DISPATCH_B(nv, ln_bwd_kernel, false, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync) }
   if (dgamma && dbeta && !sync) vilco_reduce_rows(ws, dgamma, dbeta, nb, 2 * C, C, s);  // ws rows: [dgamma | dbeta]
   return vilco_launch_status();
 }

@@ -48,7 +48,12 @@ __device__ __forceinline__ void splitN(const float (&v)[8], bf16x8 (&part)[3], f
 __device__ __forceinline__ float f16_scale_from(const float* parts, int nparts, float* out, bool writer) {
   __shared__ float red_[4];
   float m = 0.f;
-  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, vilco_ld_agent(parts + i));   // may cross an in-launch barrier
+  for (int i = threadIdx.x; i < nparts; i += 1024) {      // four partials in flight (clamped index: a repeat changes no maximum)
+    const int last = nparts - 1;
+    const float p0 = vilco_ld_agent(parts + i), p1 = vilco_ld_agent(parts + (i + 256 < last ? i + 256 : last)),   // may cross an in-launch barrier
+                p2 = vilco_ld_agent(parts + (i + 512 < last ? i + 512 : last)), p3 = vilco_ld_agent(parts + (i + 768 < last ? i + 768 : last));
+    m = fmaxf(fmaxf(m, fmaxf(p0, p1)), fmaxf(p2, p3));
+  }
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red_[threadIdx.x >> 6] = m;
   __syncthreads();
@@ -97,12 +102,11 @@ __device__ __forceinline__ void pack_kc_body(const PackArgs& a, int z, int bx, i
   const int kmax = (a.tap == 1) ? a.tapC : a.K;         // valid source columns
   const int chunks = width >> 3;
   const long total = (long)a.out_rows * chunks;
-  const float fs = a.amax ? f16_scale_from(a.amax, a.namax, a.inv_scale, bx == 0 && z == 0 && threadIdx.x == 0) : 0.f;
-  for (long i = (long)bx * blockDim.x + threadIdx.x; i < total; i += (long)nbx * blockDim.x) {
+  // the 8 source values of item i (row orow, columns k0 .. k0+7 of the packed row)
+  auto load_item = [&](long i, float (&v)[8]) {
     const int c = (int)(i % chunks);
     const long orow = i / chunks;
     const int k0 = c * 8;
-    float v[8];
     long srow = orow;
     bool row_ok = orow < a.rows;
     if (a.tap == 1) {
@@ -140,11 +144,23 @@ __device__ __forceinline__ void pack_kc_body(const PackArgs& a, int z, int bx, i
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (row_ok && k0 + e < kmax) ? src[srow * a.ld + k0 + e] : 0.f;
     }
+  };
+  // The first item's source values are requested BEFORE the scale is folded out of the amax partials (a load, a block
+  // reduction and a barrier of its own): the two round trips overlap instead of following each other.
+  const long step = (long)nbx * blockDim.x;
+  long i = (long)bx * blockDim.x + threadIdx.x;
+  float v[8];
+  if (i < total) load_item(i, v);
+  const float fs = a.amax ? f16_scale_from(a.amax, a.namax, a.inv_scale, bx == 0 && z == 0 && threadIdx.x == 0) : 0.f;
+  while (i < total) {
     bf16x8 part[3];
     splitN<NP>(v, part, fs);
-    const long o = orow * (long)width + k0;
+    const long o = (i / chunks) * (long)width + (int)(i % chunks) * 8;
+    const long inext = i + step;
+    if (inext < total) load_item(inext, v);
 #pragma unroll
     for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(dst + q * a.plane_stride + o) = part[q];
+    i = inext;
   }
 }
 
@@ -243,16 +259,38 @@ __global__ __launch_bounds__(256) void amax_kernel(AmaxArgs args) {
   const int sub = threadIdx.x / o.tw, col = threadIdx.x & (o.tw - 1), rpi = 256 / o.tw;
   const bool vec = o.vec && (o.W & 3) == 0;
   const int wq = vec ? (o.W >> 2) : o.W;
-  for (int row = blockIdx.x * rpi + sub; row < total_rows; row += o.nblocks * rpi) {
+  auto row_ptr = [&](int row) {
     const int z = row / o.R, r = row - z * o.R;
-    const float* p = o.src + (long)(z / o.nbi) * o.so + (long)(z % o.nbi) * o.si + (long)r * o.ld;
-    if (vec) {
-      for (int c = col; c < wq; c += o.tw) {
-        const float4 v = *reinterpret_cast<const float4*>(p + c * 4);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    return o.src + (long)(z / o.nbi) * o.so + (long)(z % o.nbi) * o.si + (long)r * o.ld;
+  };
+  const int rstep = o.nblocks * rpi;
+  int row = blockIdx.x * rpi + sub;
+  if (vec && wq <= o.tw) {
+    // a row is one float4 per thread: four rows' loads in flight instead of one round trip per row (a clamped repeat of
+    // the last row changes no maximum)
+    if (col < wq)
+      for (; row < total_rows; row += 4 * rstep) {
+        const int lastrow = total_rows - 1;
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ru = row + u * rstep;
+          v[u] = *reinterpret_cast<const float4*>(row_ptr(ru < total_rows ? ru : lastrow) + col * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
       }
-    } else {
-      for (int c = col; c < wq; c += o.tw) m = fmaxf(m, fabsf(p[c]));
+  } else {
+    for (; row < total_rows; row += rstep) {
+      const float* p = row_ptr(row);
+      if (vec) {
+        for (int c = col; c < wq; c += o.tw) {
+          const float4 v = *reinterpret_cast<const float4*>(p + c * 4);
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+      } else {
+        for (int c = col; c < wq; c += o.tw) m = fmaxf(m, fabsf(p[c]));
+      }
     }
   }
   m = wave_max(m);
