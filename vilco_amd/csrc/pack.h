@@ -188,9 +188,11 @@ __device__ __forceinline__ void pack_tr_body(const PackArgs& a, int bz) {
   __bf16* dst = a.dst + (long)z * a.batch_stride;
   const int r0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
-  const float fs = a.amax ? f16_scale_from(a.amax, a.namax, a.inv_scale, (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) : 0.f;
+  // load 64 k-rows x 64 r, float4 along r: the four loads of a thread are issued together (full, aligned quads from a
+  // clamped row; only edge tiles take the guarded element-wise path)
+  float4 tv[4];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {        // load 64 k-rows x 64 r, float4 along r
+  for (int it = 0; it < 4; ++it) {
     const int id = tid + it * 256;
     const int kk = id >> 4, r4 = (id & 15) * 4;
     const int k = k0 + kk, r = r0 + r4;
@@ -202,18 +204,26 @@ __device__ __forceinline__ void pack_tr_body(const PackArgs& a, int bz) {
       ksrc = (long)k + j - 1;
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok && r < nrows) {
+    if (a.vec && r + 4 <= nrows) {
+      const float4 q = *reinterpret_cast<const float4*>(src + (ok ? ksrc : 0) * a.ld + r);
+      if (ok) v = q;
+    } else if (ok && r < nrows) {
       const float* p = src + ksrc * a.ld + r;
-      if (a.vec && r + 4 <= nrows) v = *reinterpret_cast<const float4*>(p);
-      else {
-        v.x = p[0];
-        if (r + 1 < nrows) v.y = p[1];
-        if (r + 2 < nrows) v.z = p[2];
-        if (r + 3 < nrows) v.w = p[3];
-      }
+      v.x = p[0];
+      if (r + 1 < nrows) v.y = p[1];
+      if (r + 2 < nrows) v.z = p[2];
+      if (r + 3 < nrows) v.w = p[3];
     }
-    tile[kk][r4] = v.x; tile[kk][r4 + 1] = v.y; tile[kk][r4 + 2] = v.z; tile[kk][r4 + 3] = v.w;
+    tv[it] = v;
   }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int id = tid + it * 256;
+    const int kk = id >> 4, r4 = (id & 15) * 4;
+    tile[kk][r4] = tv[it].x; tile[kk][r4 + 1] = tv[it].y; tile[kk][r4 + 2] = tv[it].z; tile[kk][r4 + 3] = tv[it].w;
+  }
+  // the scale is folded out of the amax partials while the tile loads are in flight
+  const float fs = a.amax ? f16_scale_from(a.amax, a.namax, a.inv_scale, (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) : 0.f;
   __syncthreads();
   const int r = tid & 63;                 // store: thread -> (row r, two 8-k chunks)
   if (r0 + r < nrows) {

@@ -361,27 +361,40 @@ __global__ __launch_bounds__(QT) void qkv_pre_bwd_params_kernel(QkvBwdArgs a, fl
   float acc[15];
 #pragma unroll
   for (int i = 0; i < 15; ++i) acc[i] = 0.f;
-  for (long r = r0; r < r1; ++r) {
+  // two rows per iteration, all 18 loads of the pair issued up front from clamped (always valid) addresses and masked
+  // afterwards: a `valid ? p[i] : 0.f` load is a branch with its own wait
+  struct RowIn { float hm, h0, hp, dy[3], dc[3]; bool valid, lo, hi; };
+  auto fetch = [&](long r, RowIn& x) {
     const int t = (int)(r % a.Tout), b = (int)(r / a.Tout);
-    const bool valid = s * t < a.len[b];
     const int tc = s * t;
+    x.valid = tc < a.len[b]; x.lo = tc > 0; x.hi = tc + 1 < T;
     const float* hb = a.h + (long)b * T * C + c;
-    const float hm = (valid && tc > 0) ? hb[(long)(tc - 1) * C] : 0.f;
-    const float h0 = valid ? hb[(long)tc * C] : 0.f;
-    const float hp = (valid && tc + 1 < T) ? hb[(long)(tc + 1) * C] : 0.f;
+    x.hm = hb[(long)(tc > 0 ? tc - 1 : 0) * C];
+    x.h0 = hb[(long)tc * C];
+    x.hp = hb[(long)(tc + 1 < T ? tc + 1 : T - 1) * C];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { x.dy[j] = a.dy[j][r * C + c]; x.dc[j] = a.dc[j][r * C + c]; }
+  };
+  auto use = [&](long r, const RowIn& x) {
+    const float hm = (x.valid && x.lo) ? x.hm : 0.f, h0 = x.valid ? x.h0 : 0.f, hp = (x.valid && x.hi) ? x.hp : 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const float cv = valid ? w[j][0] * hm + w[j][1] * h0 + w[j][2] * hp : 0.f;
+      const float cv = x.valid ? w[j][0] * hm + w[j][1] * h0 + w[j][2] * hp : 0.f;
       const float xh = (cv - a.mean[j][r]) * a.rstd[j][r];
-      const float dy = a.dy[j][r * C + c];
-      acc[2 * j] += dy * xh;
-      acc[2 * j + 1] += dy;
-      const float dc = a.dc[j][r * C + c];          // already zero on masked rows
-      acc[6 + 3 * j] += dc * hm;
-      acc[6 + 3 * j + 1] += dc * h0;
-      acc[6 + 3 * j + 2] += dc * hp;
+      acc[2 * j] += x.dy[j] * xh;
+      acc[2 * j + 1] += x.dy[j];
+      acc[6 + 3 * j] += x.dc[j] * hm;              // dc is already zero on masked rows
+      acc[6 + 3 * j + 1] += x.dc[j] * h0;
+      acc[6 + 3 * j + 2] += x.dc[j] * hp;
     }
+  };
+  long r = r0;
+  for (; r + 2 <= r1; r += 2) {
+    RowIn x0, x1;
+    fetch(r, x0); fetch(r + 1, x1);
+    use(r, x0); use(r + 1, x1);
   }
+  if (r < r1) { RowIn x0; fetch(r, x0); use(r, x0); }
   float* p = partial + (long)blockIdx.x * 15 * C + c;
 #pragma unroll
   for (int i = 0; i < 15; ++i) p[(long)i * C] = acc[i];
