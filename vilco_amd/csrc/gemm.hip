@@ -617,12 +617,19 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   const long tiles = p.BM == 256 ? tiles256 : (p.BM == 192 ? tiles192 : tiles128);
   const int nk = p.Kp / BK;
   int ks = 1;
+  // Split-K, re-measured in round 2 with tools/lab/ks_try*.sh (kernel + finish, operands packed): what matters is the
+  // number of rounds -- a grid of exactly <= 256 workgroups beats a slightly larger one by 15-20 % (1024 x 1024 x 4608:
+  // 4 splits = 256 workgroups 42.7 us, 5 splits = 320 workgroups 50.8 us), and a tile costs ~15-20 K-steps of prologue +
+  // epilogue on top of its K loop, so a 75 %-full single round is better left alone (4608 x 1024 x 4096, 192 tiles:
+  // unsplit 148 us, 3 splits 172 us) while a 56 %-full one still gains from splitting (2304 x 1024 x 4096: 97 -> 80 us).
   if (tiles < 256) {
-    if (tiles >= 128) {
+    if (tiles >= 176) {
+      ks = 1;
+    } else if (tiles >= 128) {
       ks = nk / 32;
       if (ks > 3) ks = 3;
     } else {
-      ks = (int)((288 + tiles - 1) / tiles);
+      ks = (int)(256 / tiles);
       if (ks > nk / 8) ks = nk / 8;
       if (ks > 16) ks = 16;
     }
