@@ -7,8 +7,8 @@ import vilco_amd.modeling as vm
 dev = torch.device("cuda:0")
 cfg = bench.p_config()
 torch.manual_seed(0)
-model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet())).to(dev).train()
-batch = bench.synth_batch(2, dev)
+model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.P_XLNET)).to(dev).train()
+batch = bench.synth_batch(2, dev, seed=0)
 def step():
     model.zero_grad(set_to_none=True)
     l = model(batch, is_training=True)
