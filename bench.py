@@ -293,7 +293,7 @@ def main():
 
     params = [p for p in model.parameters()] if not dry else None
 
-    def step():
+    def eager_step():
         if params is not None:
             for p in params:                      # == model.zero_grad(set_to_none=True) without the module-tree walk (1.5 ms)
                 p.grad = None
@@ -304,6 +304,21 @@ def main():
         fwd_bwd()
         if reducer is not None:
             reducer.finish()
+
+    # One rank per GPU, no gradient exchange: the step (forward + backward) is captured once as a hipGraph and replayed
+    # (vilco_amd/graph.py) -- ~1500 launches enqueued by the runtime instead of by ~25 ms of Python.  Same kernels, same
+    # arithmetic; dropout masks move with a device-side step word, stochastic-depth factors are re-drawn by every replay.
+    # With the RCCL gradient exchange (N > 1) the step stays eager: the all-reduce is launched from autograd hooks while
+    # backward is still running.  VILCO_BENCH_GRAPH=0 forces the eager step.
+    graphed = None
+    if not dry and not distributed and os.environ.get("VILCO_BENCH_GRAPH", "1") != "0":
+        from vilco_amd.graph import GraphedStep
+        graphed = GraphedStep(model, None, eager_steps=2)
+
+        def step():
+            graphed(batch)
+    else:
+        step = eager_step
 
     def fence():
         if distributed:
@@ -363,14 +378,16 @@ def main():
             step()                                               # a rank-local step: must not touch the process group
             out["dryrun"] = True
         else:
-            local_sections(out, args, model, step, dev, ms, world)
+            out["step_mode"] = ("hipGraph replay of the captured forward + backward (vilco_amd/graph.py): %d capture(s), %d replays"
+                                % (graphed.stats['captured'], graphed.stats['replayed'])) if graphed is not None else "eager launches"
+            local_sections(out, args, model, step, eager_step, dev, ms, world, batch)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def side_config(name, dev, steps=3, warm=2):
+def side_config(name, dev, steps=10, warm=2):
     """fwd+bwd clips/s of another BASELINE / SURVEY 8d configuration, a few steps only (side line, not the headline):
     "W" = config P with D = 2304 (hd = 144, no XLNet layer; 9874 GFLOP/clip), "cfg1" = BASELINE configs[0] (T = 256,
     Cin = 512, D = 512, H = 4, XLNet layer, 53.4 GFLOP/clip).  Head dims above 64 run the materialised-score attention."""
@@ -397,10 +414,19 @@ def side_config(name, dev, steps=3, warm=2):
     if T < 2304:      # the synthetic segments of synth_batch end at 130.25 < 256: fine
         pass
 
-    def one():
+    def eager_one():
         model.zero_grad(set_to_none=True)
         model(batch, is_training=True)['final_loss'].backward()
-    for _ in range(warm):
+    use_graph = os.environ.get("VILCO_BENCH_GRAPH", "1") != "0"
+    if use_graph:
+        from vilco_amd.graph import GraphedStep
+        gs = GraphedStep(model, None, eager_steps=1)
+
+        def one():
+            gs(batch)
+    else:
+        one = eager_one
+    for _ in range(warm + 2):
         one()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -408,15 +434,53 @@ def side_config(name, dev, steps=3, warm=2):
         one()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    host = host_enqueue_ms(one, 3)
+    eager_ms = None
+    if use_graph:
+        del gs
+        for _ in range(2):
+            eager_one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eager_one()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / steps * 1e3
     del model
     torch.cuda.empty_cache()
     return {"config": name, "clips_per_gpu": 2, "ms_per_step": dt * 1e3, "clips_per_s": 2 / dt, "gflop_per_clip_fwd_bwd": gflop,
             "model_mfma_frac": 2 / dt * gflop / 1e3 / PEAK_BF16_TFLOPS, "steps": steps,
+            "host_enqueue_ms": host, "eager_ms_per_step": eager_ms,
+            "step_mode": "hipGraph replay" if use_graph else "eager launches",
             "note": "dropout 0 (droppath 0.1), %d timed steps after %d warm-up: a side line, not the headline workload" % (steps, warm)}
 
 
-def local_sections(out, args, model, step, dev, ms, world):
-    """rank-0-only measurements after the timed region: GEMM roofline, optimizer step, larger batch, CPU baseline"""
+def host_enqueue_ms(fn, n=5):
+    """host time to ISSUE one step (queue drained before each measurement, nothing waited for after it)"""
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    return sorted(ts)[len(ts) // 2] * 1e3
+
+
+def local_sections(out, args, model, step, eager_step, dev, ms, world, batch):
+    """rank-0-only measurements after the timed region: host time, GEMM roofline, optimizer step, larger batch, CPU baseline"""
+    out["host_enqueue_ms"] = host_enqueue_ms(step)
+    if step is not eager_step:
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(8):
+            eager_step()
+        torch.cuda.synchronize()
+        out["eager"] = {"ms_per_step": (time.perf_counter() - t1) / 8 * 1e3, "host_enqueue_ms": host_enqueue_ms(eager_step),
+                        "note": "the same step launched kernel by kernel from Python (no graph)"}
+    step = eager_step           # everything below instruments or re-times individual launches: eager
     gp = gemm_profile(step)
     mfma_per_product = {"f16x2": 3, "split3": 6, "split": 3, "bf16": 1}[args.precision]
     out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp_kernel (all instantiations)", "achieved": gp["tflops"],
@@ -446,10 +510,18 @@ def local_sections(out, args, model, step, dev, ms, world):
     # a whole training iteration, measured (not summed): zero_grad + fwd + bwd + clip + AdamW with lr > 0, so every weight
     # changes and its operand planes are re-packed in the next forward (in the headline loop weights stand still and their
     # planes are packed once).  The update kernel leaves max|w| per chunk, the re-pack takes its scale from there.
-    def train_iter():
-        step()
-        opt.step(clip_grad_l2norm=1.0)
-    for _ in range(2):
+    use_graph = world == 1 and os.environ.get("VILCO_BENCH_GRAPH", "1") != "0"
+    if use_graph:           # captured: graph 1 = forward + backward (weight re-packs inside), graph 2 = clip + AdamW
+        from vilco_amd.graph import GraphedStep
+        gtrain = GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=1)
+
+        def train_iter():
+            gtrain(batch)
+    else:
+        def train_iter():
+            step()
+            opt.step(clip_grad_l2norm=1.0)
+    for _ in range(4):
         train_iter()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -457,21 +529,32 @@ def local_sections(out, args, model, step, dev, ms, world):
         train_iter()
     torch.cuda.synchronize()
     it_ms = (time.perf_counter() - t1) / 8 * 1e3
+    it_host = host_enqueue_ms(train_iter)
+    if use_graph:
+        del gtrain
     out["optimizer_step"] = {"ms": opt_ms, "params_with_grad": n_par, "kind": "fused clip_grad_norm + AdamW",
                              "hbm_GBps": (32.0 * n_par) / (opt_ms * 1e-3) / 1e9,
                              "train_step_ms_incl_optimizer": ms + opt_ms,
                              "train_iteration_ms_measured": it_ms,
                              "train_iteration_clips_per_s": args.batch * 1e3 / it_ms,
-                             "train_iteration": "zero_grad + fwd + bwd + clip_grad_norm + AdamW + weight re-pack, 8 iterations, wall clock"}
+                             "train_iteration_host_enqueue_ms": it_host,
+                             "train_iteration": "zero_grad + fwd + bwd + clip_grad_norm + AdamW + weight re-pack, 8 iterations, wall "
+                                                "clock" + (", replayed as two hipGraphs" if use_graph else ", eager launches")}
     if world == 1 and args.extra_batch and args.extra_batch != args.batch:
         # not the headline (the reference trains with 2 clips per GPU): shows what is launch-bound at batch 2
         del opt
         model.zero_grad(set_to_none=True)
         big = synth_batch(args.extra_batch, dev, seed=1)
 
-        def big_step():
-            model.zero_grad(set_to_none=True)
-            model(big, is_training=True)['final_loss'].backward()
+        if use_graph:
+            gbig = GraphedStep(model, None, eager_steps=1)
+
+            def big_step():
+                gbig(big)
+        else:
+            def big_step():
+                model.zero_grad(set_to_none=True)
+                model(big, is_training=True)['final_loss'].backward()
         for _ in range(3):
             big_step()
         torch.cuda.synchronize()
@@ -482,6 +565,8 @@ def local_sections(out, args, model, step, dev, ms, world):
         dtb = (time.perf_counter() - t1) / 5
         out["larger_batch"] = {"clips_per_gpu": args.extra_batch, "ms_per_step": dtb * 1e3,
                                "clips_per_s": args.extra_batch / dtb}
+        if use_graph:
+            del gbig
     if world == 1 and not args.no_targets and args.precision == "f16x2":
         # BASELINE.md 3.3 asks for a bf16 perf run beside the parity run: the SAME step with single-pass bf16 MFMA operands
         # (1 MFMA per product, 8-bit mantissas).  It does NOT meet the 1e-3 parity bar (median gradient

@@ -120,6 +120,9 @@ int vilco_gemm(const vilco_gemm_desc* d, void* stream);
 
 /* Timing of the MFMA kernel alone (not the packs, not the split-K reduce): between begin and end every vilco_gemm   */
 /* brackets its main kernel with HIP events on the caller's stream; end waits for them and returns the sum.          */
+/* Tuning override: force the tile height (128 | 192 | 256; 0 = cost model) and split-K count (0 = heuristic) of every
+ * following vilco_gemm in this process.  Initial values: environment VILCO_GEMM_BM / VILCO_GEMM_KS, read once. */
+int vilco_gemm_force(int32_t bm, int32_t ks);
 /* floats written to desc->amax_out by vilco_gemm(desc) (depends on the tile / split-K plan); 0: not available */
 int32_t vilco_gemm_amax_parts(const vilco_gemm_desc* desc);
 int vilco_gemm_profile_begin(void);
@@ -292,6 +295,16 @@ int vilco_scale_add_bwd(const float* dout, const float* bval, const float* colsc
 /* the backward pass is the same call on dy.  x = NULL writes the mask factors (0 or 1/(1-p)) -- what the parity tests  */
 /* hand to the oracle.  nn.Dropout in modeling_xlnet_x.py:308,327,486,488,1201,1228,1280 and blocks.py:226,268,349.      */
 int vilco_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream);
+/* Step word of the counter-based masks.  Every kernel that draws a dropout mask (vilco_dropout, vilco_act_bwd, the fused  */
+/* epilogue dropout of vilco_gemm, the attention-probability dropout of vilco_attn_*) uses seed + word * 0x9E3779B1, where  */
+/* `word` is ONE 32-bit value in device memory (0 after load: the effective seed is then the argument).  A training step    */
+/* captured as a hipGraph replays its kernel arguments; with vilco_seed_word_bump as the graph's first node every replay    */
+/* draws fresh masks, forward and backward of one replay the same ones.  (The reference draws from torch's Philox stream,  */
+/* MQ/libs/modeling/blocks.py:226,268; modeling_xlnet_x.py:308: a stateful generator has no place in a replayed graph.)    */
+/* _set / _bump are stream-ordered launches; _get synchronises the device (tests, logging).                                */
+int vilco_seed_word_set(uint32_t value, void* stream);
+int vilco_seed_word_bump(void* stream);
+int vilco_seed_word_get(uint32_t* out);
 /* out = alpha*a + beta*b (b may be null) */
 int vilco_axpby(float* out, const float* a, const float* b, float alpha, float beta, int64_t n,
                 void* stream);
@@ -345,6 +358,18 @@ int vilco_optim_step_amax(int32_t kind, const int64_t* ptrs, const int64_t* nume
                           const float* lr, const float* wd, int32_t ngroups, float beta1, float beta2, float eps,
                           float momentum, const float* tensor_step, const float* norm_coef, float* chunk_amax,
                           void* stream);
+/* the same with the learning rates read from DEVICE memory when lr_dev != null (float[ngroups]; `lr` is then ignored):  */
+/* a training iteration captured as a hipGraph replays its arguments, so the per-iteration schedule value               */
+/* (MQ/libs/utils/lr_schedulers.py:71-104, stepped at train_utils.py:351) and the per-tensor step counts `tensor_step`   */
+/* are memory the host (or a captured increment) rewrites between replays.                                              */
+int vilco_optim_step_dev(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                         const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks, int32_t chunk,
+                         const float* lr, const float* wd, int32_t ngroups, float beta1, float beta2, float eps,
+                         float momentum, const float* tensor_step, const float* norm_coef, float* chunk_amax,
+                         const float* lr_dev, void* stream);
+/* dst[0..n) = vals[0..n): n <= 16 HOST floats carried as kernel arguments (stream-ordered, no staging buffer) -- how the */
+/* host hands this iteration's learning rates to a captured optimizer step.                                              */
+int vilco_store_f32(float* dst, const float* vals, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* q/k/v pre-projection of MaskedMHCA fused with the block's first LayerNorm (MQ/libs/modeling/blocks.py:561-563 */

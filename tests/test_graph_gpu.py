@@ -1,0 +1,180 @@
+"""vilco_amd.graph.GraphedStep: a training iteration replayed as hipGraphs is the iteration the eager path runs.
+
+The reference has no counterpart (eager PyTorch, MQ/libs/utils/train_utils.py:322-357); what is pinned here is that the
+capture changes nothing: same losses, same gradients, same parameter updates as launching the kernels one by one, fresh
+dropout masks on every replay, and that graphs are dropped when parameters change behind them."""
+import copy
+import ctypes
+
+import pytest
+import torch
+
+from parity_util import (build_hip_model, cases, episode_full_state, golden_inputs, load_episode_golden, load_golden,
+                         rel_err)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def seed_word_zero():
+    """the dropout step word is process-wide device state: leave it at 0 for the other tests"""
+    from vilco_amd import _lib
+    yield
+    _lib.check(_lib.load().vilco_seed_word_set(0, None))
+    torch.cuda.synchronize()
+
+
+def _seed_word():
+    from vilco_amd import _lib
+    v = ctypes.c_uint32(0)
+    _lib.check(_lib.load().vilco_seed_word_get(ctypes.byref(v)))
+    return v.value
+
+
+def _episode_model(dev):
+    import vilco_amd.modeling as vm
+    from vilco_amd.core.config import make_config
+    from ref_import import xlnet_json
+    gold = load_episode_golden()
+    cfg = make_config(**gold['overrides'])
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg['model'], xlnet_config=xlnet_json(cfg['model']['embd_dim'], cases.EP_H)))
+    model.load_state_dict(episode_full_state(gold['init_state']), strict=True)
+    model = model.to(dev)
+    model.loss_normalizer = cfg['model']['train_cfg']['init_loss_norm']
+    return cfg, model
+
+
+def test_graphed_training_equals_eager_training(dev, seed_word_zero):
+    """BASELINE configs[2]'s model (time adapters listed twice in the optimizer, L2P prompts, XLNet layer): two epochs of
+    task 0 through train_one_epoch, eager vs GraphedStep (first iteration eager, the other seven replayed).  No dropout in
+    this configuration, so the two runs must agree to rounding-order noise of nothing: bit for bit."""
+    from vilco_amd.graph import GraphedStep
+    from vilco_amd.utils.train_utils import make_optimizer, make_scheduler, train_one_epoch
+    runs = []
+    for use_graph in (False, True):
+        cfg, model = _episode_model(dev)
+        opt = make_optimizer(model, cfg['opt'])
+        sch = make_scheduler(opt, cfg['opt'], len(cases.episode_batches(0)))
+        graph = GraphedStep(model, opt, clip_grad_l2norm=cfg['train_cfg']['clip_grad_l2norm'], eager_steps=1) if use_graph else None
+        losses = []
+        for epoch in range(2):
+            model.pre_train_epoch(task_id=0, current_epoch=epoch)
+            hist = train_one_epoch(cases.episode_batches(0), model, opt, sch, epoch, 1,
+                                   clip_grad_l2norm=cfg['train_cfg']['clip_grad_l2norm'], cl_name=cfg['cl_cfg']['name'],
+                                   reg_lambda=cfg['cl_cfg']['reg_lambda'], prev_out_cls_logits_dict={}, current_task_id=0,
+                                   graph=graph)
+            losses += [{k: float(v) for k, v in h.items()} for h in hist]
+        if use_graph:
+            assert graph.stats['captured'] == 1 and graph.stats['replayed'] == 7 and graph.stats['eager'] == 1, graph.stats
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        steps = sorted({float(s['step']) for s in opt.state_dict()['state'].values()})
+        runs.append((losses, sd, steps, model.loss_normalizer))
+    (la, sa, sta, na), (lb, sb, stb, nb) = runs
+    assert sta == stb and sta[0] >= 8.0, (sta, stb)          # per-parameter step counts (16 for the twice-listed adapters)
+    assert na == nb
+    for i, (a, b) in enumerate(zip(la, lb)):
+        for k in a:
+            assert a[k] == b[k], (i, k, a[k], b[k])
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+def test_replays_draw_fresh_dropout_masks_and_match_eager(dev, seed_word_zero):
+    """train-mode step with dropout 0.1 (MLP / projection dropouts and XLNet's seven sites): replay n of the captured step
+    equals the eager step run with the dropout step word set to n and the same launch seeds -- and differs from replay
+    n - 1 (a replayed graph must not repeat its masks)."""
+    from vilco_amd import _lib, ops
+    from vilco_amd.graph import GraphedStep
+    gold = load_golden("xl")
+    lib = _lib.load()
+
+    def make():
+        m = build_hip_model(gold, dev).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.1
+            if hasattr(mod, "drop_prob"):
+                mod.drop_prob = 0.0            # stochastic depth draws from torch's generator: not what is compared here
+        m.loss_normalizer = 100.0
+        return m
+    batch = golden_inputs(gold)
+    ma, mb = make(), make()
+    gs = GraphedStep(ma, None, eager_steps=1)
+    seeds0 = 12345
+
+    def eager(word):
+        _lib.check(lib.vilco_seed_word_set(word, None))
+        ops._drop_counter[0] = seeds0
+        for p in mb.parameters():
+            p.grad = None
+        out = mb(batch, task_id=gold['task_id'], is_training=True)
+        out['final_loss'].backward()
+        return float(out['final_loss']), {n: p.grad.clone() for n, p in mb.named_parameters() if p.grad is not None}
+
+    _lib.check(lib.vilco_seed_word_set(0, None))
+    got = []
+    for it in range(4):                 # call 0 eager (word 0), call 1 = capture + replay (word -> 1), ...
+        ops._drop_counter[0] = seeds0
+        l = gs(batch, task_id=gold['task_id'])
+        torch.cuda.synchronize()
+        got.append((float(l['final_loss']), {n: p.grad.clone() for n, p in ma.named_parameters() if p.grad is not None},
+                    _seed_word()))
+    assert [g[2] for g in got] == [0, 1, 2, 3] and gs.stats['replayed'] == 3, ([g[2] for g in got], gs.stats)
+    assert len({g[0] for g in got}) == 4, "replays repeated a dropout mask: %s" % [g[0] for g in got]
+    for word, (loss, grads, _) in enumerate(got):
+        want_loss, want = eager(word)
+        assert loss == want_loss, (word, loss, want_loss)
+        assert set(grads) == set(want)
+        for n in want:      # (the gaussian-weight gradients are float atomics in loss_bwd: equal up to summation order)
+            assert torch.equal(grads[n], want[n]) or rel_err(grads[n], want[n], 1e-7) < 1e-5, (word, n)
+
+
+def test_graphs_are_dropped_when_parameters_change_behind_them(dev, seed_word_zero):
+    """fwd+bwd-only graphs read operand planes packed before the capture: writing the parameters (load_state_dict, an
+    eager optimizer step) must invalidate them -- the next call re-captures and sees the new weights"""
+    from vilco_amd.graph import GraphedStep
+    from vilco_amd.utils.train_utils import make_optimizer
+    gold = load_golden("noxl")
+    model = build_hip_model(gold, dev).train()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    model.loss_normalizer = 100.0
+    batch = golden_inputs(gold)
+    gs = GraphedStep(model, None, eager_steps=1)
+
+    def step():
+        return float(gs(batch, task_id=gold['task_id'])['final_loss'])
+    ref = copy.deepcopy(model)      # runs the same sequence of steps eagerly (the loss-normaliser EMA advances alike)
+
+    def ref_step():
+        for p in ref.parameters():
+            p.grad = None
+        out = ref(batch, task_id=gold['task_id'], is_training=True)
+        out['final_loss'].backward()
+        return float(out['final_loss'])
+    step()
+    step()
+    assert gs.stats['captured'] == 1
+    opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-2))
+    opt.step(clip_grad_l2norm=1.0)             # eager update: weights written through raw pointers
+    ropt = make_optimizer(ref, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-2))
+    ref_step()
+    ref_step()
+    ropt.step(clip_grad_l2norm=1.0)
+    dropped = gs.stats['dropped']
+    step()                                     # must notice, fall back to eager, then re-capture
+    step()
+    assert gs.stats['dropped'] == dropped + 1 and gs.stats['captured'] == 2, gs.stats
+    ref_step()
+    ref_step()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad) or rel_err(p.grad, q.grad, 1e-7) < 1e-5, n
+    sd = {k: v + 0.01 for k, v in model.state_dict().items() if v.is_floating_point()}
+    model.load_state_dict(sd, strict=False)
+    dropped = gs.stats['dropped']
+    step()
+    assert gs.stats['dropped'] == dropped + 1, gs.stats

@@ -1,8 +1,8 @@
-"""Times the main P-config GEMM shapes under forced (BM, split-K) choices (env overrides read per call)."""
+"""Times the main P-config GEMM shapes under forced (BM, split-K) choices (vilco_gemm_force)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch
-from vilco_amd import ops
+from vilco_amd import ops, _lib
 
 def timeit(fn, n=8, warm=2):
     for _ in range(warm): fn()
@@ -31,12 +31,10 @@ for form, M, N, K in shapes:
     res = []
     for bm in (128, 256):
         for ks in (0, 1, 2, 3, 4, 6, 8):
-            os.environ["VILCO_GEMM_BM"] = str(bm)
-            if ks: os.environ["VILCO_GEMM_KS"] = str(ks)
-            else: os.environ.pop("VILCO_GEMM_KS", None)
+            _lib.check(_lib.load().vilco_gemm_force(bm, ks))
             t = timeit(lambda: ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N))
             res.append((t, bm, ks))
-    os.environ.pop("VILCO_GEMM_BM", None); os.environ.pop("VILCO_GEMM_KS", None)
+    _lib.check(_lib.load().vilco_gemm_force(0, 0))
     t0 = timeit(lambda: ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N))
     res.sort()
     fl = 2.0 * M * N * K

@@ -69,6 +69,7 @@ SIGNATURES = {
     "vilco_gemm_workspace": (sz, [C.POINTER(GemmDesc)]),
     "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "vilco_gemm_amax_parts": (i32, [C.POINTER(GemmDesc)]),
+    "vilco_gemm_force": (C.c_int, [i32, i32]),
     "vilco_gemm_profile_begin": (C.c_int, []),
     "vilco_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "vilco_gemm_profile_records": (C.c_int64, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int64]),
@@ -106,6 +107,9 @@ SIGNATURES = {
     "vilco_scale_add_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, i32,
                                       c_fp, sz, c_fp]),
     "vilco_dropout": (C.c_int, [c_fp, c_fp, i64, f32, C.c_uint32, C.c_uint64, c_fp]),
+    "vilco_seed_word_set": (C.c_int, [C.c_uint32, c_fp]),
+    "vilco_seed_word_bump": (C.c_int, [c_fp]),
+    "vilco_seed_word_get": (C.c_int, [C.POINTER(C.c_uint32)]),
     "vilco_axpby": (C.c_int, [c_fp, c_fp, c_fp, f32, f32, i64, c_fp]),
     "vilco_act_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp]),
     "vilco_act_bwd_amax": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp,
@@ -120,6 +124,9 @@ SIGNATURES = {
                                    f32, f32, f32, f32, c_fp, c_fp, c_fp]),
     "vilco_optim_step_amax": (C.c_int, [i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), i32,
                                         f32, f32, f32, f32, c_fp, c_fp, c_fp, c_fp]),
+    "vilco_optim_step_dev": (C.c_int, [i32, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), i32,
+                                       f32, f32, f32, f32, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "vilco_store_f32": (C.c_int, [c_fp, C.POINTER(f32), i32, c_fp]),
     "vilco_qkv_pre_supported": (C.c_int, [i32]),
     "vilco_qkv_pre_amax_parts": (C.c_int, [i32, i32, i32]),
     "vilco_qkv_pre_fwd": (C.c_int, [c_fp, c_fp, c_fp, C.POINTER(c_fp), C.POINTER(c_fp), C.POINTER(c_fp), c_fp, c_fp,

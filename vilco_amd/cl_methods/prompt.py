@@ -30,7 +30,7 @@ class Prompt(nn.Module):
     @staticmethod
     def l2_normalize(x, dim=None, epsilon=1e-12):
         sq = torch.sum(x ** 2, dim=dim, keepdim=True)
-        return x * torch.rsqrt(torch.maximum(sq, torch.tensor(epsilon, device=x.device)))
+        return x * torch.rsqrt(torch.clamp_min(sq, epsilon))       # == maximum(sq, eps): no host scalar to upload
 
     def forward(self, x_embed, prompt_mask=None, cls_features=None):
         if self.embedding_key == 'mean':

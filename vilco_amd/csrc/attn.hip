@@ -206,6 +206,7 @@ struct AttnArgs {
   // dropout on the attention probabilities (modeling_xlnet_x.py:308, blocks.py:226): keep iff hash(seed, (bh*Tq+i)*Tk+j) >= thresh
   uint32_t drop_thresh, drop_seed;
   float drop_inv_keep;
+  const uint32_t* seed_word;   // device step word mixed into drop_seed (common.h: vilco_step_seed)
   // optional max|x| partials of the outputs (one per workgroup), left for the operand pack of the next product
   // (vilco_pack_item.amax); written by the hd = 64 fast kernels only (vilco_attn_amax_parts)
   float* am_o; float* am_dq; float* am_dk; float* am_dv; float* am_ds;
@@ -283,6 +284,7 @@ __device__ __forceinline__ float mask_score(float s, int i, int j, int len, int 
 // ------------------------------------------------------------------------------------------ forward
 template <int HDP, int NP, bool F16, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(AttnArgs a) {
+  if (a.drop_thresh) a.drop_seed = vilco_step_seed(a.drop_seed, a.seed_word);
   constexpr int BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);          // [NP][64 keys][HDP]
@@ -525,6 +527,7 @@ __device__ unsigned long long vilco_lab_attn_stamps[64 * 8];
 // mask -- keys >= kv_len masked except the diagonal --, dropout on the probabilities): same kernel, three more steps
 template <bool XL>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) {
+  if (a.drop_thresh) a.drop_seed = vilco_step_seed(a.drop_seed, a.seed_word);
   constexpr int HDP = 64, BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);          // [2 parts][64 keys][RS64]
@@ -790,6 +793,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dBias)
 template <int HDP, int NP, bool F16, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
+  if (a.drop_thresh) a.drop_seed = vilco_step_seed(a.drop_seed, a.seed_word);
   constexpr int BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);          // [NP][64 keys][HDP]
@@ -987,6 +991,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 // mask, probability dropout) plus the dS store the position-term gradients are derived from (a.dbias, [B,H,Tq,Tk])
 template <bool XL>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs a) {
+  if (a.drop_thresh) a.drop_seed = vilco_step_seed(a.drop_seed, a.seed_word);
   constexpr int HDP = 64, BKV = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);          // [2 parts][64 keys][RS64]
@@ -1251,6 +1256,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
 // [64 q][68] LDS image that all four waves read (lane = key, 16 queries per lane and tile: scalar LDS reads).
 template <bool XL>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArgs a) {
+  if (a.drop_thresh) a.drop_seed = vilco_step_seed(a.drop_seed, a.seed_word);
   constexpr int HDP = 64, BQ = 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sQ = reinterpret_cast<__bf16*>(smem_raw);          // [2 parts][64 q][RS64]
@@ -1482,6 +1488,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
 // gives each lane one key (col) and 4 consecutive queries (rows), so P^T / dS^T go to LDS as packed stores.
 template <int HDP, int NP, bool F16, bool HASB, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) {
+  if (a.drop_thresh) a.drop_seed = vilco_step_seed(a.drop_seed, a.seed_word);
   constexpr int BKV = 64, BQ = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);          // [NP][64 keys][HDP]
@@ -2000,7 +2007,7 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.lse = lse; a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode; a.window = window;
-  a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
+  a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p); a.seed_word = vilco_seed_word_dev();
   if (o_amax && !fast64(a, precision)) return VILCO_ERR_UNSUPPORTED;      // see vilco_attn_amax_parts
   a.am_o = o_amax;
   unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
@@ -2055,7 +2062,7 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.lse = const_cast<float*>(lse); a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode; a.window = window;
-  a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p);
+  a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p); a.seed_word = vilco_seed_word_dev();
   a.dout = dout; a.delta = delta; a.o_in = o; a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias;
   if ((dq_amax || dk_amax || dv_amax) && !fast64(a, precision)) return VILCO_ERR_UNSUPPORTED;      // see vilco_attn_amax_parts
   a.am_dq = dq_amax; a.am_dk = dk_amax; a.am_dv = dv_amax;

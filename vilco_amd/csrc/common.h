@@ -75,6 +75,15 @@ __device__ __forceinline__ uint32_t vilco_drop_hash(uint32_t seed, uint64_t idx)
   h += seed; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
   return h;
 }
+// The seed a kernel actually uses: the launch's seed plus the device-resident step word (sync.hip).  A step captured as a
+// hipGraph replays its kernel arguments, so what must change from replay to replay lives in memory: the graph's first node
+// bumps the word (vilco_seed_word_bump) and every mask of the replay moves with it.  Eager launches run with word 0,
+// where the effective seed IS the launch's seed.
+__device__ __forceinline__ uint32_t vilco_step_seed(uint32_t seed, const uint32_t* word) {
+  return seed + __builtin_nontemporal_load(word) * 0x9E3779B1u;
+}
+const uint32_t* vilco_seed_word_dev();     // sync.hip: device address of the step word
+
 static inline uint32_t vilco_drop_threshold_host(float p) {     // host side: the kernels receive the threshold
   if (p <= 0.f) return 0u;
   const double t = (double)p * 4294967296.0;

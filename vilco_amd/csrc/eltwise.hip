@@ -180,7 +180,8 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ dz,
     float* __restrict__ ws, int act, const int* __restrict__ len, int T, long rows, int C,
     int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, float drop_inv_keep, float* __restrict__ dbias,
-    unsigned* sync, float* __restrict__ amax_parts) {
+    unsigned* sync, float* __restrict__ amax_parts, const uint32_t* __restrict__ seed_word) {
+  if (drop_thresh) drop_seed = vilco_step_seed(drop_seed, seed_word);
   __shared__ float amax_red[EW_THREADS / 64];
   float amax = 0.f;          // max |dz| of this block: dz goes straight into an operand pack
   const long r0 = (long)blockIdx.x * rows_per_block;
@@ -412,7 +413,9 @@ extern "C" int vilco_scale_add_bwd(const float* dout, const float* bval, const f
 
 // y = keep ? x / (1-p) : 0   (x null: the mask factors themselves, for tests);  in place allowed
 __global__ __launch_bounds__(EW_THREADS) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
-                                                             uint32_t thresh, float inv_keep, uint32_t seed, uint64_t offset) {
+                                                             uint32_t thresh, float inv_keep, uint32_t seed, uint64_t offset,
+                                                             const uint32_t* __restrict__ seed_word) {
+  seed = vilco_step_seed(seed, seed_word);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const bool keep = vilco_drop_hash(seed, offset + (uint64_t)i) >= thresh;
     y[i] = keep ? (x ? x[i] : 1.f) * inv_keep : 0.f;
@@ -423,7 +426,7 @@ extern "C" int vilco_dropout(const float* x, float* y, int64_t n, float p, uint3
   if (!y || n < 0 || !(p >= 0.f) || p >= 1.f) return VILCO_ERR_BADARG;
   if (n == 0) return VILCO_OK;
   hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x, y,
-                     (long)n, vilco_drop_threshold_host(p), 1.f / (1.f - p), seed, offset);
+                     (long)n, vilco_drop_threshold_host(p), 1.f / (1.f - p), seed, offset, vilco_seed_word_dev());
   return vilco_launch_status();
 }
 
@@ -463,7 +466,7 @@ extern "C" int vilco_act_bwd_amax(const float* dy, const float* aux, float* dz, 
   if (emit) *n_parts = nb * ((C + EW_THREADS - 1) / EW_THREADS);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
                      (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,
-                     emit ? amax_parts : nullptr);
+                     emit ? amax_parts : nullptr, vilco_seed_word_dev());
   if (dbias && !sync) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }

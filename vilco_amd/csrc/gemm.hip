@@ -75,6 +75,7 @@ struct GArgs {
   int band, bandT;          // XLNet relative-position band (vilco_gemm_desc.band)
   uint32_t drop_thresh, drop_seed;   // fused output dropout (vilco_gemm_desc.drop_p): keep iff hash(seed, m*N+n) >= thresh
   float drop_inv_keep;
+  const uint32_t* seed_word;   // device step word mixed into drop_seed (common.h: vilco_step_seed)
   float* amax_out;          // optional: max|stored value| per workgroup (vilco_gemm_desc.amax_out)
   Epi e;
 };
@@ -93,7 +94,7 @@ __device__ __forceinline__ float store_out(const GArgs& g, long idx, int n, floa
   else if (e.act == VILCO_ACT_GELU) v = gelu_f(v);
   if (!valid) v = 0.f;
   if (e.colscale) v *= e.colscale[n];
-  if (g.drop_thresh) v = vilco_drop_hash(g.drop_seed, (uint64_t)idx) >= g.drop_thresh ? v * g.drop_inv_keep : 0.f;
+  if (g.drop_thresh) v = vilco_drop_hash(vilco_step_seed(g.drop_seed, g.seed_word), (uint64_t)idx) >= g.drop_thresh ? v * g.drop_inv_keep : 0.f;
   if (e.residual && (valid || !e.res_masked)) v += e.residual[idx];
   if (e.beta != 0.f) v += e.beta * g.cfinal[idx];
   g.cfinal[idx] = v;
@@ -116,9 +117,10 @@ __device__ __forceinline__ float store_out4(const GArgs& g, long idx, int n, con
   if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
   if (e.colscale) v *= *reinterpret_cast<const f32x4*>(e.colscale + n);
   if (g.drop_thresh) {
+    const uint32_t seed = vilco_step_seed(g.drop_seed, g.seed_word);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      v[k] = vilco_drop_hash(g.drop_seed, (uint64_t)(idx + k)) >= g.drop_thresh ? v[k] * g.drop_inv_keep : 0.f;
+      v[k] = vilco_drop_hash(seed, (uint64_t)(idx + k)) >= g.drop_thresh ? v[k] * g.drop_inv_keep : 0.f;
   }
   if (e.residual && (valid || !e.res_masked)) v += *reinterpret_cast<const f32x4*>(e.residual + idx);
   if (e.beta != 0.f) v += *reinterpret_cast<const f32x4*>(g.cfinal + idx) * e.beta;
@@ -540,6 +542,15 @@ inline bool use_km() {
 constexpr long SCALE_BYTES = 2 * AMAX_MAX_BLOCKS * 4 + 256;   // fp16 x2 format: amax partials of A and B, then {1/sA, sA, 1/sB, sB}
 constexpr long PACK_HDR = AMAX_MAX_BLOCKS * 4 + 512;          // vilco_pack buffers: amax partials, {1/s, s}, then the planes
 
+struct Tune { int bm, ks; };
+inline Tune& tune() {       // env read once per process (the plan is made twice per launch); vilco_gemm_force changes it
+  static Tune t = [] {
+    const char* b = getenv("VILCO_GEMM_BM"); const char* k = getenv("VILCO_GEMM_KS");
+    return Tune{b ? atoi(b) : 0, k ? atoi(k) : 0};
+  }();
+  return t;
+}
+
 struct Plan {
   int NP, Kp, BM, ksplit, kchunk;
   bool a_tr, b_tr;
@@ -636,8 +647,10 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
     if (ks < 1) ks = 1;
   }
   // tuning overrides (tools/gemm_tune.py): VILCO_GEMM_BM = 128|256, VILCO_GEMM_KS = forced split count
-  if (const char* e = getenv("VILCO_GEMM_BM")) { const int v = atoi(e); if (v == 128 || v == 256 || (v == 192 && d->precision >= 3)) p.BM = v; }
-  if (const char* e = getenv("VILCO_GEMM_KS")) { const int v = atoi(e); if (v >= 1 && v <= nk) ks = v; }
+  // (read once per process: the plan is made twice per launch)
+  const int force_bm = tune().bm, force_ks = tune().ks;
+  if (force_bm == 128 || force_bm == 256 || (force_bm == 192 && d->precision >= 3)) p.BM = force_bm;
+  if (force_ks >= 1 && force_ks <= nk) ks = force_ks;
   p.kchunk = (nk + ks - 1) / ks;
   p.ksplit = (nk + p.kchunk - 1) / p.kchunk;
   long out_span = 0;
@@ -948,7 +961,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   g.ksplit = p.ksplit; g.kchunk = p.kchunk; g.split_stride = p.split_stride;
   g.inv_a = inv_a; g.inv_b = inv_b;
   g.band = d->band; g.bandT = d->bandT;
-  g.drop_thresh = vilco_drop_threshold_host(d->drop_p); g.drop_seed = d->drop_seed; g.drop_inv_keep = 1.f / (1.f - d->drop_p);
+  g.drop_thresh = vilco_drop_threshold_host(d->drop_p); g.drop_seed = d->drop_seed; g.drop_inv_keep = 1.f / (1.f - d->drop_p); g.seed_word = vilco_seed_word_dev();
   g.vec_out = (d->N % 4) == 0 && (d->ldc % 4) == 0 && (d->sCo % 4) == 0 && (d->sCi % 4) == 0 && vilco_aligned(d->C, 16) &&
               vilco_aligned(d->bias, 16) && vilco_aligned(d->preact, 16) && vilco_aligned(d->colscale, 16) &&
               vilco_aligned(d->residual, 16);
@@ -994,4 +1007,13 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((int)blocks), dim3(256), 0, s, g, nz);
   }
   return vilco_launch_status();
+}
+
+// tuning override (tools/gemm_tune.py): force the tile height (128 | 192 | 256; 0 = cost model) and the split-K count
+// (0 = heuristic) of every following vilco_gemm of this process; the environment variables VILCO_GEMM_BM / VILCO_GEMM_KS
+// give the initial values.
+extern "C" int vilco_gemm_force(int32_t bm, int32_t ks) {
+  if (bm < 0 || ks < 0) return VILCO_ERR_BADARG;
+  tune().bm = bm; tune().ks = ks;
+  return VILCO_OK;
 }

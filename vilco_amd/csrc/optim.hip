@@ -62,6 +62,8 @@ struct Hyper {
   float beta1, beta2, eps;
   float momentum;                          // SGD
   const float* tstep;                      // [n] per-tensor step count (after this update), torch keeps it per param
+  const float* lr_dev;                     // optional [ngroups] learning rates in device memory (override lr[]): a captured
+                                           // step replays its kernel arguments, the schedule's value must come from memory
 };
 
 // torch.optim.AdamW (decoupled weight decay): p *= 1 - lr*wd ; m,v EMA ; p -= lr/bias1 * m / (sqrt(v)/sqrt(bias2) + eps)
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(MultiArgs a, Hyper h
   long cnt = a.numel[t] - off;
   if (cnt > a.chunk) cnt = a.chunk;
   const int gi = a.group[t];
-  const float lr = h.lr[gi], wd = h.wd[gi];
+  const float lr = h.lr_dev ? h.lr_dev[gi] : h.lr[gi], wd = h.wd[gi];
   const float c = coef ? coef[1] : 1.f;
   const float stp = h.tstep[t];
   const float step_size = lr / (1.f - powf(h.beta1, stp));      // bias corrections 1 - beta^step
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(OPT_THREADS) void sgd_kernel(MultiArgs a, Hyper h, 
   long cnt = a.numel[t] - off;
   if (cnt > a.chunk) cnt = a.chunk;
   const int gi = a.group[t];
-  const float lr = h.lr[gi], wd = h.wd[gi];
+  const float lr = h.lr_dev ? h.lr_dev[gi] : h.lr[gi], wd = h.wd[gi];
   const float c = coef ? coef[1] : 1.f;
   const bool first = h.tstep[t] <= 1.f;          // momentum buffer starts as the first gradient
   float mx = 0.f;
@@ -199,7 +201,23 @@ __global__ __launch_bounds__(OPT_THREADS) void scaled_sum_kernel(const float* __
   if (threadIdx.x == 0) out[0] = (float)(red[0] * (double)scale);
 }
 
+struct F16Vals { float v[16]; };
+__global__ void store_f32_kernel(float* __restrict__ dst, F16Vals vals, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+
 }  // namespace
+
+// dst[0..n) = vals[0..n) (n <= 16 host floats, carried as kernel arguments: no staging buffer whose lifetime the caller
+// would have to manage, stream-ordered with the replays that read dst).  The learning rates of a captured step.
+extern "C" int vilco_store_f32(float* dst, const float* vals, int32_t n, void* stream) {
+  if (!dst || !vals || n < 0 || n > 16) return VILCO_ERR_BADARG;
+  if (n == 0) return VILCO_OK;
+  F16Vals v;
+  for (int i = 0; i < 16; ++i) v.v[i] = i < n ? vals[i] : 0.f;
+  hipLaunchKernelGGL(store_f32_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dst, v, n);
+  return vilco_launch_status();
+}
 
 extern "C" int vilco_cl_penalty(const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
                                 const int64_t* chunk_off, int32_t n, int32_t nchunks, int32_t chunk, float lambda,
@@ -232,11 +250,11 @@ extern "C" int vilco_grad_norm(const int64_t* ptrs, const int64_t* numel, const 
   return vilco_launch_status();
 }
 
-extern "C" int vilco_optim_step_amax(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
-                                     const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks,
-                                     int32_t chunk, const float* lr, const float* wd, int32_t ngroups, float beta1,
-                                     float beta2, float eps, float momentum, const float* tensor_step,
-                                     const float* norm_coef, float* chunk_amax, void* stream) {
+extern "C" int vilco_optim_step_dev(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                                    const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks,
+                                    int32_t chunk, const float* lr, const float* wd, int32_t ngroups, float beta1,
+                                    float beta2, float eps, float momentum, const float* tensor_step,
+                                    const float* norm_coef, float* chunk_amax, const float* lr_dev, void* stream) {
   if (!ptrs || !numel || !chunk_tensor || !chunk_off || !group || !lr || !wd || n < 0 || nchunks < 0 || chunk <= 0)
     return VILCO_ERR_BADARG;
   if (ngroups < 1 || ngroups > 8 || !tensor_step || (kind != 0 && kind != 1)) return VILCO_ERR_BADARG;
@@ -246,12 +264,22 @@ extern "C" int vilco_optim_step_amax(int32_t kind, const int64_t* ptrs, const in
   h.beta1 = beta1; h.beta2 = beta2; h.eps = eps;
   h.momentum = momentum;
   h.tstep = tensor_step;
+  h.lr_dev = lr_dev;
   MultiArgs a{reinterpret_cast<const long*>(ptrs), reinterpret_cast<const long*>(numel), chunk_tensor,
               reinterpret_cast<const long*>(chunk_off), group, n, chunk};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (kind == 0) hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, s, a, h, norm_coef, chunk_amax);
   else hipLaunchKernelGGL(sgd_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, s, a, h, norm_coef, chunk_amax);
   return vilco_launch_status();
+}
+
+extern "C" int vilco_optim_step_amax(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
+                                     const int64_t* chunk_off, const int32_t* group, int32_t n, int32_t nchunks,
+                                     int32_t chunk, const float* lr, const float* wd, int32_t ngroups, float beta1,
+                                     float beta2, float eps, float momentum, const float* tensor_step,
+                                     const float* norm_coef, float* chunk_amax, void* stream) {
+  return vilco_optim_step_dev(kind, ptrs, numel, chunk_tensor, chunk_off, group, n, nchunks, chunk, lr, wd, ngroups, beta1,
+                              beta2, eps, momentum, tensor_step, norm_coef, chunk_amax, nullptr, stream);
 }
 
 extern "C" int vilco_optim_step(int32_t kind, const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,

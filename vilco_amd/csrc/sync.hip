@@ -47,3 +47,38 @@ extern "C" int vilco_sync_timeouts_read(void) {
   for (int i = 0; i < VILCO_SYNC_SLOTS * VILCO_SYNC_SITES; ++i) v += w[(long)i * VILCO_SYNC_WORDS + 2];
   return (int)v;
 }
+
+// ---- step word of the counter-based dropout masks (common.h: vilco_step_seed)
+__device__ uint32_t vilco_seed_word_storage[16];      // word 0; its own 64-byte line
+
+const uint32_t* vilco_seed_word_dev() {
+  static const uint32_t* p = [] {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(vilco_seed_word_storage)) != hipSuccess) q = nullptr;
+    return reinterpret_cast<const uint32_t*>(q);
+  }();
+  return p;
+}
+
+__global__ void seed_word_kernel(uint32_t* w, uint32_t v, int add) { *w = add ? *w + v : v; }
+
+extern "C" int vilco_seed_word_set(uint32_t value, void* stream) {
+  uint32_t* w = const_cast<uint32_t*>(vilco_seed_word_dev());
+  if (!w) return VILCO_ERR_LAUNCH;
+  hipLaunchKernelGGL(seed_word_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), w, value, 0);
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_seed_word_bump(void* stream) {
+  uint32_t* w = const_cast<uint32_t*>(vilco_seed_word_dev());
+  if (!w) return VILCO_ERR_LAUNCH;
+  hipLaunchKernelGGL(seed_word_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), w, 1u, 1);
+  return vilco_launch_status();
+}
+
+// current value (synchronises the device: tests / logging only)
+extern "C" int vilco_seed_word_get(uint32_t* out) {
+  if (!out) return VILCO_ERR_BADARG;
+  if (hipDeviceSynchronize() != hipSuccess) return VILCO_ERR_LAUNCH;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(vilco_seed_word_storage), sizeof(uint32_t)) == hipSuccess ? VILCO_OK : VILCO_ERR_LAUNCH;
+}

@@ -146,6 +146,35 @@ class GradReducer:
                     p.grad = v
         self._pending = []
 
+    def reduce_now(self):
+        """Average the gradients that are already complete in p.grad -- a step replayed as a hipGraph (vilco_amd/graph.py)
+        runs no autograd hooks -- and write the result back INTO those gradient tensors: a captured optimizer step holds
+        their addresses.  Same buckets, same order as the hook path; costs the copy back (no overlap with backward: a
+        replayed backward is one graph launch)."""
+        if not self.enabled:
+            return
+        if self.buckets is None:
+            self._build()
+        self.begin()
+        for b in self.buckets:
+            self._launch(b)
+        self._next = len(self.buckets)
+        with torch.no_grad():
+            for b in self._pending:
+                b["work"].wait()
+                if not self._avg:
+                    b["flat"].div_(self.world)
+                src, dst = [], []
+                for p, v in zip(b["params"], b["views"]):
+                    if p.grad is None:
+                        p.grad = v.clone()
+                    elif p.grad.data_ptr() != v.data_ptr():
+                        src.append(v)
+                        dst.append(p.grad)
+                if src:
+                    torch._foreach_copy_(dst, src)
+        self._pending = []
+
     def rebuild(self):
         """forget the plan (the set of trained parameters changed); the next `finish` builds a new one"""
         self.remove()

@@ -1,0 +1,194 @@
+"""A training iteration captured as hipGraphs and replayed -- the host side of the step without the host.
+
+The reference's step (MQ/libs/utils/train_utils.py:322-357: zero_grad, forward, backward, clip_grad_norm_, optimizer
+step) is ~1500 kernel launches on this path, each enqueued by a few microseconds of Python + ctypes: ~25 ms of host time
+per iteration, about what the GPU needs for config P and 4x what it needs for the T = 256 configuration.  The reference has
+no counterpart of this file (eager PyTorch); this is the MI355X answer to its step loop.
+
+`GraphedStep(model, optimizer)` runs the first iterations of every input signature eagerly, then captures
+
+  graph 1: [bump the dropout step word] -> layout change -> backbone -> heads -> fused labels + losses -> backward
+  graph 2: global-norm clip coefficient -> fused AdamW / SGD update (+ max|w| partials for the next weight packs)
+
+and from then on an iteration is: copy the batch into the static input buffers, replay 1, (eager work the caller wants
+between backward and update: a gradient all-reduce, an EWC / MAS penalty), hand the learning rates over, replay 2.
+What must differ between replays lives in device memory: the inputs, the dropout step word (common.h: vilco_step_seed),
+the stochastic-depth factors (torch's graph-safe Philox draw, captured), the loss-normaliser EMA, the optimizer's step
+counts and learning rates (vilco_optim_step_dev).
+
+What is captured is what ran: graphs are keyed by the input shapes, task id and the identity / requires_grad of every
+parameter, and dropped when parameters were written from outside (load_state_dict, an eager optimizer step) -- cached
+operand planes and max|w| partials would be stale otherwise.  Steps the device half cannot run alone (distillation
+against host-side logits, narration SSL, BiC) fall back to the eager path.
+"""
+import ctypes as C
+import gc
+
+import torch
+
+from . import _lib, ops
+
+
+class GraphedStep:
+    def __init__(self, model, optimizer=None, clip_grad_l2norm=-1.0, eager_steps=2, between=None, enabled=True,
+                 gt_pad=8, max_graphs=8, reducer=None):
+        """optimizer: a FusedOptimizer (None: forward + backward only, gradients left in p.grad);
+        eager_steps: iterations of a new signature run eagerly before its capture (>= 1 with an optimizer: the capture
+        must follow an eager update, whose max|w| partials scale the captured weight packs);
+        between: callable run eagerly between backward and the update of every iteration;
+        gt_pad: ground-truth rows are padded to this many segments per clip so that their count does not key the graph;
+        reducer: a dist.GradReducer -- eager iterations exchange gradients from its autograd hooks (overlapped with
+        backward), replayed ones right after graph 1 (`reduce_now`, averaged in place)."""
+        self.model, self.optimizer, self.clip = model, optimizer, float(clip_grad_l2norm)
+        self.eager_steps = max(int(eager_steps), 1 if optimizer is not None else 0)
+        self.between, self.enabled, self.gt_pad, self.max_graphs = between, bool(enabled), gt_pad, int(max_graphs)
+        self.reducer = reducer
+        self._graphs = {}
+        self._pool = None
+        self._lr_dev = None
+        self.params = [p for p in model.parameters()]
+        self.stats = dict(eager=0, captured=0, replayed=0, dropped=0)
+
+    # ------------------------------------------------------------------ bookkeeping
+    def _param_sig(self):
+        ps = [p for p in self.model.parameters()]
+        if len(ps) != len(self.params) or any(a is not b for a, b in zip(ps, self.params)):
+            self.params = ps
+        return hash(tuple((p.data_ptr(), p.requires_grad) for p in ps))
+
+    @staticmethod
+    def _version_sum(tracked):
+        return sum(p._version for p in tracked)
+
+    def reset(self):
+        """forget every captured graph; their memory pool goes with the last of them"""
+        self.stats['dropped'] += sum(1 for e in self._graphs.values() if 'graph' in e)
+        self._graphs = {}
+        self._pool = None
+
+    # ------------------------------------------------------------------ one iteration
+    def __call__(self, video_list, task_id=0, prev_out_cls_logits=None):
+        model = self.model
+        inp = model.prepare(video_list, True, gt_pad=self.gt_pad)
+        if not (self.enabled and model.training and model.capturable(inp, task_id, prev_out_cls_logits)):
+            return self._eager(inp, video_list, task_id, prev_out_cls_logits)
+        key = (inp.signature(), int(task_id), self._param_sig(), int(model.n_known > 0))
+        ent = self._graphs.get(key)
+        if ent is None:
+            if sum(1 for e in self._graphs.values() if 'graph' in e) >= self.max_graphs:
+                self.reset()
+            ent = self._graphs[key] = {'seen': 0}
+        if 'graph' in ent and not self._still_valid(ent):
+            self.reset()
+            ent = self._graphs[key] = {'seen': 0}
+        if 'graph' not in ent:
+            if ent['seen'] < self.eager_steps:
+                ent['seen'] += 1
+                return self._eager(inp, video_list, task_id, prev_out_cls_logits)
+            self._capture(ent, inp, task_id)
+        return self._replay(ent, inp)
+
+    def _eager(self, inp, video_list, task_id, prev):
+        self.stats['eager'] += 1
+        for p in self.params:
+            p.grad = None
+        if self.reducer is not None:
+            self.reducer.begin()
+        losses = self.model.forward_prepared(inp, video_list, task_id=task_id, prev_out_cls_logits=prev)
+        losses['final_loss'].backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        if self.between is not None:
+            self.between()
+        if self.optimizer is not None:
+            self.optimizer.step(clip_grad_l2norm=self.clip)
+        # detached: a caller holding the loss dict must not keep this iteration's autograd graph (and with it the
+        # parameters' AccumulateGrad nodes, which remember the stream they were made on) alive into a later capture
+        return {k: v.detach() for k, v in losses.items()}
+
+    def _still_valid(self, ent):
+        if ent['versions'] != self._version_sum(ent['tracked']):
+            return False                     # a parameter was written through torch (load_state_dict, an in-place edit)
+        if self.optimizer is None:
+            return ent['wgen'] == ops._weight_gen[0]      # weights written through raw pointers since the capture: the
+                                                          # captured forward reads operand planes packed before it
+        return ent['plans'] is self.optimizer._plans      # (a captured update re-packs its weights inside graph 1)
+
+    # ------------------------------------------------------------------ capture
+    def _capture(self, ent, inp, task_id):
+        from .modeling import blocks
+        from .modeling.meta_archs import StepInputs
+        model, lib = self.model, _lib.load()
+        static = StepInputs()
+        static.T, static.narr = inp.T, None
+        for name in StepInputs.__slots__:
+            if name not in ("T", "narr"):
+                t = getattr(inp, name)
+                setattr(static, name, None if t is None else t.clone())
+        for p in self.params:
+            p.grad = None
+        model._cat = None                    # last iteration's head tensors (and through them its autograd graph)
+        blocks.reset_drop_pool()
+        gc.collect()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        hooks_on = self.reducer.enabled if self.reducer is not None else False
+        if self.reducer is not None:
+            self.reducer.enabled = False     # no collectives inside the capture: replays exchange after graph 1
+        try:
+            with torch.cuda.graph(g, pool=self._pool):
+                _lib.check(lib.vilco_seed_word_bump(ops._stream()))
+                losses = model.forward_prepared(static, None, task_id=task_id)
+                losses['final_loss'].backward()
+                keys = sorted(losses)
+                out = torch.stack([losses[k].detach().reshape(()).float() for k in keys])
+        finally:
+            if self.reducer is not None:
+                self.reducer.enabled = hooks_on
+        del losses
+        blocks.reset_drop_pool()
+        if self._pool is None:
+            self._pool = g.pool()
+        ent.update(graph=g, static=static, out=out, keys=keys, grads=[p.grad for p in self.params])
+        if self.optimizer is not None:
+            opt = self.optimizer
+            opt.prepare_step()               # plans + pointer tables for THESE gradient tensors, built outside the capture
+            if self._lr_dev is None:
+                self._lr_dev = torch.zeros(16, dtype=torch.float32, device=self.params[0].device)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=self._pool):
+                opt.step(clip_grad_l2norm=self.clip, lr_dev=self._lr_dev)
+            for pl in opt._plans:            # the capture counted an update that did not run
+                pl['count'] -= 1
+            ent.update(opt_graph=g2, plans=opt._plans)
+        # the parameters the captured step reads: those that got a gradient, and frozen ones (the adapters' EMA copies are
+        # neither: they are written in place after every iteration and only read at inference)
+        ent['tracked'] = [p for p, g in zip(self.params, ent['grads']) if g is not None or not p.requires_grad]
+        ent['versions'] = self._version_sum(ent['tracked'])
+        ent['wgen'] = ops._weight_gen[0]
+        self.stats['captured'] += 1
+
+    # ------------------------------------------------------------------ replay
+    def _replay(self, ent, inp):
+        static = ent['static']
+        for name, t in inp.tensors():
+            getattr(static, name).copy_(t, non_blocking=True)
+        ent['graph'].replay()
+        for p, g in zip(self.params, ent['grads']):
+            if p.grad is not g:
+                p.grad = g
+        if self.reducer is not None:
+            self.reducer.reduce_now()
+        if self.between is not None:
+            self.between()
+        if self.optimizer is not None:
+            opt = self.optimizer
+            ng = len(opt.param_groups)
+            lr = (C.c_float * ng)(*[float(g['lr']) for g in opt.param_groups])
+            _lib.check(_lib.load().vilco_store_f32(self._lr_dev.data_ptr(), lr, ng, ops._stream()))
+            ent['opt_graph'].replay()
+            opt.note_replays(1)
+            opt._opt_called = True           # torch's LR schedulers check that optimizer.step() ran before scheduler.step()
+        self.stats['replayed'] += 1
+        out = ent['out'].clone()
+        return {k: out[i] for i, k in enumerate(ent['keys'])}

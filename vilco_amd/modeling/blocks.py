@@ -53,6 +53,13 @@ _DROP_POOL = {}          # (device, B, keep) -> [rows of ready factors, next row
 _DROP_POOL_ROWS = 64
 
 
+def reset_drop_pool():
+    """forget the drawn stochastic-depth factors.  Called around a stream capture (vilco_amd/graph.py): the pool drawn
+    inside the capture is re-drawn by every replay (torch's graph-safe Philox offset), rows drawn before it would be
+    replayed as constants."""
+    _DROP_POOL.clear()
+
+
 def _drop_rowscale(x, drop_prob, training):
     """per-sample stochastic-depth factor (blocks.py:628-641) as a [B] row scale, or None.
     The reference draws `keep + rand(B)`, floors it and divides by keep at each of its ~30 sites per step (four tiny

@@ -266,6 +266,19 @@ class PtTransformerRegHead(_ConvHead):
         return tuple(from_tm(y) for y in self.forward_tm([to_tm(f) for f in fpn_feats], lens))
 
 
+class StepInputs:
+    """device-resident inputs of one step (PtTransformer.prepare): feats_cf [B,Cin,T], lens int32 [B], text_cf
+    [B,Ctxt,L], text_lens int32 [B], gt float [B, 3*Nmax+1] (training), narr = narration tuple or None"""
+    __slots__ = ("feats_cf", "lens", "T", "text_cf", "text_lens", "narr", "gt")
+
+    def tensors(self):
+        """(name, tensor) of every device buffer a replayed step reads"""
+        return [(k, getattr(self, k)) for k in ("feats_cf", "lens", "text_cf", "text_lens", "gt") if getattr(self, k) is not None]
+
+    def signature(self):
+        return tuple((k, tuple(t.shape)) for k, t in self.tensors()) + (("narr", self.narr is not None),)
+
+
 @register_meta_arch("LocPointTransformer")
 class PtTransformer(nn.Module):
     def __init__(self, backbone_type, fpn_type, use_xl, backbone_arch, scale_factor, input_dim,
@@ -433,9 +446,8 @@ class PtTransformer(nn.Module):
             setattr(self, name, new)
 
     # ------------------------------------------------------------------ batching
-    def preprocessing(self, video_list, is_training=True, padding_val=0.0):
-        """list of dicts -> (x_tm [B,T,C] on device, lens int32 [B], max_len)  (meta_archs.py:1134-1181;
-        the reference returns channel-first [B,C,T] + bool mask: see `preprocessing_cf`)."""
+    def _batch_cf(self, video_list, is_training=True, padding_val=0.0):
+        """list of dicts -> (batched [B,C,T] channel-first on device, lens int32 [B], max_len)  (meta_archs.py:1134-1181)"""
         feats = [x['feats'] for x in video_list if len(x['labels']) > 0]
         feats_lens = [f.shape[-1] for f in feats]
         max_len = max(feats_lens)
@@ -454,6 +466,12 @@ class PtTransformer(nn.Module):
         for f, dst in zip(feats, batched):
             dst[..., :f.shape[-1]].copy_(f, non_blocking=True)       # H2D (or D2D) of the raw [C, t_i]
         lens = torch.as_tensor(feats_lens, dtype=torch.int32).to(dev)
+        return batched, lens, max_len
+
+    def preprocessing(self, video_list, is_training=True, padding_val=0.0):
+        """list of dicts -> (x_tm [B,T,C] on device, lens int32 [B], max_len)  (meta_archs.py:1134-1181;
+        the reference returns channel-first [B,C,T] + bool mask: see `preprocessing_cf`)."""
+        batched, lens, max_len = self._batch_cf(video_list, is_training, padding_val)
         return ops.transpose(batched), lens, max_len
 
     def preprocessing_cf(self, video_list, is_training=True, padding_val=0.0):
@@ -464,6 +482,12 @@ class PtTransformer(nn.Module):
     @torch.no_grad()
     def query_preprocessing(self, video_list, padding_val=0.0):
         """text tokens [768, L_i] -> token-major [B, Lmax, 768] + lens (meta_archs.py:1184-1221)."""
+        batched, lens, narr = self._query_batch_cf(video_list, padding_val)
+        return ops.transpose(batched), lens, narr
+
+    @torch.no_grad()
+    def _query_batch_cf(self, video_list, padding_val=0.0):
+        """-> (batched [B,768,Lmax] channel-first on device, lens int32 [B], narration tuple or None)"""
         feats = [x['prompt_feature'] for x in video_list]
         lens_h = [f.shape[-1] for f in feats]
         dev = self.device
@@ -481,7 +505,39 @@ class PtTransformer(nn.Module):
             m0 = torch.Tensor([x['narration_mask'] for x in video_list]).to(dev)
             m1 = (torch.arange(max(nl))[None, :] < torch.as_tensor(nl)[:, None]).unsqueeze(1).to(dev)
             narr = (nb, m0, m1)
-        return ops.transpose(batched), lens, narr
+        return batched, lens, narr
+
+    def _gt_table(self, video_list, nmax=None):
+        """ground truth of the labelled clips as ONE float table [B, 3*Nmax+1] for the fused label / loss kernels
+        (include/vilco_hip.h: vilco_loss_desc.gt): 2*Nmax segment bounds, Nmax labels, the count.  Nmax may be padded
+        (the kernels stop at the count), which keeps the table's shape stable from batch to batch."""
+        vids = [x for x in video_list if len(x['labels']) > 0]
+        n_real = max(int(x['labels'].shape[0]) for x in vids)
+        nmax = n_real if nmax is None else max(int(nmax), n_real)
+        gt = torch.zeros(len(vids), 3 * nmax + 1, dtype=torch.float32)
+        for b, x in enumerate(vids):
+            n = int(x['labels'].shape[0])
+            gt[b, :2 * n] = x['segments'].reshape(-1).float().cpu()
+            gt[b, 2 * nmax:2 * nmax + n] = x['labels'].float().cpu()
+            gt[b, 3 * nmax] = n
+        return gt.to(self.device, non_blocking=True)
+
+    def prepare(self, video_list, is_training=True, gt_pad=None):
+        """Everything `forward` takes from the clip dictionaries, as device tensors: the host half of the step (padding,
+        H2D copies, the ground-truth table).  `forward_prepared` is the device half -- no host reads, no H2D copies, so a
+        training step over a `StepInputs` can be captured as a hipGraph and replayed over refreshed buffers
+        (vilco_amd/graph.py).  The channel-first -> token-major layout change is part of the device half."""
+        inp = StepInputs()
+        inp.feats_cf, inp.lens, inp.T = self._batch_cf(video_list, is_training)
+        inp.text_cf = inp.text_lens = inp.narr = None
+        if self.use_cross_modal:
+            inp.text_cf, inp.text_lens, inp.narr = self._query_batch_cf(video_list)
+            assert inp.text_cf.shape[0] == inp.feats_cf.shape[0], \
+                "every clip of the batch needs labels (the reference drops unlabelled clips from the video batch only)"
+        inp.gt = None
+        if is_training and video_list[0].get('segments') is not None and video_list[0].get('labels') is not None:
+            inp.gt = self._gt_table(video_list, gt_pad)
+        return inp
 
     # ------------------------------------------------------------------ forward
     def _run_network(self, x_tm, lens, text_tm, text_lens, raw_offsets=False):
@@ -495,10 +551,34 @@ class PtTransformer(nn.Module):
 
     def forward(self, video_list, task_id=-1, ensemble=False, hidden_state=False, is_training=True,
                 prev_out_cls_logits=None, get_emb=False, val_qilDatasetList=None):
-        x_tm, lens, _ = self.preprocessing(video_list, is_training)
-        text_tm = text_lens = narr = None
+        inp = self.prepare(video_list, is_training)
+        return self.forward_prepared(inp, video_list, task_id=task_id, ensemble=ensemble, is_training=is_training,
+                                     prev_out_cls_logits=prev_out_cls_logits, get_emb=get_emb,
+                                     val_qilDatasetList=val_qilDatasetList)
+
+    def capturable(self, inp, task_id=-1, prev_out_cls_logits=None):
+        """can forward_prepared(inp, None, task_id) + backward run without touching the host?  (the fused label / loss
+        kernels, a fixed prompt window, no narration SSL -- whose memory-bank update reads a device flag --, no
+        distillation against host-side logits)"""
+        if not (self.fused_loss and self.sync_free_loss and self.train_loss_weight > 0 and self.num_classes <= 128):
+            return False
+        if inp.gt is None or (self.training and self.narration_ssl) or prev_out_cls_logits:
+            return False
+        if self.n_known > 0 and self.cl_name in ('bic', 'icarl'):
+            return False
+        if hasattr(self, 'prompt') and not (0 <= task_id and (task_id + 1) * self.prompt.top_k <= self.prompt.pool_size):
+            return False
+        return True
+
+    def forward_prepared(self, inp, video_list=None, task_id=-1, ensemble=False, is_training=True,
+                         prev_out_cls_logits=None, get_emb=False, val_qilDatasetList=None):
+        """the device half of `forward` over a StepInputs; `video_list` is only needed by the paths that read the clip
+        dictionaries (inference meta data, the unfused label path)."""
+        x_tm, lens = ops.transpose(inp.feats_cf), inp.lens
+        text_tm = text_lens = None
+        narr = inp.narr
         if self.use_cross_modal:
-            text_tm, text_lens, narr = self.query_preprocessing(video_list)
+            text_tm, text_lens = ops.transpose(inp.text_cf), inp.text_lens
 
         reduce_sim = None
         if hasattr(self, 'prompt'):
@@ -545,11 +625,10 @@ class PtTransformer(nn.Module):
             return out_cls_logits, out_offsets, fpn_masks
 
         if is_training:
-            assert video_list[0]['segments'] is not None, "GT action labels does not exist"
-            assert video_list[0]['labels'] is not None, "GT action labels does not exist"
+            assert inp.gt is not None, "GT action labels does not exist"
             dev = self.device
             if fused:
-                losses = self._fused_losses(video_list, points, fpn_lens, out_cls_logits, out_offsets,
+                losses = self._fused_losses(inp.gt, points, fpn_lens, out_cls_logits, out_offsets,
                                             prev_out_cls_logits, reduce_sim)
             else:
                 gt_segments = [x['segments'].to(dev) for x in video_list if len(x['labels']) > 0]
@@ -680,24 +759,17 @@ class PtTransformer(nn.Module):
             self._loss_tab = tab
         return tab[1]
 
-    def _fused_losses(self, video_list, points, fpn_lens, out_cls_logits, out_offsets, prev_out_cls_logits, reduce_sim):
-        """meta_archs.py:1253-1344 + 1374-1447 through ops.mq_loss; the CL terms (:1478-1519) are added on top."""
-        cat = self._cat
+    def _fused_losses(self, gt, points, fpn_lens, out_cls_logits, out_offsets, prev_out_cls_logits, reduce_sim):
+        """meta_archs.py:1253-1344 + 1374-1447 through ops.mq_loss; the CL terms (:1478-1519) are added on top.
+        gt: the table of `_gt_table` -- one row per clip of the batch, in batch order."""
+        cat, self._cat = self._cat, None       # not kept: it holds this step's head tensors and their autograd graph
         dev = self.device
-        vids = [x for x in video_list if len(x['labels']) > 0]
-        nmax = max(int(x['labels'].shape[0]) for x in vids)
-        gt = torch.zeros(len(vids), 3 * nmax + 1, dtype=torch.float32)
-        for b, x in enumerate(vids):
-            n = int(x['labels'].shape[0])
-            gt[b, :2 * n] = x['segments'].reshape(-1).float().cpu()
-            gt[b, 2 * nmax:2 * nmax + n] = x['labels'].float().cpu()
-            gt[b, 3 * nmax] = n
-        gt = gt.to(dev, non_blocking=True)
         if cat is not None and getattr(cat, "raw_offsets", None) is not None and out_offsets is None:
             logits, offsets = cat.cls_logits, cat.raw_offsets
             scale = torch.stack([s.scale for s in self.reg_head.scale])
         else:
             logits, offsets, scale, cat = torch.cat(out_cls_logits, dim=1), torch.cat(out_offsets, dim=1), None, None
+        assert gt.shape[0] == logits.shape[0], "ground-truth rows (%d) != clips in the batch (%d)" % (gt.shape[0], logits.shape[0])
         tables = self._loss_tables(points, cat, dev)
         level_len = torch.stack([l.to(torch.int32) for l in fpn_lens], dim=1).contiguous()
         gauss = torch.cat([self.mu, self.sigma, self.mu_reg_left, self.sigma_reg_left, self.mu_reg_right,

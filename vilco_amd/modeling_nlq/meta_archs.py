@@ -150,13 +150,13 @@ class PtTransformer(mq.PtTransformer):
                             prompt_feature=x['query_feats']))
         return out
 
-    def preprocessing(self, video_list, is_training=True, padding_val=0.0):
+    def _batch_cf(self, video_list, is_training=True, padding_val=0.0):
         vl = [x if 'labels' in x else dict(x, labels=[0]) for x in video_list]      # NLQ batches every clip (:923)
-        return super().preprocessing(vl, is_training, padding_val)
+        return super()._batch_cf(vl, is_training, padding_val)
 
-    def query_preprocessing(self, video_list, padding_val=0.0):
+    def _query_batch_cf(self, video_list, padding_val=0.0):
         vl = [x if 'prompt_feature' in x else dict(x, prompt_feature=x['query_feats']) for x in video_list]
-        return super().query_preprocessing(vl, padding_val)
+        return super()._query_batch_cf(vl, padding_val)
 
     def forward(self, video_list, task_id=-1, ensemble=False, hidden_state=False, is_training=True,
                 prev_out_cls_logits=None, get_emb=False, val_qilDatasetList=None):

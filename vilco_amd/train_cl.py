@@ -56,14 +56,31 @@ def cache_prev_logits(model, loader, task_id):
     return out
 
 
+def _barrier(reducer):
+    if reducer is not None:
+        import torch.distributed as dist
+        dist.barrier(group=reducer.group)
+
+
 def run_episodes(cfg, model, train_stream, validate=None, ckpt_folder=None, gpu_id=0, start_task=0, start_epoch=0,
-                 combine_train=False, reducer=None, logger=None, print_freq=20, on_step_history=None):
+                 combine_train=False, reducer=None, logger=None, print_freq=20, on_step_history=None, use_graph=False,
+                 keep_history=True):
     """cfg: the merged config dict (opt / train_cfg / cl_cfg as in libs/core/config.py).
     validate(model, epoch, task) -> mAP-like float (higher is better), or None to skip validation (every epoch's
-    state then counts as "best", so the last epoch is what gets reloaded).
+    state then counts as "best", so the last epoch is what gets reloaded).  `validate` must be RANK-LOCAL (no
+    collectives): inside the epoch loop only the main rank calls it (train_cl.py:283), the others wait at a barrier.
+    use_graph: replay the iterations as hipGraphs (vilco_amd/graph.py; a fresh GraphedStep per optimizer, i.e. per task).
+    keep_history: keep every iteration's loss dict (device scalars) in the log; off for long runs.
     Returns (model, optimizer, scheduler, log) with log = list of per-task dicts."""
     is_main = int(os.environ.get("LOCAL_RANK", "0")) == 0
     optimizer = make_optimizer(model, cfg['opt'])
+
+    def make_graph(opt):
+        if not use_graph:
+            return None
+        from .graph import GraphedStep
+        return GraphedStep(model, opt, clip_grad_l2norm=cfg['train_cfg']['clip_grad_l2norm'], reducer=reducer)
+    graph = make_graph(optimizer)
     it = iter(train_stream)
     num_tasks = train_stream.num_tasks
     data, loader, num_next = next(it)
@@ -90,19 +107,24 @@ def run_episodes(cfg, model, train_stream, validate=None, ckpt_folder=None, gpu_
             hist = train_one_epoch(loader, model, optimizer, scheduler, epoch, 1, model_ema=None,
                                    clip_grad_l2norm=cfg['train_cfg']['clip_grad_l2norm'], print_freq=print_freq,
                                    logger=logger, cl_name=cfg['cl_cfg']['name'], reg_lambda=cfg['cl_cfg']['reg_lambda'],
-                                   prev_out_cls_logits_dict=prev_logits, current_task_id=j, reducer=reducer)
-            entry['history'].append(hist)
+                                   prev_out_cls_logits_dict=prev_logits, current_task_id=j, reducer=reducer, graph=graph,
+                                   keep_history=keep_history or on_step_history is not None)
+            if keep_history:
+                entry['history'].append(hist)
             if on_step_history is not None:
                 on_step_history(j, epoch, hist)
-            if not (is_main and not combine_train) or epoch < max_epochs // 3:
+            if combine_train or epoch < max_epochs // 3:
                 continue
-            metric = validate(model, epoch, j) if validate is not None else float(epoch)
-            if metric > best:
-                best, best_epoch = metric, epoch
-                if ckpt_folder is not None:
-                    save_checkpoint({'task': j, 'epoch': epoch, 'state_dict': model.state_dict(),
-                                     'scheduler': scheduler.state_dict(), 'optimizer': optimizer.state_dict(),
-                                     'reg_params': model.reg_params}, file_folder=ckpt_folder, file_name=ck_name)
+            if is_main:
+                metric = validate(model, epoch, j) if validate is not None else float(epoch)
+                if metric > best:
+                    best, best_epoch = metric, epoch
+                    if ckpt_folder is not None:
+                        save_checkpoint({'task': j, 'epoch': epoch, 'state_dict': model.state_dict(),
+                                         'scheduler': scheduler.state_dict(), 'optimizer': optimizer.state_dict(),
+                                         'reg_params': model.reg_params}, file_folder=ckpt_folder, file_name=ck_name)
+            _barrier(reducer)          # the other ranks do not run ahead into the next epoch's collectives while rank 0
+                                       # validates and writes the checkpoint
         entry['best_metric'], entry['best_epoch'] = best, best_epoch
 
         # replay memory for the next task (train_cl.py:343-361)
@@ -111,10 +133,14 @@ def run_episodes(cfg, model, train_stream, validate=None, ckpt_folder=None, gpu_
             model.add_samples_to_mem(None, data, memory_quota(memory_size, n_cls))
         train_stream.memory = model.memory
         model.n_known = len(model.memory)
-        if ckpt_folder is not None and is_main:
-            os.makedirs(ckpt_folder, exist_ok=True)
-            with open(os.path.join(ckpt_folder, cfg['cl_cfg']['path_memory']), 'wb') as h:
-                pickle.dump(model.memory, h)
+        if ckpt_folder is not None:
+            if is_main:
+                os.makedirs(ckpt_folder, exist_ok=True)
+                with open(os.path.join(ckpt_folder, cfg['cl_cfg']['path_memory']), 'wb') as h:
+                    pickle.dump(model.memory, h)
+            _barrier(reducer)          # the checkpoint rank 0 wrote is complete before anybody reads it
+            # EVERY rank reloads the task's best state (train_cl.py:363 runs on every rank): replicas that kept their
+            # last-epoch weights would never meet the others again -- the gradient average does not re-align weights
             model = load_best_checkpoint(model, ckpt_folder, ck_name, j, gpu_id)
         if validate is not None:
             entry['final_metric'] = validate(model, max_epochs - 1, j)
@@ -130,4 +156,5 @@ def run_episodes(cfg, model, train_stream, validate=None, ckpt_folder=None, gpu_
             scheduler = make_scheduler(optimizer, cfg['opt'], iters_per_epoch)
             if reducer is not None:
                 reducer.rebuild()          # the class head and the gaussian parameters are new tensors
+            graph = make_graph(optimizer)  # new parameters, new optimizer: the old task's graphs are dropped
     return model, optimizer, scheduler, log

@@ -66,13 +66,20 @@ def param_groups(model):
 
 class FusedOptimizer(optim.Optimizer):
     """AdamW (torch.optim.AdamW defaults: betas (0.9, 0.999), eps 1e-8) or SGD+momentum over fp32 CUDA
-    parameters, executed by vilco_grad_norm / vilco_optim_step."""
+    parameters, executed by vilco_grad_norm / vilco_optim_step.
+
+    Everything a step needs lives on the device between steps: the chunk tables, the [4, n] pointer table (rebuilt only when
+    a parameter, gradient or state tensor moved), the per-tensor step counts (incremented by a device add) and -- when a
+    `lr_dev` tensor is passed -- the learning rates.  A step is then three launches with no host -> device copy, which is
+    what lets vilco_amd/graph.py capture it as a hipGraph; `state[p]['step']` (torch.optim's layout) is brought up to date
+    lazily (`state_dict()`, plan changes)."""
 
     def __init__(self, params, lr, kind="AdamW", momentum=0.9, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         assert kind in ("AdamW", "SGD")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, momentum=momentum))
         self.kind = kind
-        self._plan_key, self._plan = None, None
+        self._plans = None              # list over passes, valid for self._plans_key
+        self._plans_key = None
         self.last_grad_norm = None      # device tensor [norm, clip coef] of the last step
 
     def _passes(self):
@@ -88,9 +95,9 @@ class FusedOptimizer(optim.Optimizer):
                 while len(passes) <= k:
                     passes.append([])
                 passes[k].append((p, gi))
-        return passes
+        return passes, seen
 
-    def _build_plan(self, items):
+    def _build_plan(self, k, items, occurrences):
         numel = [p.numel() for p, _ in items]
         ct, co, first = [], [], []
         for i, n in enumerate(numel):
@@ -101,18 +108,92 @@ class FusedOptimizer(optim.Optimizer):
         first.append(len(ct))
         dev = items[0][0].device
         amax = torch.empty(max(len(ct), 1), dtype=torch.float32, device=dev)
-        return dict(first=first, amax=amax, amax_views=[amax[first[i]:first[i + 1]] for i in range(len(numel))],
+        inc = [float(occurrences[id(p)]) for p, _ in items]
+        base = [float(self.state[p]['step']) for p, _ in items]
+        # step count handed to the kernel = count AFTER this pass's increment: a parameter listed m times goes
+        # s -> s+1 (pass 0) -> s+2 (pass 1) ... within one iteration and by m from iteration to iteration
+        tstep0 = [b + (k + 1) - m for b, m in zip(base, inc)]
+        uniform = all(m == 1.0 for m in inc)
+        return dict(items=items, first=first, amax=amax,
+                    amax_views=[amax[first[i]:first[i + 1]] for i in range(len(numel))],
                     numel=torch.tensor(numel, dtype=torch.int64, device=dev),
                     chunk_tensor=torch.tensor(ct, dtype=torch.int32, device=dev),
                     chunk_off=torch.tensor(co, dtype=torch.int64, device=dev),
                     group=torch.tensor([gi for _, gi in items], dtype=torch.int32, device=dev),
-                    partial=torch.empty(max(len(ct), 1), dtype=torch.float32, device=dev), nchunks=len(ct))
+                    partial=torch.empty(max(len(ct), 1), dtype=torch.float32, device=dev), nchunks=len(ct),
+                    tstep=torch.tensor(tstep0, dtype=torch.float32, device=dev),
+                    inc=None if uniform else torch.tensor(inc, dtype=torch.float32, device=dev),
+                    inc_host=inc, base=base, count=0, tables={})
+
+    def _sync_steps(self):
+        """bring state[p]['step'] (host tensors, torch.optim's layout) up to date with the device-side counts"""
+        if self._plans:
+            pl = self._plans[0]                  # pass 0 lists every stepped parameter exactly once
+            if pl['count']:
+                for (p, _), b, m in zip(pl['items'], pl['base'], pl['inc_host']):
+                    self.state[p]['step'] = torch.tensor(b + m * pl['count'])
+
+    def _flush_steps(self):
+        self._sync_steps()
+        self._plans, self._plans_key = None, None
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._plans, self._plans_key = None, None
+        return super().load_state_dict(state_dict)
+
+    def _ensure_state(self, items):
+        for p, _ in items:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                raise RuntimeError("FusedOptimizer needs contiguous fp32 parameters on the HIP device")
+            st = self.state[p]
+            if len(st) == 0:
+                st['step'] = torch.tensor(0.0)
+                if self.kind == "AdamW":
+                    st['exp_avg'] = torch.zeros_like(p)
+                    st['exp_avg_sq'] = torch.zeros_like(p)
+                else:
+                    st['momentum_buffer'] = torch.zeros_like(p)
+
+    def prepare_step(self):
+        """(re)build whatever the next step() needs that costs a host -> device copy: chunk plans when the set of stepped
+        parameters changed, pointer tables when a tensor moved.  step() calls it itself; a caller about to CAPTURE step()
+        calls it first, outside the capture."""
+        passes, occ = self._passes()
+        key = tuple(tuple(id(p) for p, _ in items) for items in passes)
+        if key != self._plans_key:
+            self._flush_steps()
+            for items in passes:
+                self._ensure_state(items)
+            self._plans = [self._build_plan(k, items, occ) for k, items in enumerate(passes)]
+            self._plans_key = key
+        s1 = 'exp_avg' if self.kind == "AdamW" else 'momentum_buffer'
+        adam = self.kind == "AdamW"
+        tables = []
+        for pl in self._plans:
+            items = pl['items']
+            rows = ([p.data_ptr() for p, _ in items], [p.grad.data_ptr() for p, _ in items],
+                    [self.state[p][s1].data_ptr() for p, _ in items],
+                    [self.state[p]['exp_avg_sq'].data_ptr() if adam else 0 for p, _ in items])
+            tkey = hash((tuple(rows[0]), tuple(rows[1])))
+            tab = pl['tables'].get(tkey)
+            if tab is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("FusedOptimizer.step() under stream capture needs prepare_step() before the capture")
+                tab = pl['tables'][tkey] = torch.tensor(rows, dtype=torch.int64).to(items[0][0].device)
+            tables.append(tab)
+        return tables
 
     @torch.no_grad()
-    def step(self, closure=None, clip_grad_l2norm=-1.0):
+    def step(self, closure=None, clip_grad_l2norm=-1.0, lr_dev=None):
+        """lr_dev: optional device float tensor [len(param_groups)] the kernels read the learning rates from (a captured
+        step); default: the param_groups' values, passed by value."""
         lib = _lib.load()
-        stream = torch.cuda.current_stream().cuda_stream
-        passes = self._passes()
+        stream = ops._stream()
+        tables = self.prepare_step()
         ng = len(self.param_groups)
         lr = (C.c_float * ng)(*[float(g['lr']) for g in self.param_groups])
         wd = (C.c_float * ng)(*[float(g['weight_decay']) for g in self.param_groups])
@@ -120,45 +201,30 @@ class FusedOptimizer(optim.Optimizer):
         emitted = {}     # id(p) -> (p, partials view, count) of the LAST pass that wrote p
         coef = None      # clip coefficient of pass 0, reused by every pass: clip_grad_norm_ scales p.grad in place
                          # (train_utils.py:343-347), so a parameter listed twice is stepped twice with the CLIPPED gradient
-        for k, items in enumerate(passes):
-            for p, _ in items:
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
-                    raise RuntimeError("FusedOptimizer needs contiguous fp32 parameters on the HIP device")
-                st = self.state[p]
-                if len(st) == 0:
-                    st['step'] = torch.tensor(0.0)
-                    if self.kind == "AdamW":
-                        st['exp_avg'] = torch.zeros_like(p)
-                        st['exp_avg_sq'] = torch.zeros_like(p)
-                    else:
-                        st['momentum_buffer'] = torch.zeros_like(p)
-            key = (k, tuple(id(p) for p, _ in items))
-            if k == 0 and key != self._plan_key:
-                self._plan_key, self._plan = key, self._build_plan(items)
-            plan = self._plan if k == 0 else self._build_plan(items)
-            s1 = 'exp_avg' if self.kind == "AdamW" else 'momentum_buffer'
-            ptrs = torch.tensor([[p.data_ptr() for p, _ in items], [p.grad.data_ptr() for p, _ in items],
-                                 [self.state[p][s1].data_ptr() for p, _ in items],
-                                 [self.state[p]['exp_avg_sq'].data_ptr() if self.kind == "AdamW" else 0 for p, _ in items]],
-                                dtype=torch.int64).to(items[0][0].device, non_blocking=True)
+        for k, (plan, ptrs) in enumerate(zip(self._plans, tables)):
+            items = plan['items']
             n = len(items)
             if k == 0:
-                coef = torch.empty(2, dtype=torch.float32, device=items[0][0].device)
+                coef = plan.get('coef')
+                if coef is None:
+                    coef = plan['coef'] = torch.empty(2, dtype=torch.float32, device=items[0][0].device)
                 _lib.check(lib.vilco_grad_norm(ptrs.data_ptr(), plan['numel'].data_ptr(), plan['chunk_tensor'].data_ptr(),
                                                plan['chunk_off'].data_ptr(), n, plan['nchunks'], CHUNK,
                                                float(clip_grad_l2norm), plan['partial'].data_ptr(), coef.data_ptr(), stream))
                 self.last_grad_norm = coef
-            for p, _ in items:
-                self.state[p]['step'] += 1          # torch.optim keeps the step per parameter
-            tstep = torch.tensor([float(self.state[p]['step']) for p, _ in items], dtype=torch.float32).to(
-                items[0][0].device, non_blocking=True)
+            if plan['inc'] is None:
+                plan['tstep'].add_(1.0)              # torch.optim keeps the step per parameter
+            else:
+                plan['tstep'].add_(plan['inc'])
+            plan['count'] += 1
             # the update also leaves max|p| of every chunk it wrote: the scale of next step's fp16 x2 weight planes
-            _lib.check(lib.vilco_optim_step_amax(0 if self.kind == "AdamW" else 1, ptrs.data_ptr(), plan['numel'].data_ptr(),
-                                                 plan['chunk_tensor'].data_ptr(), plan['chunk_off'].data_ptr(),
-                                                 plan['group'].data_ptr(), n, plan['nchunks'], CHUNK, lr, wd, ng,
-                                                 g0['betas'][0], g0['betas'][1], g0['eps'], g0['momentum'], tstep.data_ptr(),
-                                                 None if coef is None or clip_grad_l2norm <= 0 else coef.data_ptr(),
-                                                 plan['amax'].data_ptr() if OPT_AMAX else None, stream))
+            _lib.check(lib.vilco_optim_step_dev(0 if self.kind == "AdamW" else 1, ptrs.data_ptr(), plan['numel'].data_ptr(),
+                                                plan['chunk_tensor'].data_ptr(), plan['chunk_off'].data_ptr(),
+                                                plan['group'].data_ptr(), n, plan['nchunks'], CHUNK, lr, wd, ng,
+                                                g0['betas'][0], g0['betas'][1], g0['eps'], g0['momentum'], plan['tstep'].data_ptr(),
+                                                None if coef is None or clip_grad_l2norm <= 0 else coef.data_ptr(),
+                                                plan['amax'].data_ptr() if OPT_AMAX else None,
+                                                None if lr_dev is None else lr_dev.data_ptr(), stream))
             first = plan['first']
             for i, (p, _) in enumerate(items):
                 if p.dim() >= 2 and OPT_AMAX:    # matrices: the tensors that get packed
@@ -167,6 +233,12 @@ class FusedOptimizer(optim.Optimizer):
         for p, parts, cnt in emitted.values():
             ops.tag_weight_amax(p, parts, cnt)
         return None
+
+    def note_replays(self, n=1):
+        """a captured step() was replayed n times: account for the step counts the replays advanced on the device"""
+        for pl in self._plans or ():
+            pl['count'] += n
+        ops.weights_changed()
 
 
 def make_optimizer(model, optimizer_config):
@@ -251,41 +323,58 @@ class AverageMeter(object):
 
 def train_one_epoch(train_loader, model, optimizer, scheduler, curr_epoch, n_gpu=1, model_ema=None,
                     clip_grad_l2norm=-1, tb_writer=None, print_freq=20, logger=None, cl_name=None, reg_lambda=0.0,
-                    prev_out_cls_logits_dict=None, current_task_id=0, reducer=None):
+                    prev_out_cls_logits_dict=None, current_task_id=0, reducer=None, graph=None, keep_history=True):
     """One epoch of the continual-learning training loop (train_utils.py:278-423), same arguments.  Per iteration:
     zero_grad, forward with `task_id` and the cached iCaRL/BiC logits of the batch's videos, backward of
     final_loss (+ the EWC / MAS penalty of cl_name, applied as one multi-tensor kernel that adds its gradient to
     p.grad), [gradient all-reduce], fused clip + optimizer step, scheduler step, adapter EMA (`post_train_step`).
     Nothing in the loop reads a device value unless a log line is due (every `print_freq` iterations).
-    Returns the list of per-iteration loss dicts (device tensors), which the reference does not -- harmless."""
+    graph: a vilco_amd.graph.GraphedStep built over (model, optimizer, clip_grad_l2norm[, reducer]) -- iterations whose
+    device half can run alone are then replayed as hipGraphs instead of launched kernel by kernel; the others (and the
+    first iterations of every new batch shape) take the eager path inside it.
+    Returns the list of per-iteration loss dicts (device scalars; empty with keep_history=False), which the reference
+    does not -- harmless."""
     from ..cl_methods import regularizers
     model.train()
     model.compute_means = model.cl_name == 'icarl'
     tracker, history = {}, []
+    if graph is not None:
+        assert graph.model is model and graph.optimizer is optimizer, "the GraphedStep was built over another model / optimizer"
+        assert graph.reducer is reducer, "pass the reducer to the GraphedStep as well"
+        graph.clip = float(clip_grad_l2norm)
+    last_pen = [None]
+
+    def penalty():
+        # loss + lambda * sum_i sum_p F_i (theta*_i - theta)^2 (EWC.py:6-22 / MAS.py:5-21): value added to the
+        # reported loss, gradient added straight into p.grad.  The penalty is the same on every rank, so adding it
+        # after the gradient average equals averaging it.
+        last_pen[0] = regularizers.apply_penalty(model, reg_lambda, kind=cl_name) if cl_name in ('ewc', 'mas') else None
+
     for iter_idx, video_list in enumerate(train_loader, 0):
-        optimizer.zero_grad(set_to_none=True)
         prev = []
         for v in video_list:
             if prev_out_cls_logits_dict is not None and v['video_id'] in prev_out_cls_logits_dict:
                 prev.append(prev_out_cls_logits_dict[v['video_id']])
-        if reducer is not None:
-            reducer.begin()
-        losses = model(video_list, task_id=current_task_id, prev_out_cls_logits=prev)
-        losses['final_loss'].backward()
-        if reducer is not None:
-            reducer.finish()
-        if cl_name in ('ewc', 'mas'):
-            # loss + lambda * sum_i sum_p F_i (theta*_i - theta)^2 (EWC.py:6-22 / MAS.py:5-21): value added to the
-            # reported loss, gradient added straight into p.grad.  The penalty is the same on every rank, so adding it
-            # after the gradient average equals averaging it.
-            pen = regularizers.apply_penalty(model, reg_lambda, kind=cl_name)
-            if pen is not None:
-                losses['final_loss'] = losses['final_loss'].detach() + pen
-        optimizer.step(clip_grad_l2norm=clip_grad_l2norm)
+        if graph is not None:
+            graph.between = penalty
+            losses = graph(video_list, task_id=current_task_id, prev_out_cls_logits=prev)
+        else:
+            optimizer.zero_grad(set_to_none=True)
+            if reducer is not None:
+                reducer.begin()
+            losses = model(video_list, task_id=current_task_id, prev_out_cls_logits=prev)
+            losses['final_loss'].backward()
+            if reducer is not None:
+                reducer.finish()
+            penalty()
+            optimizer.step(clip_grad_l2norm=clip_grad_l2norm)
+        if last_pen[0] is not None:
+            losses['final_loss'] = losses['final_loss'].detach() + last_pen[0]
         scheduler.step()
         if model.use_adapt:
             model.post_train_step()
-        history.append({k: v.detach() for k, v in losses.items()})
+        if keep_history:
+            history.append({k: v.detach() for k, v in losses.items()})
         if iter_idx != 0 and iter_idx % print_freq == 0 and logger is not None:
             for k, v in losses.items():
                 tracker.setdefault(k, AverageMeter()).update(float(v))
