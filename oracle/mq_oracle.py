@@ -599,6 +599,31 @@ def cl_penalty(named_params, importance_list, optpar_list, lam):
     return total
 
 
+def cl_distill(out_cls_logits, prev_out_cls_logits, n_known, cl_name, n_classes):
+    """the distillation term iCaRL / BiC add to final_loss when n_known > 0 (meta_archs.py:1482-1519).
+    out_cls_logits: list over pyramid levels of [B, T_l, ncls] logits; prev_out_cls_logits: what train_cl.py:226-235
+    cached for the batch's clips -- a list over clips of lists over levels of [T_l, ncls_prev] sigmoid outputs (numpy in
+    the reference).  Only clip 0 of the batch and the first cached clip enter (`out_cls_logits_i[0, ...]`,
+    `prev_out_cls_logits[0]`): kept as is.
+      bic  : 0.01 * n_known / n_classes * mean_t( -sum_c prev[t, c] * log_softmax(logits[0, t, :n_known] / 2)[c] ) per level
+      icarl: 0.01 * sum_{y < n_known} BCEWithLogits(logits[0, :, y], prev[:, y]) per level"""
+    len_f = len(out_cls_logits)
+    prev = prev_out_cls_logits
+    total = 0.0
+    for i in range(len_f):
+        cur = out_cls_logits[i]
+        if cl_name == 'bic':
+            pv = torch.as_tensor(prev[i]).to(cur.dtype)
+            logp = F.log_softmax(cur[0, :, :n_known] / 2, dim=1)
+            total = total + 0.01 * (n_known / n_classes) * -torch.mean(torch.sum(pv[:, :n_known] * logp, dim=1))
+        else:
+            if len(prev) != len_f or len(prev) == 1:          # a list over clips: take the first clip's levels (:1505-1506)
+                prev = prev[0]
+            pv = torch.as_tensor(prev[i]).to(cur.dtype)
+            total = total + 0.01 * sum(F.binary_cross_entropy_with_logits(cur[0, :, y], pv[:, y]) for y in range(n_known))
+    return total
+
+
 def bic_correct(logits, splits, alphas, betas):
     """BiC bias layers on class-range slices of the logits (meta_archs.py:823-836); logits [..., ncls]."""
     parts, lo = [], 0

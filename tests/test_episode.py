@@ -224,3 +224,98 @@ def test_episode_reproduces_reference(dev):
             opt = make_optimizer(model, cfg['opt'])
             sch = make_scheduler(opt, cfg['opt'], len(cases.episode_batches(1)))
             model.train()
+
+
+@pytest.mark.gpu
+def test_single_part_weight_gradients_vs_fp64_oracle(dev):
+    """The arithmetic the benchmark runs: weight-gradient products whose contraction spans >= 2048 tokens use the leading
+    fp16 part of both operands (ops.dw_precision = 4, one MFMA per product).  The episode case has B * T = 2 * 1024 = 2048
+    rows, so its first iteration takes that path in every Linear / 1x1-conv layer of the stem and the XLNet layer: every
+    gradient against the float64 ORACLE at the 1e-3 bar of the north star (not against the HIP path's own 3-MFMA result)."""
+    from oracle import mq_oracle
+    from vilco_amd import ops
+    gold = load_episode_golden()
+    cfg, model = _build(gold, dev)
+    model.train()
+    assert ops.dw_precision == 4 and ops.DW_FAST_MIN_K <= 2048 and ops.get_precision() == 3
+    fast = []
+    real = ops.gemm
+
+    def spy(A, B, Cc, M, N, K, *a, **k):
+        if k.get("precision") == 4:
+            fast.append((M, N, K))
+        return real(A, B, Cc, M, N, K, *a, **k)
+    ops.gemm = spy
+    try:
+        vl = cases.episode_batches(0)[0]
+        losses = model(vl, task_id=0, is_training=True)
+        losses['final_loss'].backward()
+    finally:
+        ops.gemm = real
+    assert len(fast) >= 20 and all(K >= 2048 for _, _, K in fast), fast[:5]
+    p = {k: (v.double() if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point())
+         for k, v in episode_full_state(gold['init_state']).items()}
+    vl64 = [{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()} for d in vl]
+    want, _ = mq_oracle.forward_losses(p, cfg['model'], vl64, task_id=0, n_known=0)
+    want['final_loss'].backward()
+    for k in ('cls_loss', 'reg_loss', 'al_loss', 'final_loss'):
+        assert rel_err(losses[k], want[k]) < 1e-3, (k, float(losses[k]), float(want[k]))
+    errs = []
+    for k, q in model.named_parameters():
+        if p[k].grad is not None and q.grad is not None and not k.endswith(NOISE_GRADS):
+            errs.append((rel_err(q.grad, p[k].grad, GRAD_FLOOR), k))
+    errs.sort(reverse=True)
+    assert len(errs) > 250 and errs[0][0] < 1e-3, errs[:6]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_run_episodes_end_to_end(dev, tmp_path, use_graph):
+    """vilco_amd.train_cl.run_episodes itself over the two-task stream (MQ/train_cl.py:206-389): initial / in-epoch / final
+    validation calls, best-checkpoint files with the reference's keys (:300-307), the memory pickle (:355-361), the
+    best-checkpoint reload (:363; here the best epoch is NOT the last, so the reload changes the weights), class-head
+    growth and a new optimizer for task 1 -- eager and replayed as hipGraphs."""
+    import pickle
+    from vilco_amd.train_cl import run_episodes
+    from vilco_amd.utils.cl_stream import InMemoryQILStream
+    gold = load_episode_golden()
+    cfg, model = _build(gold, dev)
+    cfg = dict(cfg, opt=dict(cfg['opt'], epochs=2, warmup_epochs=1))            # 3 epochs per task, validation from epoch 1
+    cfg['cl_cfg'] = dict(cfg['cl_cfg'], path_memory='memory.pkl')
+    stream = InMemoryQILStream([_task_data(0), _task_data(1)], batch_size=2, seed=3)
+    random.seed(0)
+    calls, snaps = [], {}
+
+    def validate(m, epoch, task):
+        calls.append((task, epoch))
+        # epoch 1 scores best: the checkpoint written then must be what the task ends with
+        if len([c for c in calls if c[0] == task]) == 2:          # (first call of a task is the incoming-model validation)
+            snaps[task] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            return 1.0
+        return 0.1
+    folder = str(tmp_path)
+    model, opt, sch, log = run_episodes(cfg, model, stream, validate=validate, ckpt_folder=folder, gpu_id=0,
+                                        use_graph=use_graph, keep_history=True)
+    assert [t for t, _ in calls] == [0] * 4 + [1] * 4 and [e for _, e in calls] == [0, 1, 2, 2, 0, 1, 2, 2], calls
+    assert [e['best_epoch'] for e in log] == [1, 1] and [e['best_metric'] for e in log] == [1.0, 1.0]
+    for task in (0, 1):
+        ck = torch.load(os.path.join(folder, 'best_task_%03d_performance.pth.tar' % task), weights_only=False)
+        assert sorted(ck) == ['epoch', 'optimizer', 'reg_params', 'scheduler', 'state_dict', 'task']
+        assert ck['task'] == task and ck['epoch'] == 1
+        assert sorted(ck['optimizer']) == ['param_groups', 'state'] and len(ck['optimizer']['param_groups']) == 3
+        steps = {float(s['step']) for s in ck['optimizer']['state'].values()}
+        n_it = len(log[task]['history'][0])
+        assert min(steps) == 2 * n_it, (steps, n_it)             # two epochs of updates at the time of the checkpoint
+        for k, v in snaps[task].items():
+            assert torch.equal(ck['state_dict'][k].to(dev), v), k
+    # the model the run ends with is task 1's BEST state (epoch 1), not its last epoch's
+    sd = model.state_dict()
+    assert all(torch.equal(sd[k], v) for k, v in snaps[1].items())
+    with open(os.path.join(folder, 'memory.pkl'), 'rb') as h:
+        mem = pickle.load(h)
+    assert sorted(mem) == sorted(model.memory) and model.n_known == len(mem) == cases.EP_NCLS0 + cases.EP_NEW
+    assert all(len(v) <= max(1, cfg['cl_cfg']['memory_size'] // model.cls_head.cls_head.conv.out_channels) for v in mem.values())
+    assert model.cls_head.cls_head.conv.out_channels == cases.EP_NCLS0 + cases.EP_NEW
+    hist = [h for e in log for ep in e['history'] for h in ep]
+    assert len(hist) == 3 * (len(log[0]['history'][0]) + len(log[1]['history'][0]))
+    assert all(bool(torch.isfinite(h['final_loss'])) for h in hist)

@@ -150,3 +150,50 @@ def test_single_part_weight_gradients_at_full_size(dev):
     errs = sorted((((g1[k] - g2[k]).abs().max() / g2[k].abs().max().clamp_min(1e-7)).item(), k) for k in g1)
     assert errs[-1][0] < 5e-4, errs[-5:]          # measured: 3.5e-4 worst (branch.0 key.weight), 2e-4 typical
     assert sum(1 for e, _ in errs if e > 0) > 30          # the fast mode is actually in use (48 weight tensors at P)
+
+
+def test_p_config_train_step_vs_fp32_oracle_with_replayed_masks(dev):
+    """ONE full-size step of the benchmark workload itself -- config P, two clips, train mode with dropout 0.1 /
+    stochastic depth 0.1 / XLNet dropout 0.1, the single-part weight-gradient products active -- against the fp32 oracle
+    (the CPU restatement of the reference, ~15-30 s on the GPU box's host cores) replaying exactly the masks and
+    stochastic-depth factors the HIP path drew: losses and EVERY parameter gradient at the north star's 1e-3."""
+    import bench
+    import vilco_amd.modeling as vm
+    from oracle import mq_oracle
+    from vilco_amd import ops
+    cfg = bench.p_config()
+    torch.manual_seed(0)
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet())).to(dev).train()
+    batch = bench.synth_batch(2, dev)
+    assert ops.dw_precision == 4 and ops.get_precision() == 3
+    ops.dropout_log = []
+    try:
+        losses = model(batch, is_training=True)
+        losses['final_loss'].backward()
+        log = list(ops.dropout_log)
+    finally:
+        ops.dropout_log = None
+    torch.cuda.synchronize()
+    got = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    got_losses = {k: float(v) for k, v in losses.items()}
+    p = {k: (v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())) for k, v in model.state_dict().items()}
+    del model, losses
+    torch.cuda.empty_cache()
+    vl = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d.items()} for d in batch]
+    ctx = mq_oracle.DropReplay(log, lambda pr, seed, shape: ops.dropout_mask(pr, seed, shape, dev).cpu())
+    mq_oracle.DROP = ctx
+    try:
+        want, _ = mq_oracle.forward_losses(p, cfg, vl)
+        want['final_loss'].backward()
+    finally:
+        mq_oracle.DROP = None
+    assert ctx.leftover() == {}, ctx.leftover()
+    for k in ('cls_loss', 'reg_loss', 'final_loss'):
+        assert abs(got_losses[k] - float(want[k])) <= 1e-3 * abs(float(want[k])), (k, got_losses[k], float(want[k]))
+    errs = []
+    for k, g in got.items():
+        if p[k].grad is not None and not k.endswith(('key_norm.bias', '.key.bias')):     # analytically zero (softmax shift)
+            w = p[k].grad
+            errs.append((((g - w).abs().max() / w.abs().max().clamp_min(1e-7)).item(), k))
+    errs.sort(reverse=True)
+    assert len(errs) > 300 and errs[0][0] < 1e-3, errs[:8]

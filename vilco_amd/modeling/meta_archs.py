@@ -31,6 +31,12 @@ def normal_distribution(x, mu=0, sigma=1):
     return (-(x - mu) ** 2 / (2 * sigma ** 2)).exp()
 
 
+def _as_device(x, device):
+    """cached distillation targets: device tensors as train_cl.cache_prev_logits keeps them here, or the reference's
+    numpy arrays (train_cl.py:226-235)"""
+    return x.to(device) if torch.is_tensor(x) else torch.from_numpy(x).to(device)
+
+
 class BiasLayer(nn.Module):
     """BiC bias-correction layer (meta_archs.py:26-36)."""
 
@@ -876,7 +882,7 @@ class PtTransformer(nn.Module):
             n_classes = self.cls_head.cls_head.conv.out_channels
             alpha, temp, dist_loss = self.n_known / n_classes, 2, 0
             for cur, prev in zip(out_cls_logits, prev_out_cls_logits):
-                prev = torch.from_numpy(prev).to(cur.device)
+                prev = _as_device(prev, cur.device)
                 logp = F.log_softmax(cur[0, :, :self.n_known] / temp, dim=1)
                 dist_loss = dist_loss + 0.01 * alpha * -torch.mean(torch.sum(prev[:, :self.n_known] * logp, dim=1))
             final_loss = final_loss + dist_loss
@@ -886,7 +892,7 @@ class PtTransformer(nn.Module):
             for i in range(len_f):
                 if len(prev_out_cls_logits) != len_f or len(prev_out_cls_logits) == 1:
                     prev_out_cls_logits = prev_out_cls_logits[0]
-                prev = torch.from_numpy(prev_out_cls_logits[i]).to(out_cls_logits[i].device)
+                prev = _as_device(prev_out_cls_logits[i], out_cls_logits[i].device)
                 dist_loss = dist_loss + 0.01 * sum(self.dist_loss(out_cls_logits[i][0, :, y], prev[:, y])
                                                    for y in range(self.n_known))
             final_loss = final_loss + dist_loss

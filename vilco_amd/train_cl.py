@@ -46,13 +46,17 @@ def memory_quota(memory_size, n_classes):
 
 
 @torch.no_grad()
-def cache_prev_logits(model, loader, task_id):
-    """{video_id: [sigmoid(cls logits) per pyramid level as numpy]} of the incoming model (train_cl.py:226-235)"""
+def cache_prev_logits(model, loader, task_id, as_numpy=False):
+    """{video_id: [sigmoid(cls logits) per pyramid level]} of the incoming model (train_cl.py:226-235): the distillation
+    targets of iCaRL / BiC.  They stay ON THE DEVICE (one small tensor per level and clip; the reference round-trips them
+    through numpy and uploads them again in every iteration, meta_archs.py:1492,1508); as_numpy=True gives the
+    reference's format."""
     out = {}
     for video_list in loader:
         cls_logits, _, _ = model(video_list, task_id=task_id, get_emb=True)
         for i, v in enumerate(video_list):
-            out[v['video_id']] = [np.array(torch.sigmoid(lvl[i]).cpu().numpy()) for lvl in cls_logits]
+            probs = [torch.sigmoid(lvl[i]).clone() for lvl in cls_logits]
+            out[v['video_id']] = [np.array(t.cpu().numpy()) for t in probs] if as_numpy else probs
     return out
 
 
