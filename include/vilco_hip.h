@@ -123,6 +123,10 @@ int vilco_gemm(const vilco_gemm_desc* d, void* stream);
 /* Tuning override: force the tile height (128 | 192 | 256; 0 = cost model) and split-K count (0 = heuristic) of every
  * following vilco_gemm in this process.  Initial values: environment VILCO_GEMM_BM / VILCO_GEMM_KS, read once. */
 int vilco_gemm_force(int32_t bm, int32_t ks);
+/* Split-K finish of every following vilco_gemm: 1 = inside the launch (the last-arriving split workgroup of a tile sums
+ * the partial accumulators in split order and runs the epilogue), 0 = fp32 slabs + a reduce launch (default: measured
+ * faster, gemm.hip).  Same summation order either way.  Initial value: environment VILCO_GEMM_FIXUP=1 enables. */
+int vilco_gemm_set_fixup(int32_t on);
 /* floats written to desc->amax_out by vilco_gemm(desc) (depends on the tile / split-K plan); 0: not available */
 int32_t vilco_gemm_amax_parts(const vilco_gemm_desc* desc);
 int vilco_gemm_profile_begin(void);

@@ -585,3 +585,42 @@ def test_gemm_output_amax_partials(dev, M, N, K, act):
     assert ops.pack(C, M, N) is planes
     C.mul_(2.0)
     assert ops._amax_of(C)[0] is None and ops.pack(C, M, N) is not planes
+
+
+@pytest.mark.parametrize("M,N,K,form", [(154, 1024, 1024, "nt"), (154, 1024, 4096, "nt"), (288, 1024, 1024, "nn"), (1024, 1024, 4608, "tn"),
+                                        (77, 333, 2000, "nt"), (1152, 1024, 4096, "nn"), (130, 64, 640, "tn")])
+def test_split_k_fixup_equals_reduce_kernel(dev, M, N, K, form):
+    """split-K problems finished inside the launch (the tile's last-arriving workgroup sums the partial accumulators in
+    split order: vilco_gemm_set_fixup(1)) against the fp32-slab + splitk_reduce_kernel form: bit for bit,
+    with bias / activation / row mask / amax partials in the epilogue, and repeatable (the counters reset themselves)."""
+    from vilco_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(M + K)
+    if form == "nt":
+        A, B, a_kc, b_kc, lda, ldb = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), 1, 1, K, K
+        want = A.double() @ B.double().t()
+    elif form == "nn":
+        A, B, a_kc, b_kc, lda, ldb = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev), 1, 0, K, N
+        want = A.double() @ B.double()
+    else:
+        A, B, a_kc, b_kc, lda, ldb = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev), 0, 0, M, N
+        want = A.double().t() @ B.double()
+    bias = torch.randn(N, device=dev)
+    lens = torch.tensor([M - 3], dtype=torch.int32, device=dev)
+    outs = []
+    try:
+        for mode in (0, 1, 1, 1):
+            _lib.check(lib.vilco_gemm_set_fixup(mode))
+            C = torch.full((M, N), float('nan'), device=dev)
+            pre = torch.empty_like(C)
+            ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N, bias=bias, preact=pre, act=2, row_len=lens, rowT=M, want_amax=True)
+            parts, n = ops._amax_of(C)
+            outs.append((C, pre, float(parts[:n].max()) if parts is not None else None))
+    finally:
+        _lib.check(lib.vilco_gemm_set_fixup(0))
+    ref = torch.nn.functional.gelu(want + bias.double())
+    ref[M - 3:] = 0
+    assert rel(outs[0][0], ref) < 4e-6
+    for C, pre, am in outs[1:]:
+        assert torch.equal(C, outs[0][0]) and torch.equal(pre, outs[0][1])
+        assert am == float(C.abs().max()) == outs[0][2]

@@ -17,6 +17,7 @@
 // 3 = two fp16 parts of the per-tensor scaled operands ("f16x2": 22 bits, 3 MFMAs; pack.h; the default).
 // Reference arithmetic replaced: see include/vilco_hip.h (vilco_gemm).
 #include <cstdlib>
+#include <mutex>
 #include <utility>
 #include <vector>
 #include "common.h"
@@ -69,6 +70,7 @@ struct GArgs {
   int tiles_n, ntiles;
   int ksplit, kchunk;   // kchunk = K-steps per split
   long split_stride;    // elements between split slabs
+  unsigned* tile_ctr;   // split-K fix-up: arrival counter per (batch, tile); null = partial slabs + splitk_reduce_kernel
   const float* inv_a;       // fp16 x2 format: {1/s, s} of each operand, left by the pack kernels
   const float* inv_b;
   int vec_out;              // N, ldc, batch strides multiples of 4 and every epilogue pointer 16-byte aligned
@@ -183,6 +185,25 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* p, int rs4) {     // row
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + rs4));
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// Split-K fix-up inside the launch.  Every split workgroup stores its accumulators -- in their REGISTER layout, one
+// 16-byte piece per lane and 16 x 16 block, 1 KB per wave instruction -- to its slot of the workspace with `sc1`
+// (write-through) stores, waits for them, and one lane bumps the tile's arrival counter (agent-scope atomic).  The
+// workgroup whose add came last (it learns so from the value the add returned) loads the other splits' pieces with
+// `sc1` loads, sums them IN SPLIT ORDER (its own piece from registers: the result does not depend on who was last, and
+// equals what splitk_reduce_kernel computes, bit for bit), resets the counter and runs the ordinary epilogue.  This is
+// the hand-off row "one lane of each storing workgroup adds to ONE counter / the workgroup whose add came last" of
+// MI355X_MICROARCH.md (stores and loads all sc1, 16 bytes).  No second launch, no fp32 slab in the output's layout.
+__device__ __forceinline__ void st_sc1(f32x4* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ld_sc1(f32x4& v, const f32x4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
+// the loads above are invisible to the compiler's vmcnt bookkeeping: wait here, and tie the four registers to the wait
+__device__ __forceinline__ void wait_sc1(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 
 template <int BM, int NP, bool F16, bool AKM, bool BKM>
@@ -432,7 +453,50 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   // the stores / residual loads are 16 bytes per lane, 256 contiguous bytes per row, instead of 4-byte scatters
   // (measured before: 24k of a 112k-cycle block at K = 1024).
   const long coff = zo * g.sCo + zi * g.sCi;
-  const bool partial = g.ksplit > 1;
+  if (g.ksplit > 1 && g.tile_ctr) {
+    __shared__ unsigned arrived;
+    constexpr long PIECES = MI * 4 * 64;                        // f32x4 pieces per wave
+    const long tile = (long)blockIdx.z * g.ntiles + bid;
+    f32x4* mine = reinterpret_cast<f32x4*>(g.c) + ((tile * g.ksplit + ks) * 8 + wave) * PIECES + lane;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st_sc1(mine + (i * 4 + j) * 64, acc[i][j]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave, before the barrier the signal is behind
+    __syncthreads();
+    if (tid == 0) arrived = __hip_atomic_fetch_add(g.tile_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (arrived != (unsigned)(g.ksplit - 1)) return;
+    if (tid == 0) __hip_atomic_store(g.tile_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+    const f32x4* all = reinterpret_cast<const f32x4*>(g.c) + (tile * g.ksplit * 8 + wave) * PIECES + lane;
+    const long sstride = 8 * PIECES;
+    // every piece of one other split is requested before the first is used (one memory round trip per split, not per
+    // piece); two splits are in flight at a time.  The running sums start from split 0 and take the splits in order.
+    constexpr int NPC = MI * 4;
+    f32x4 sum[NPC];
+#pragma unroll
+    for (int q = 0; q < NPC; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < g.ksplit; s0 += 2) {
+      f32x4 va[NPC], vb[NPC];
+      const bool ha = s0 != ks, hb = s0 + 1 < g.ksplit && s0 + 1 != ks;
+#pragma unroll
+      for (int q = 0; q < NPC; ++q) {
+        va[q] = sum[q]; vb[q] = sum[q];
+        if (ha) ld_sc1(va[q], all + (long)s0 * sstride + q * 64);
+        if (hb) ld_sc1(vb[q], all + (long)(s0 + 1) * sstride + q * 64);
+      }
+#pragma unroll
+      for (int q = 0; q < NPC; q += 2) wait_sc1(va[q], va[q + 1], vb[q], vb[q + 1]);
+#pragma unroll
+      for (int q = 0; q < NPC; ++q) {
+        sum[q] += ha ? va[q] : acc[q / 4][q % 4];
+        if (s0 + 1 < g.ksplit) sum[q] += hb ? vb[q] : acc[q / 4][q % 4];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NPC; ++q) acc[q / 4][q % 4] = sum[q];
+  }
+  const bool partial = g.ksplit > 1 && !g.tile_ctr;
   float* cp = g.c + (partial ? (long)ks * g.split_stride : 0);
   float* stg = reinterpret_cast<float*>(smem_raw) + wave * (16 * EPI_LD);
   const int n = n0 + wn * 64 + (lane & 15) * 4;
@@ -474,7 +538,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
       float m = red[0];
 #pragma unroll
       for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
-      g.amax_out[((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m;
+      g.amax_out[(long)blockIdx.z * gridDim.x + blockIdx.x] = m;     // (split-K fix-up: one last arriver per tile)
     }
   }
   STAMPX(3);
@@ -562,7 +626,39 @@ struct Plan {
   int a_nbo, a_nbi, b_nbo, b_nbi;
   long a_bytes, b_bytes, part_bytes;
   long split_stride;
+  bool fixup;                     // split-K finished inside the launch (tile counters) instead of by splitk_reduce_kernel
 };
+
+// Arrival counters of the split-K fix-up: persistent, zero at load, reset by each tile's last arriver.  One region per
+// stream (launches of one stream are ordered; different streams may run GEMMs at the same time).
+constexpr int FIX_TILES = 4096, FIX_STREAMS = 32;
+__device__ unsigned vilco_tile_counters[FIX_STREAMS * FIX_TILES];
+// Default OFF.  Measured on MI355X (r03, same box, hipGraph replay of the whole step; tools/fixup_ab.sh): config P
+// 27.49 ms with the fix-up against 27.59 ms with the reduce launch (noise), the T = 256 configuration 10.97 ms against
+// 10.43 ms.  The chain sc1 stores -> vmcnt(0) -> atomic round trip -> sc1 loads costs the last arriver ~6 us, a dependent
+// second launch ~5 us: device-scope hand-offs go through the memory side of the 8 XCDs (DESIGN.md 3.6 found the same for
+// grid barriers).  Kept (tested bit-exact against the reduce kernel) behind VILCO_GEMM_FIXUP=1 / vilco_gemm_set_fixup.
+inline bool& fixup_enabled() {
+  static bool on = [] { const char* e = getenv("VILCO_GEMM_FIXUP"); return e && e[0] == '1'; }();
+  return on;
+}
+unsigned* tile_counters(hipStream_t s) {
+  static std::mutex mu;
+  static hipStream_t streams[FIX_STREAMS];
+  static int n = 0;
+  static unsigned* base = nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!base) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(vilco_tile_counters)) != hipSuccess || !q) return nullptr;
+    base = reinterpret_cast<unsigned*>(q);
+  }
+  for (int i = 0; i < n; ++i)
+    if (streams[i] == s) return base + (long)i * FIX_TILES;
+  if (n >= FIX_STREAMS) return nullptr;
+  streams[n] = s;
+  return base + (long)(n++) * FIX_TILES;
+}
 
 void make_plan(const vilco_gemm_desc* d, Plan& p) {
   p.NP = d->precision == 1 ? 1 : ((d->precision == 0 || d->precision == 3 || d->precision == 4) ? 2 : 3);
@@ -660,6 +756,14 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   }
   p.split_stride = out_span;
   p.part_bytes = p.ksplit > 1 ? align_up(out_span * p.ksplit * 4, 256) : 0;
+  p.fixup = false;
+  if (p.ksplit > 1 && fixup_enabled()) {
+    const long ntiles = tn * ((d->M + p.BM - 1) / p.BM) * nbatch;
+    if (ntiles <= FIX_TILES) {      // slots [tile][split] of BM x 128 floats in the accumulators' register layout
+      p.fixup = true;
+      p.part_bytes = align_up(ntiles * p.ksplit * (long)p.BM * BN * 4, 256);
+    }
+  }
 }
 
 template <int BM, int NP, bool F16, bool AKM, bool BKM>
@@ -708,7 +812,7 @@ ProfState& prof() { static ProfState p; return p; }
 // number of max|C| partials a vilco_gemm call with this descriptor writes to desc->amax_out (0: too many -- do not ask)
 static long amax_out_parts(const vilco_gemm_desc* d, const Plan& p) {
   const long nz = (long)d->batch_outer * d->batch_inner;
-  if (p.ksplit > 1) {
+  if (p.ksplit > 1 && !p.fixup) {
     long blocks = ((long)d->M * d->N * nz + 255) / 256;
     return blocks > 2048 ? 2048 : blocks;
   }
@@ -967,6 +1071,11 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
               vilco_aligned(d->residual, 16);
   g.c = p.ksplit > 1 ? parts : d->C;
   g.cfinal = d->C;
+  g.tile_ctr = nullptr;
+  if (p.fixup) {
+    g.tile_ctr = tile_counters(s);
+    if (!g.tile_ctr) return VILCO_ERR_UNSUPPORTED;      // more than FIX_STREAMS streams in one process
+  }
   g.amax_out = d->band == 1 ? nullptr : d->amax_out;
   g.e = Epi{d->alpha, d->beta, d->bias, d->preact, d->act, d->row_len, d->rowT, d->colscale, d->residual,
             d->res_masked};
@@ -1000,7 +1109,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     prof().ev.emplace_back(ev0, ev1);
     prof().rec.push_back(ProfRec{{d->M, d->N, d->K, nz, p.BM, p.ksplit, d->precision, p.a_km, p.b_km, p.a_tap | (p.b_tap << 4)}});
   }
-  if (p.ksplit > 1) {
+  if (p.ksplit > 1 && !p.fixup) {
     long blocks = ((long)d->M * d->N * nz + 255) / 256;       // == amax_out_parts(): one max|C| partial per block, either form
     if (blocks > 2048) blocks = 2048;
     if (g.vec_out) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((int)blocks), dim3(256), 0, s, g, nz);
@@ -1012,6 +1121,13 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
 // tuning override (tools/gemm_tune.py): force the tile height (128 | 192 | 256; 0 = cost model) and the split-K count
 // (0 = heuristic) of every following vilco_gemm of this process; the environment variables VILCO_GEMM_BM / VILCO_GEMM_KS
 // give the initial values.
+// split-K finish: 1 = inside the launch (tile counters), 0 = partial slabs + splitk_reduce_kernel (default; see
+// fixup_enabled()).  Both sum the splits in the same order: the results are bitwise equal (tests/test_ops_gpu.py).
+extern "C" int vilco_gemm_set_fixup(int32_t on) {
+  fixup_enabled() = on != 0;
+  return VILCO_OK;
+}
+
 extern "C" int vilco_gemm_force(int32_t bm, int32_t ks) {
   if (bm < 0 || ks < 0) return VILCO_ERR_BADARG;
   tune().bm = bm; tune().ks = ks;
