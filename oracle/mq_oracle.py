@@ -624,6 +624,68 @@ def cl_distill(out_cls_logits, prev_out_cls_logits, n_known, cl_name, n_classes)
     return total
 
 
+@torch.no_grad()
+def icarl_exemplar_means(p, cfg, memory, batches_of):
+    """class means of the exemplars' pyramid features, meta_archs.py:1067-1096 (`classify`, compute_means branch).
+    memory: {class_id: [clips]} in insertion order; batches_of(data_class) = cilsettask.get_dataloader(data_class,
+    sample_frame=True) -> iterable of one-clip batches.  Every clip's level-l feature map [1, C, T_l] is divided by its
+    Frobenius norm (padding included), averaged over the class's exemplars and normalised again.
+    -> list over levels of [n_classes, C, T_l]."""
+    means = None
+    for class_id, videos in memory.items():
+        per_level = None
+        for video_list in batches_of({class_id: videos}):
+            feats = forward_network(p, cfg, video_list, training=False)[0]
+            f = [x / x.norm() for x in feats]
+            per_level = [[a] for a in f] if per_level is None else [l + [a] for l, a in zip(per_level, f)]
+        mus = []
+        for lvl in per_level:
+            mu = torch.stack(lvl, dim=0).mean(0).squeeze()            # [C, T_l]
+            mus.append(mu / mu.norm())
+        means = [[m] for m in mus] if means is None else [l + [m] for l, m in zip(means, mus)]
+    return [torch.stack(l, dim=0) for l in means]
+
+
+@torch.no_grad()
+def icarl_dists(p, cfg, means, clip):
+    """squared distance of every (level, position) feature of `clip` to every class mean, meta_archs.py:1098-1129:
+    list over levels of [1, T_l, n_classes]."""
+    feats = forward_network(p, cfg, [clip], training=False)[0]
+    out = []
+    for f, m in zip(feats, means):
+        fn = (f / f.norm()).unsqueeze(3)                               # [1, C, T_l, 1]
+        d = (fn - m.permute(1, 2, 0).unsqueeze(0)).pow(2).sum(1).squeeze()
+        out.append(d.unsqueeze(0) if d.dim() == 2 else d)
+    return out
+
+
+@torch.no_grad()
+def decode_single_video_icarl(cfg, pts, masks, cls_logits, offsets, dists):
+    """inference_single_video with iCaRL's class distances (meta_archs.py:1626-1643, then the common tail :1663-1692):
+    candidates are the (position, class) pairs closer to their class mean than the level's average distance, ranked by
+    distance.  The rank indices address the UNFILTERED distance array but are applied to the filtered candidates (:1641-
+    1642); when they would run past the end the reference keeps every candidate (:1637-1640).  Kept as is."""
+    tc = cfg['test_cfg']
+    segs, scores, labels = [], [], []
+    for cls_i, off_i, pts_i, m_i, d_i in zip(cls_logits, offsets, pts, masks, dists):
+        prob = (cls_i.sigmoid() * m_i.unsqueeze(-1)).flatten()
+        d = d_i.flatten()
+        keep = d < d.mean()
+        prob, idx = prob[keep], keep.nonzero(as_tuple=True)[0]
+        k = min(tc['pre_nms_topk'], idx.size(0))
+        order = d.sort(descending=False)[1]
+        if not order[:k].max() > prob.shape[0]:
+            prob, idx = prob[order[:k]].clone(), idx[order[:k]].clone()
+        pt = torch.div(idx, cfg['num_classes'], rounding_mode='floor')
+        offs, pp = off_i[pt], pts_i[pt]
+        left, right = pp[:, 0] - offs[:, 0] * pp[:, 3], pp[:, 0] + offs[:, 1] * pp[:, 3]
+        ok = (right - left) > tc['duration_thresh']
+        segs.append(torch.stack((left, right), -1)[ok])
+        scores.append(prob[ok])
+        labels.append(torch.fmod(idx, cfg['num_classes'])[ok])
+    return torch.cat(segs), torch.cat(scores), torch.cat(labels)
+
+
 def bic_correct(logits, splits, alphas, betas):
     """BiC bias layers on class-range slices of the logits (meta_archs.py:823-836); logits [..., ncls]."""
     parts, lo = [], 0

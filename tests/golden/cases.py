@@ -201,3 +201,34 @@ def nlq_model_batch():
                     'one_hot_labels': torch.ones(len(segs), 1), 'fps': 30.0, 'duration': 60.0 + i,
                     'feat_stride': 16.043, 'feat_num_frames': 16.043})
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# iCaRL case: the reference's `classify` (meta_archs.py:1061-1131) only runs on a 10-level pyramid (fpn_levels = 10 is
+# hard-coded there), and matches class-distance rows with class logits by flat index, i.e. needs one exemplar class per
+# output class.
+IC_T, IC_D, IC_CIN, IC_CTXT, IC_NCLS = 1024, 32, 40, 24, 4
+
+
+def icarl_overrides():
+    o = overrides(D=IC_D, T=IC_T, Cin=IC_CIN, Ctxt=IC_CTXT, H=4, use_xl=False, droppath=0.0, cl=dict(name='icarl'))
+    o['dataset']['num_classes'] = IC_NCLS
+    o['model']['backbone_arch'] = (2, 2, 9)
+    o['model']['regression_range'] = [(0, 4), (4, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 256), (256, 512),
+                                      (512, 1024), (1024, 10000)]
+    o['test_cfg'] = dict(o['test_cfg'], pre_nms_topk=300)
+    return o
+
+
+def icarl_clip(idx, labels=(0, 1)):
+    g = torch.Generator().manual_seed(9000 + idx)
+    t = IC_T - 31 * (idx % 3)
+    return {'video_id': 'ic%d' % idx, 'feats': torch.randn(IC_CIN, t, generator=g),
+            'segments': torch.tensor([[20.0 + idx % 7, 90.0], [200.5, 350.25]]), 'labels': torch.tensor(list(labels)),
+            'fps': 30.0, 'duration': 300.0, 'feat_stride': 16, 'feat_num_frames': 16,
+            'segmentation_labels': torch.zeros(t, IC_NCLS), 'prompt_feature': torch.randn(IC_CTXT, 7 + idx % 3, generator=g)}
+
+
+def icarl_memory():
+    """{class: [exemplar clips]}: two per class, insertion order = class order"""
+    return {c: [icarl_clip(10 * c + k, (c, (c + 1) % IC_NCLS)) for k in range(2)] for c in range(IC_NCLS)}

@@ -900,18 +900,63 @@ class PtTransformer(nn.Module):
         out['final_loss'] = final_loss
         return out
 
+    # ------------------------------------------------------------------ iCaRL nearest-exemplar-mean classification
+    @torch.no_grad()
+    def _pyramid_features(self, video_list):
+        """backbone + neck of an inference batch (one clip): list over levels of token-major [1, T_l, C]"""
+        inp = self.prepare(video_list, is_training=False)
+        x_tm = ops.transpose(inp.feats_cf)
+        text_tm = text_lens = None
+        if self.use_cross_modal:
+            text_tm, text_lens = ops.transpose(inp.text_cf), inp.text_lens
+            if hasattr(self, 'prompt'):
+                text_tm = self.prompt(text_tm, prompt_mask=None, cls_features=None)['prompted_embedding'].contiguous()
+        feats, all_lens = self.backbone.forward_tm(x_tm, inp.lens, text_tm, text_lens)
+        return self.neck.forward_tm(feats, all_lens)[0]
+
+    @torch.no_grad()
+    def classify(self, x, cilsettask):
+        """iCaRL's classifier (meta_archs.py:1061-1131): squared distances between the clip's normalised pyramid features
+        and the class means of the exemplars in `self.memory` -> list over levels of [1, T_l, n_classes].
+        The means are (re)computed while `compute_means` is set (`cilsettask.get_dataloader({class: clips},
+        sample_frame=True)` yields the exemplars as one-clip batches): each exemplar's level-l map is divided by its
+        Frobenius norm, the maps are averaged per class and normalised again.
+        One difference: the reference hard-codes `fpn_levels = 10` (:1065) and therefore fails on any other pyramid
+        depth (the shipped (2, 2, 5) architectures have 6 levels); the level count is taken from the model here.  On a
+        10-level model the outputs equal the reference's (tests/test_icarl.py)."""
+        if self.compute_means:
+            means = None
+            for class_id, videos in self.memory.items():
+                per_level = None
+                for video_list in cilsettask.get_dataloader({class_id: videos}, sample_frame=True):
+                    f = [t / t.norm() for t in self._pyramid_features(video_list)]
+                    per_level = [[a] for a in f] if per_level is None else [l + [a] for l, a in zip(per_level, f)]
+                mus = []
+                for lvl in per_level:
+                    mu = torch.stack(lvl, dim=0).mean(0)[0]               # [T_l, C]
+                    mus.append(mu / mu.norm())
+                means = [[m] for m in mus] if means is None else [l + [m] for l, m in zip(means, mus)]
+            self.exemplar_means = [torch.stack(l, dim=0) for l in means]          # per level [n_classes, T_l, C]
+            self.compute_means = False
+        dists = []
+        for f, m in zip(self._pyramid_features([x]), self.exemplar_means):
+            fn = f / f.norm()                                                      # [1, T_l, C]
+            dists.append((fn.unsqueeze(1) - m.unsqueeze(0)).pow(2).sum(-1).permute(0, 2, 1).contiguous())   # [1, T_l, n_cls]
+        return dists
+
     # ------------------------------------------------------------------ inference
     @torch.no_grad()
     def inference(self, video_list, points, fpn_masks, out_cls_logits, out_offsets, out_lb_logits,
                   out_rb_logits, cilsettask=None):
-        if cilsettask is not None and self.compute_means:
-            raise NotImplementedError("the iCaRL nearest-exemplar-mean classifier (meta_archs.py:1061-1131) "
-                                      "is not on the ViLCo path (SURVEY.md 8f-3)")
         results = []
         for idx, vl in enumerate(video_list):
+            # final validation of an iCaRL run (meta_archs.py:1561-1562): class distances of this clip.  `classify`
+            # clears compute_means once the exemplar means exist, so -- as in the reference -- only the first clip
+            # validated after training is decoded from distances; the following ones take the ordinary path.
+            cls_preds = self.classify(vl, cilsettask) if (cilsettask is not None and self.compute_means) else None
             r = self.inference_single_video(points, [x[idx] for x in fpn_masks],
                                             [x[idx] for x in out_cls_logits], [x[idx] for x in out_offsets],
-                                            None, None)
+                                            None, None, cls_preds_per_vid=cls_preds)
             for k_out, k_in in (('video_id', 'video_id'), ('fps', 'fps'), ('duration', 'duration'),
                                 ('feat_stride', 'feat_stride'), ('feat_num_frames', 'feat_num_frames')):
                 r[k_out] = vl[k_in]
@@ -924,7 +969,7 @@ class PtTransformer(nn.Module):
         """threshold -> top-k -> decode per level (meta_archs.py:1594-1692).  On the device the whole pyramid of the clip
         is one vilco_decode call (exact top-k by radix select, one host read: the candidate count); VILCO_DEVICE_DECODE=0
         or host tensors take the tensor-expression path below, which mirrors the reference line by line."""
-        if out_cls_logits[0].is_cuda and os.environ.get("VILCO_DEVICE_DECODE", "1") != "0":
+        if cls_preds_per_vid is None and out_cls_logits[0].is_cuda and os.environ.get("VILCO_DEVICE_DECODE", "1") != "0":
             lens = [int(c.shape[0]) for c in out_cls_logits]
             row0 = torch.tensor([sum(lens[:i]) for i in range(len(lens))], dtype=torch.int32, device=out_cls_logits[0].device)
             level_len = torch.stack([m.sum() for m in fpn_masks]).to(torch.int32)
@@ -933,15 +978,29 @@ class PtTransformer(nn.Module):
                                               self.test_pre_nms_thresh, self.test_duration_thresh)
             return {'segments': segs, 'scores': scores, 'labels': labels}
         segs_all, scores_all, cls_all = [], [], []
-        for cls_i, off_i, pts_i, mask_i in zip(out_cls_logits, out_offsets, points, fpn_masks):
+        for lvl, (cls_i, off_i, pts_i, mask_i) in enumerate(zip(out_cls_logits, out_offsets, points, fpn_masks)):
             prob = (cls_i.sigmoid() * mask_i.unsqueeze(-1)).flatten()
-            keep = prob > self.test_pre_nms_thresh
-            prob = prob[keep]
-            topk_idxs = keep.nonzero(as_tuple=True)[0]
-            num_topk = min(self.test_pre_nms_topk, topk_idxs.size(0))
-            prob, order = prob.sort(descending=True)
-            prob = prob[:num_topk].clone()
-            topk_idxs = topk_idxs[order[:num_topk]].clone()
+            if cls_preds_per_vid is not None:
+                # iCaRL (meta_archs.py:1626-1643): candidates = (position, class) pairs closer to their class mean than the
+                # level's average distance, ranked by distance.  The rank indices address the unfiltered distance array
+                # but are applied to the filtered candidates; when they would run past the end every candidate is kept.
+                dist = cls_preds_per_vid[lvl].flatten()
+                keep = dist < dist.mean()
+                prob = prob[keep]
+                topk_idxs = keep.nonzero(as_tuple=True)[0]
+                num_topk = min(self.test_pre_nms_topk, topk_idxs.size(0))
+                order = dist.sort(descending=False)[1]
+                if not bool(order[:num_topk].max() > prob.shape[0]):
+                    prob = prob[order[:num_topk]].clone()
+                    topk_idxs = topk_idxs[order[:num_topk]].clone()
+            else:
+                keep = prob > self.test_pre_nms_thresh
+                prob = prob[keep]
+                topk_idxs = keep.nonzero(as_tuple=True)[0]
+                num_topk = min(self.test_pre_nms_topk, topk_idxs.size(0))
+                prob, order = prob.sort(descending=True)
+                prob = prob[:num_topk].clone()
+                topk_idxs = topk_idxs[order[:num_topk]].clone()
             pt_idxs = torch.div(topk_idxs, self.num_classes, rounding_mode='floor')
             cls_idxs = torch.fmod(topk_idxs, self.num_classes)
             offs, pts = off_i[pt_idxs], pts_i[pt_idxs]
