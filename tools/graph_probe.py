@@ -47,7 +47,8 @@ def eager():
         p.grad = None
     return model(batch, is_training=True)['final_loss'].backward()
 
-print(name, "eager fwd+bwd: %.2f ms/step (host enqueue %.2f ms)" % timed(eager, steps), flush=True)
+if not os.environ.get("PROBE_SKIP_EAGER"):
+    print(name, "eager fwd+bwd: %.2f ms/step (host enqueue %.2f ms)" % timed(eager, steps), flush=True)
 if os.environ.get("PROBE_STAGES"):
     from vilco_amd import _lib
     import gc

@@ -140,6 +140,7 @@ class GraphedStep:
                 _lib.check(lib.vilco_seed_word_bump(ops._stream()))
                 losses = model.forward_prepared(static, None, task_id=task_id)
                 losses['final_loss'].backward()
+                ops.join_side_streams()          # forked chains (ops.fork_enabled) end here
                 keys = sorted(losses)
                 out = torch.stack([losses[k].detach().reshape(()).float() for k in keys])
         finally:

@@ -134,7 +134,7 @@ class ConvTransformerBackbone(nn.Module):
         side = None
         if self.use_cross_modal and text is not None:
             main = torch.cuda.current_stream()
-            side = _text_stream(x.device) if (_TEXT_STREAM and x.is_cuda) else None
+            side = _text_stream(x.device) if (x.is_cuda and (_TEXT_STREAM or ops.fork_enabled("text"))) else None
             if side is not None:
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):

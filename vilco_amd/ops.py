@@ -69,6 +69,66 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# ---- concurrency inside a captured step (vilco_amd/graph.py).  A replayed hipGraph has no host in the loop, so independent
+# chains can be forked onto side streams at capture time and the runtime overlaps them: the 77-token text branch under the
+# video stem, the regression head beside the classification head, and the weight-gradient products (nothing in backward
+# waits for them) beside the dX chain -- they fill the CUs that the 75 %-full GEMM rounds of this model's shapes leave
+# idle.  VILCO_GRAPH_STREAMS lists what is forked ("text,heads,dw"; "" = nothing); only active while a stream is capturing
+# (in eager mode a second queue made the step time erratic).
+_FORKS = set(x for x in os.environ.get("VILCO_GRAPH_STREAMS", "text,heads").split(",") if x)
+_side_streams = {}
+_dw_seen = set()
+
+
+def fork_enabled(what):
+    if not (what in _FORKS and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return False
+    cur = torch.cuda.current_stream()               # no nested forks: a chain already on a side stream stays on it
+    return all(st != cur for st in _side_streams.values())
+
+
+def side_stream(name, device=None):
+    dev = torch.cuda.current_device() if device is None else (device.index if device.index is not None else torch.cuda.current_device())
+    key = (name, dev)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
+
+def join_side_streams():
+    """make the current stream wait for everything forked so far (end of a captured backward)"""
+    cur = torch.cuda.current_stream()
+    for (name, dev), st in _side_streams.items():
+        if dev == cur.device_index:
+            cur.wait_stream(st)
+    _dw_seen.clear()
+
+
+class _DwFork:
+    """context for one weight-gradient product: on the "dw" side stream when forking is on and this weight has not been
+    seen in the current backward (a weight used twice accumulates its gradients on the main stream: keep those ordered)"""
+
+    def __init__(self, w):
+        self.on = fork_enabled("dw") and id(w) not in _dw_seen
+        if fork_enabled("dw"):
+            _dw_seen.add(id(w))
+        self.ctx = None
+
+    def __enter__(self):
+        if self.on:
+            cur = torch.cuda.current_stream()
+            st = side_stream("dw")
+            st.wait_stream(cur)
+            self.ctx = torch.cuda.stream(st)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+
 def _chk(*ts):
     for t in ts:
         if t is None:
@@ -406,8 +466,9 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=prec, a_planes=pz, b_planes=pw, want_amax=True)   # dX = dZ W     (NN)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(prec, M), a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
+            with _DwFork(w):
+                dw = torch.empty_like(w)
+                gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(prec, M), a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -464,8 +525,9 @@ class _LinearKN(torch.autograd.Function):
             dx = torch.empty_like(x)
             gemm(dy, w, dx, M, K, N, 1, 1, N, N, K, precision=prec, a_planes=pz, b_planes=pw)   # dX = dY W^T   (NT)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            gemm(x, dy, dw, K, N, M, 0, 0, K, N, N, precision=_dw_prec(prec, M), a_planes=px, b_planes=pz)   # dW = X^T dY   (TN)
+            with _DwFork(w):
+                dw = torch.empty_like(w)
+                gemm(x, dy, dw, K, N, M, 0, 0, K, N, N, precision=_dw_prec(prec, M), a_planes=px, b_planes=pz)   # dW = X^T dY   (TN)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy.view(M, N)).view(ctx.bshape)
         return dx, dw, db
@@ -529,10 +591,11 @@ class _Conv3(torch.autograd.Function):
             gemm(dz, wt, dx, B * T, Cin, 3 * Cout, 1, 1, Cout, 3 * Cout, Cin, tap=TAP_A, tapC=Cout,
                  tapT=T, b_planes=pwt, a_amax=_amax_of(dz))
         if ctx.needs_input_grad[1]:
-            dwp = torch.empty(Cout, 3 * Cin, dtype=torch.float32, device=x.device)
-            gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
-                 tapT=T, precision=_dw_prec(_precision, B * T), a_amax=_amax_of(dz), b_amax=_amax_of(x))
-            dw = permute3(dwp, (Cout, Cin, 3), 0, (3 * Cin, 1, Cin))
+            with _DwFork(w):
+                dwp = torch.empty(Cout, 3 * Cin, dtype=torch.float32, device=x.device)
+                gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
+                     tapT=T, precision=_dw_prec(_precision, B * T), a_amax=_amax_of(dz), b_amax=_amax_of(x))
+                dw = permute3(dwp, (Cout, Cin, 3), 0, (3 * Cin, 1, Cin))
         return dx, dw, db, None
 
 
