@@ -349,6 +349,28 @@ def main():
     ms = dt / args.steps * 1e3
     clips_per_s = world * args.batch * args.steps / dt
 
+    # Diagnostics of the gradient exchange (EVERY rank runs them: they contain collectives): each bucket's all-reduce
+    # alone, and the same step without the exchange -- what the exchange costs, and how much of it backward hides.
+    multi = None
+    if reducer is not None:
+        buckets = reducer.profile_buckets()
+        reducer.enabled = False
+        for _ in range(2):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step()
+        fence()
+        local_ms = (time.perf_counter() - t1) / 5 * 1e3
+        tot = sum(b["ms"] for b in buckets)
+        multi = {"buckets": buckets, "exchange_ms_sum_of_buckets_alone": tot, "ms_per_step_without_exchange": local_ms,
+                 "exposed_exchange_ms": ms - local_ms,
+                 "overlap_frac": (1.0 - max(ms - local_ms, 0.0) / tot) if tot > 0 else None,
+                 "gradient_bytes": sum(b["mb"] for b in buckets) * 2 ** 20,
+                 "note": "bucketed RCCL all-reduce (AVG) launched from autograd hooks as buckets complete; the weight-gradient "
+                         "kernels write into the bucket slots (no gather copy); busbw = algbw * 2 (n - 1) / n"}
+
     # Everything below is RANK-LOCAL (no collectives): rank 0 measures with the gradient exchange switched off while the
     # other ranks wait in the final barrier.  (Round 1 ran reducer steps on rank 0 only here, whose all-reduces had
     # no peer -- ADVICE r1.)
@@ -374,6 +396,8 @@ def main():
                          "42 MB batch, meta_archs.py:1178: ~1 ms on PCIe 5, not part of `value`)",
                "clips_per_s_per_gpu": clips_per_s / world,
                "model_mfma_frac": clips_per_s / world * GFLOP_PER_CLIP_FWD_BWD / 1e3 / PEAK_BF16_TFLOPS}
+        if multi is not None:
+            out["multi_gpu"] = multi
         if dry:
             step()                                               # a rank-local step: must not touch the process group
             out["dryrun"] = True

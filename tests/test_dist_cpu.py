@@ -88,6 +88,9 @@ def test_bench_protocol_two_ranks():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["dryrun"] is True
+    mg = out["multi_gpu"]                    # exchange diagnostics: per-bucket all-reduce time, step time without the exchange
+    assert len(mg["buckets"]) >= 1 and all(b["ms"] > 0 and b["mb"] > 0 for b in mg["buckets"])
+    assert mg["ms_per_step_without_exchange"] > 0 and mg["exchange_ms_sum_of_buckets_alone"] > 0
 
 
 class _FakeDetector(torch.nn.Module):

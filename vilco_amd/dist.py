@@ -9,11 +9,22 @@ VQ's `find_unused_parameters=True` DDP (VQ/train_cl.py:112-117) are what this mi
 tensors never get a gradient at arch (2,2,5), so the bucket plan is pruned statically after the first
 backward instead of searching the graph every step.
 
-Memory traffic: a finished gradient is copied ONCE into its slot of the bucket's flat buffer (the
-collective needs contiguous memory); after the all-reduce `p.grad` is re-pointed at that slot (a view, no
-copy back) and the average is taken by the collective itself (ReduceOp.AVG on RCCL; gloo has no AVG, so
-the CPU test path divides).  Kernels that produce weight gradients can ask `grad_slot(p)` for the slot and
-write there directly, which removes the remaining copy.
+Memory traffic: the weight-gradient products -- where the bytes are -- write straight INTO their slot of the
+bucket's flat buffer (`begin()` installs `grad_slot` as `ops.grad_slot_provider`; ops._grad_out), so the
+collective finds its input in place; the small gradients (biases, LayerNorm, scales) and any gradient autograd
+had to sum are copied into their slots by one multi-tensor copy per bucket.  After the all-reduce `p.grad` is a
+view of the slot (no copy back) and the average is taken by the collective itself (ReduceOp.AVG on RCCL; gloo
+has no AVG, so the CPU test path divides).
+
+Why bucketed all-reduce and not a hand-rolled reduce-scatter + all-gather: on the 8-GPU xGMI mesh every pair of
+GPUs has its own link, so the bandwidth-optimal exchange is direct -- each rank sends 1/8 of a bucket to each
+peer (reduce-scatter), sums, and sends its eighth back (all-gather): 2 x 7/8 of the bucket over 7 links in
+parallel, ~1.4 ms for the 843 MB of config P at ~150 GB/s per link, against ~9.6 ms for a one-link ring
+(SURVEY.md 5).  RCCL picks its algorithm per message size from the topology it detects; on a fully connected
+mesh it builds as many rings / trees as there are links, which reaches the same link-parallel bandwidth for
+64 MB buckets without our issuing 56 point-to-point transfers per bucket from Python.  `profile_buckets()`
+reports what a node actually delivers per bucket (bench.py prints it for N > 1), which is the number that
+decides whether a direct RS + AG is worth writing; this container has one GPU, so it has not been measured.
 
 Robustness (every rank must issue the same collectives in the same order):
   * the plan is built from the UNION over ranks of the gradient-bearing parameters (one MAX all-reduce of a
@@ -40,6 +51,7 @@ class GradReducer:
         self._hooks = []
         self._pending = []
         self._slot = {}              # id(param) -> (bucket index, view)
+        self._slot_by_ptr = {}       # param.data_ptr() -> (bucket index, view)
         self._handed = set()
         self._next = 0               # index of the next bucket to launch (strict order)
 
@@ -63,6 +75,7 @@ class GradReducer:
         for bi, b in enumerate(self.buckets):
             for p, v in zip(b["params"], b["views"]):
                 self._slot[id(p)] = (bi, v)
+                self._slot_by_ptr[p.data_ptr()] = (bi, v)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
     @staticmethod
@@ -82,11 +95,12 @@ class GradReducer:
         second gradient in ordinary memory and autograd sums the two)."""
         if not self.enabled or self.buckets is None:
             return None
-        s = self._slot.get(id(p))
-        if s is None or id(p) in self._handed:
+        key = p.data_ptr()           # (inside autograd the weight arrives as a saved-tensor alias: same memory, another object)
+        s = self._slot_by_ptr.get(key)
+        if s is None or key in self._handed or s[1].numel() != p.numel():
             return None
-        self._handed.add(id(p))
-        return s[1]
+        self._handed.add(key)
+        return s[1].view(p.shape)
 
     def _make_hook(self, bi):
         def hook(param):
@@ -120,6 +134,8 @@ class GradReducer:
 
     # -- per step ---------------------------------------------------------------------------
     def begin(self):
+        from . import ops
+        ops.grad_slot_provider = self.grad_slot if self.enabled else None      # dW kernels write into the bucket slots
         self._handed = set()
         self._next = 0
         if self.buckets is not None:
@@ -175,12 +191,39 @@ class GradReducer:
                     torch._foreach_copy_(dst, src)
         self._pending = []
 
+    def profile_buckets(self, iters=3):
+        """Every rank calls this (it issues collectives): each bucket's all-reduce alone, fenced by device syncs ->
+        [{"mb", "ms", "algbw_GBps", "busbw_GBps"}] (busbw = algbw * 2 (n - 1) / n, the ring convention).  For reading a
+        scaling run: the step's exchange cost is the sum of these minus what overlapped with backward."""
+        import time
+        if self.buckets is None:
+            return []
+        out = []
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        for b in self.buckets:
+            flat = b["flat"]
+            sync = (lambda: torch.cuda.synchronize(flat.device)) if flat.is_cuda else (lambda: None)
+            dist.all_reduce(flat, op=op, group=self.group)                 # warm the communicator for this size
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                dist.all_reduce(flat, op=op, group=self.group)
+            sync()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            mb = flat.numel() * flat.element_size() / 2 ** 20
+            alg = flat.numel() * flat.element_size() / (ms * 1e-3) / 1e9
+            out.append({"mb": mb, "ms": ms, "algbw_GBps": alg, "busbw_GBps": alg * 2 * (self.world - 1) / max(self.world, 1)})
+        return out
+
     def rebuild(self):
         """forget the plan (the set of trained parameters changed); the next `finish` builds a new one"""
         self.remove()
-        self.buckets, self._slot, self._pending = None, {}, []
+        self.buckets, self._slot, self._slot_by_ptr, self._pending = None, {}, {}, []
 
     def remove(self):
+        from . import ops
+        if ops.grad_slot_provider is not None and getattr(ops.grad_slot_provider, "__self__", None) is self:
+            ops.grad_slot_provider = None
         for h in self._hooks:
             h.remove()
         self._hooks = []

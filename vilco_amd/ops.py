@@ -69,6 +69,20 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# Where a weight gradient is written.  Under data parallelism dist.GradReducer keeps one flat buffer per bucket; the kernels
+# that produce the large gradients (the dW products) write straight into the parameter's slot of that buffer, so the
+# collective finds its input in place (no gather copy) and p.grad ends up a view of the bucket.  None = ordinary memory.
+grad_slot_provider = None
+
+
+def _grad_out(w):
+    if grad_slot_provider is not None:
+        slot = grad_slot_provider(w)
+        if slot is not None and slot.shape == w.shape and slot.is_contiguous():
+            return slot
+    return torch.empty_like(w)
+
+
 # ---- concurrency inside a captured step (vilco_amd/graph.py).  A replayed hipGraph has no host in the loop, so independent
 # chains can be forked onto side streams at capture time and the runtime overlaps them: the 77-token text branch under the
 # video stem, the regression head beside the classification head, and the weight-gradient products (nothing in backward
@@ -467,7 +481,7 @@ class _Linear(torch.autograd.Function):
             gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=prec, a_planes=pz, b_planes=pw, want_amax=True)   # dX = dZ W     (NN)
         if ctx.needs_input_grad[1]:
             with _DwFork(w):
-                dw = torch.empty_like(w)
+                dw = _grad_out(w)
                 gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(prec, M), a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
         return dx, dw, db, None, None, None, None, None
 
@@ -526,7 +540,7 @@ class _LinearKN(torch.autograd.Function):
             gemm(dy, w, dx, M, K, N, 1, 1, N, N, K, precision=prec, a_planes=pz, b_planes=pw)   # dX = dY W^T   (NT)
         if ctx.needs_input_grad[1]:
             with _DwFork(w):
-                dw = torch.empty_like(w)
+                dw = _grad_out(w)
                 gemm(x, dy, dw, K, N, M, 0, 0, K, N, N, precision=_dw_prec(prec, M), a_planes=px, b_planes=pz)   # dW = X^T dY   (TN)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy.view(M, N)).view(ctx.bshape)
@@ -537,9 +551,11 @@ def linear_kn(x, w, b=None):
     return _LinearKN.apply(x, w, b)
 
 
-def permute3(src, dims, off, strides):
+def permute3(src, dims, off, strides, out=None):
     lib = _lib.load()
-    out = torch.empty(dims, dtype=torch.float32, device=src.device)
+    if out is None:
+        out = torch.empty(dims, dtype=torch.float32, device=src.device)
+    assert tuple(out.shape) == tuple(dims) and out.is_contiguous()
     _lib.check(lib.vilco_permute3(src.data_ptr(), out.data_ptr(), dims[0], dims[1], dims[2], off,
                                   strides[0], strides[1], strides[2], _stream()))
     return out
@@ -595,7 +611,7 @@ class _Conv3(torch.autograd.Function):
                 dwp = torch.empty(Cout, 3 * Cin, dtype=torch.float32, device=x.device)
                 gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
                      tapT=T, precision=_dw_prec(_precision, B * T), a_amax=_amax_of(dz), b_amax=_amax_of(x))
-                dw = permute3(dwp, (Cout, Cin, 3), 0, (3 * Cin, 1, Cin))
+                dw = permute3(dwp, (Cout, Cin, 3), 0, (3 * Cin, 1, Cin), out=_grad_out(w))
         return dx, dw, db, None
 
 
