@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../.."
 for v in "$@"; do
   rm -f vilco_amd/csrc/gemm.o
-  make -C vilco_amd/csrc -j8 EXTRA=-DVILCO_GEMM_VARIANT=$v > /dev/null
+  make -C vilco_amd/csrc -j8 EXTRA="$(echo $v | sed "s/^p\(.*\)/-DVILCO_GEMM_PRIO=\1/; s/^\([0-9]\)/-DVILCO_GEMM_VARIANT=\1/")" > /dev/null
   cp vilco_amd/libvilco_hip.so tools/lab/libvilco_v$v.so
 done
 rm -f vilco_amd/csrc/gemm.o

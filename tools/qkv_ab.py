@@ -6,5 +6,5 @@ import bench_targets as bt
 dev = torch.device("cuda:0")
 out = [bt.qkv_pre_target(dev, 2), bt.qkv_pre_target(dev, 8), bt.qkv_pre_target(dev, 8, stride=2), bt.qkv_pre_target(dev, 2, C=1024)]
 for o in out:
-    print(os.environ.get("VILCO_QKV_CS", "1"), os.environ.get("VILCO_QKV_CS_TB", "-"), o["shape"], "stride", o["stride"],
+    print("LDS=" + os.environ.get("VILCO_QKV_LDS", "1"), "TB=" + os.environ.get("VILCO_QKV_TB", "-"), o["shape"], "stride", o["stride"],
           "%.1f us  %.0f GB/s  frac %.3f" % (o["us"], o["GBps"], o["hbm_frac"]))

@@ -366,6 +366,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 #ifndef VILCO_GEMM_VARIANT
 #define VILCO_GEMM_VARIANT 3
 #endif
+#ifndef VILCO_GEMM_PRIO      // 1: MFMA phase at priority 1 (default); 0: no s_setprio; 2: MEM phase above the MFMA phase
+#define VILCO_GEMM_PRIO 1
+#endif
   bf16x8 fa[NP][MI], fb[NP][4];
   auto frag_reads = [&](int t) {
     const __bf16* s = smem + (t & 1) * NP * TILE;
@@ -397,7 +400,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 #endif
   };
   auto mfma_phase = [&]() {
+#if VILCO_GEMM_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
+#elif VILCO_GEMM_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -421,7 +428,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
           acc[i][j] = mma<F16>(fa[2][i], fb[0][j], acc[i][j]);
         }
     }
+#if VILCO_GEMM_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
+#elif VILCO_GEMM_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);       // (lab) the MEM phase that follows outranks the partner's MFMA stream
+#endif
   };
 
   // ONE barrier per K-step.  Group 0 runs [MEM(t) MFMA(t)] between barriers, group 1 [MFMA(t-1) MEM(t)]: the two
