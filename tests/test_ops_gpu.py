@@ -624,3 +624,35 @@ def test_split_k_fixup_equals_reduce_kernel(dev, M, N, K, form):
     for C, pre, am in outs[1:]:
         assert torch.equal(C, outs[0][0]) and torch.equal(pre, outs[0][1])
         assert am == float(C.abs().max()) == outs[0][2]
+
+
+@pytest.mark.parametrize("M,N,K,form", [(1024, 1024, 4608, "tn"), (1024, 4096, 4608, "tn"), (300, 200, 96, "tn"), (257, 130, 2080, "nt"),
+                                        (512, 384, 160, "nn"), (1024, 1024, 9082, "tn")])
+def test_single_part_products_two_k_steps_per_interval(dev, M, N, K, form):
+    """precision 4 (the leading fp16 part of both operands, one MFMA per product; weight gradients with long
+    contractions): the kernel covers two K-steps per barrier interval (gemm.hip: K2) -- odd step counts, split-K plans,
+    all three operand orientations, against the product of the fp16-rounded operands in float64."""
+    from vilco_amd import ops
+    torch.manual_seed(M + N + K)
+    if form == "nt":
+        A, B, a_kc, b_kc, lda, ldb = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), 1, 1, K, K
+        Ad, Bd = A, B.t()
+    elif form == "nn":
+        A, B, a_kc, b_kc, lda, ldb = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev), 1, 0, K, N
+        Ad, Bd = A, B
+    else:
+        A, B, a_kc, b_kc, lda, ldb = torch.randn(K, M, device=dev), torch.randn(K, N, device=dev), 0, 0, M, N
+        Ad, Bd = A.t(), B
+
+    def lead(t):            # what the kernel multiplies: fp16(x * s) / s with s the power of two that puts max|x| in [2^14, 2^15)
+        s = 2.0 ** (14 - torch.floor(torch.log2(t.abs().max())).item())
+        return (t * s).half().double() / s
+    want = lead(Ad) @ lead(Bd)
+    C = torch.empty(M, N, device=dev)
+    ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N, precision=4)
+    assert rel(C, want) < 2e-6, rel(C, want)
+    # packed operands (what the weight-gradient products of the model use)
+    pa, pb = ops.pack(A, A.shape[0], A.shape[1]), ops.pack(B, B.shape[0], B.shape[1])
+    C2 = torch.empty(M, N, device=dev)
+    ops.gemm(A, B, C2, M, N, K, a_kc, b_kc, lda, ldb, N, precision=4, a_planes=pa, b_planes=pb)
+    assert rel(C2, want) < 2e-6

@@ -1,6 +1,6 @@
 """gpurun_out/<TAG>_* -> profiles/ (bench line, kernel stats, PMC traffic summary) and a printed recap.  TAG from argv[1] (default r02_z)."""
 import json, csv, shutil, os, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02_z"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03_z"
 RND = TAG.split("_")[0]
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 g = lambda f: os.path.join(R, 'gpurun_out', f)

@@ -5,6 +5,7 @@ from vilco_amd import ops
 ops.set_precision(sys.argv[1] if len(sys.argv) > 1 else "f16x2")
 M, N, K = [int(x) for x in (sys.argv[2:5] or (4608, 4096, 1024))]
 form = sys.argv[5] if len(sys.argv) > 5 else "NT"
+PREC = int(sys.argv[6]) if len(sys.argv) > 6 else None          # 4: single-part products
 dev = torch.device("cuda:0")
 if form == "NT":
     A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev); a_kc, b_kc, lda, ldb = 1, 1, K, K
@@ -20,11 +21,11 @@ torch.cuda.synchronize()
 pa = ops.pack(A, A.shape[0], A.shape[1])
 pb = ops.pack(B, B.shape[0], B.shape[1])
 for _ in range(3):
-    ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N, a_planes=pa, b_planes=pb)
+    ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N, a_planes=pa, b_planes=pb, precision=PREC)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(30):
-    ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N, a_planes=pa, b_planes=pb)
+    ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N, a_planes=pa, b_planes=pb, precision=PREC)
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 30 * 1e3

@@ -1,6 +1,6 @@
 # round-end measurement bundle: bench line (with cpu_baseline, targets, side configs), rocprofv3 kernel stats of the SAME
 # workload (bench.py --no-cpu-baseline --no-targets --extra-batch 0), PMC traffic passes (FETCH_SIZE / WRITE_SIZE separately)
-R=$PWD; TAG=${TAG:-r02_z}
+R=$PWD; TAG=${TAG:-r03_z}
 if [ -z "$SKIP_BENCH" ]; then python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -1 gpurun_out/${TAG}_bench.json | cut -c1-300; fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ps /tmp/pf /tmp/pw

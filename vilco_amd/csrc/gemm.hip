@@ -206,8 +206,14 @@ __device__ __forceinline__ void wait_sc1(f32x4& a, f32x4& b, f32x4& c, f32x4& d)
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 
-template <int BM, int NP, bool F16, bool AKM, bool BKM>
+// K2 (r03): the single-part products (precision 4: weight gradients with long contractions) keep the TWO-slot layout of
+// the two-part kernels but fill the slots with part 0 of two CONSECUTIVE K-steps: a barrier interval then covers 64
+// elements of K -- 2 MFMAs per fragment pair, the same fragment reads and staging traffic as a two-part step.  With one
+// part and 32 elements per interval the loop was bound by its MEM phase (16 MFMAs per wave against ~1000 cycles of
+// reads, stores and loads: ~2000 cycles per 32 k, MFMA pipe 25 % busy); the interval's fixed cost now buys twice the K.
+template <int BM, int NP, bool F16, bool AKM, bool BKM, bool K2 = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
+  static_assert(!K2 || (NP == 2 && F16), "K2: two slots, fp16 parts");
   constexpr int NT = 512;
   constexpr int MI = BM / 64;                    // 16-row A fragments per wave (wave tile = 16*MI x 64)
   // k-major LDS row strides (elements): 16 mod 128, so that a row is 8 dwords mod 64 banks (the 192-row tile borrows
@@ -304,7 +310,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 
   const int kt0 = ks * g.kchunk;
   int kt1 = kt0 + g.kchunk;
-  const int nk_all = g.Kp / BK;
+  const int nk32 = g.Kp / BK;                          // K-steps of 32 in the planes
+  const int nk_all = K2 ? (nk32 + 1) / 2 : nk32;       // barrier intervals
   if (kt1 > nk_all) kt1 = nk_all;
   int kb = kt0;
   if (g.band) {   // block-uniform: relative-position band of this tile (see vilco_gemm_desc.band)
@@ -327,15 +334,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 
   bf16x8 stA[NP][RA], stB[NP][RB];
   auto gload = [&](int kt) {
-    const __bf16* ka = pa + (long)kt * stepA;
-    const __bf16* kb = pb + (long)kt * stepB;
+    const __bf16* ka = pa + (long)(K2 ? 2 * kt : kt) * stepA;
+    const __bf16* kb = pb + (long)(K2 ? 2 * kt : kt) * stepB;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
+      // slot q: part q of this K-step, or (K2) part 0 of K-step 2 kt + q -- zeros beyond an odd count of steps
+      const long qa = K2 ? q * stepA : q * g.a.plane_stride, qb = K2 ? q * stepB : q * g.b.plane_stride;
+      const bool live = !K2 || 2 * kt + q < nk32;
 #pragma unroll
       for (int r = 0; r < RA; ++r)
-        if (r + 1 < RA || tailA) stA[q][r] = *reinterpret_cast<const bf16x8*>(ka + q * g.a.plane_stride + offA[r]);
+        if (r + 1 < RA || tailA) stA[q][r] = live ? *reinterpret_cast<const bf16x8*>(ka + qa + offA[r]) : bf16x8{};
 #pragma unroll
-      for (int r = 0; r < RB; ++r) stB[q][r] = *reinterpret_cast<const bf16x8*>(kb + q * g.b.plane_stride + offB[r]);
+      for (int r = 0; r < RB; ++r) stB[q][r] = live ? *reinterpret_cast<const bf16x8*>(kb + qb + offB[r]) : bf16x8{};
     }
   };
   auto lstore = [&](int st) {
@@ -409,7 +419,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = mma<F16>(fa[0][i], fb[0][j], acc[i][j]);
-    if constexpr (NP >= 2) {
+    if constexpr (K2) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mma<F16>(fa[1][i], fb[1][j], acc[i][j]);
+    } else if constexpr (NP >= 2) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -638,6 +653,10 @@ inline bool use_km() {
 constexpr long SCALE_BYTES = 2 * AMAX_MAX_BLOCKS * 4 + 256;   // fp16 x2 format: amax partials of A and B, then {1/sA, sA, 1/sB, sB}
 constexpr long PACK_HDR = AMAX_MAX_BLOCKS * 4 + 512;          // vilco_pack buffers: amax partials, {1/s, s}, then the planes
 
+inline bool k2_enabled() {
+  static const bool on = [] { const char* e = getenv("VILCO_GEMM_K2"); return !(e && e[0] == '0'); }();
+  return on;
+}
 struct Tune { int bm, ks; };
 inline Tune& tune() {       // env read once per process (the plan is made twice per launch); vilco_gemm_force changes it
   static Tune t = [] {
@@ -658,6 +677,7 @@ struct Plan {
   int a_nbo, a_nbi, b_nbo, b_nbi;
   long a_bytes, b_bytes, part_bytes;
   long split_stride;
+  bool k2;                        // precision 4: a barrier interval of the kernel covers two K-steps (64 elements of K)
   bool fixup;                     // split-K finished inside the launch (tile counters) instead of by splitk_reduce_kernel
 };
 
@@ -754,7 +774,8 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
     if (c128 < best) { p.BM = 128; best = c128; }
   }
   const long tiles = p.BM == 256 ? tiles256 : (p.BM == 192 ? tiles192 : tiles128);
-  const int nk = p.Kp / BK;
+  p.k2 = d->precision == 4 && d->band == 0 && k2_enabled();
+  const int nk = p.k2 ? (p.Kp / BK + 1) / 2 : p.Kp / BK;       // barrier intervals of the K loop
   int ks = 1;
   // Split-K, re-measured in round 2 with tools/lab/ks_try*.sh (kernel + finish, operands packed): what matters is the
   // number of rounds -- a grid of exactly <= 256 workgroups beats a slightly larger one by 15-20 % (1024 x 1024 x 4608:
@@ -798,27 +819,27 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   }
 }
 
-template <int BM, int NP, bool F16, bool AKM, bool BKM>
+template <int BM, int NP, bool F16, bool AKM, bool BKM, bool K2 = false>
 void launch_pp_km(const GArgs& g, dim3 grid, hipStream_t s) {
   constexpr size_t a_el = AKM ? 32 * ((BM == 192 ? 256 : BM) + 16) : BM * 32, b_el = BKM ? 32 * (BN + 16) : BN * 32;
   constexpr size_t pipe = (size_t)2 * NP * (a_el + b_el) * sizeof(__bf16), epi = (size_t)8 * 16 * EPI_LD * 4;
   constexpr size_t lds = pipe > epi ? pipe : epi;
   static const bool once = [] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, NP, F16, AKM, BKM>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, NP, F16, AKM, BKM, K2>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL((gemm_pp_kernel<BM, NP, F16, AKM, BKM>), grid, dim3(512), lds, s, g);
+  hipLaunchKernelGGL((gemm_pp_kernel<BM, NP, F16, AKM, BKM, K2>), grid, dim3(512), lds, s, g);
 }
 
 // operand orientations in use: (kc,kc) forward / convs, (kc,km) dX = dY W, (km,km) dW = dY^T X
-template <int BM, int NP, bool F16 = false>
+template <int BM, int NP, bool F16 = false, bool K2 = false>
 void launch_pp(const GArgs& g, dim3 grid, hipStream_t s, bool akm = false, bool bkm = false) {
-  if (akm && bkm) launch_pp_km<BM, NP, F16, true, true>(g, grid, s);
-  else if (bkm) launch_pp_km<BM, NP, F16, false, true>(g, grid, s);
-  else launch_pp_km<BM, NP, F16, false, false>(g, grid, s);
+  if (akm && bkm) launch_pp_km<BM, NP, F16, true, true, K2>(g, grid, s);
+  else if (bkm) launch_pp_km<BM, NP, F16, false, true, K2>(g, grid, s);
+  else launch_pp_km<BM, NP, F16, false, false, K2>(g, grid, s);
 }
 
 }  // namespace
@@ -1117,7 +1138,11 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
   {
     const bool ak = p.a_km, bk = p.b_km;
-    if (d->precision == 4) {          // one MFMA per product on the leading fp16 parts (plane strides unchanged)
+    if (d->precision == 4 && p.k2) {  // one MFMA per product on the leading fp16 parts, two K-steps per barrier interval
+      if (p.BM == 256) launch_pp<256, 2, true, true>(g, grid, s, ak, bk);
+      else if (p.BM == 192) launch_pp<192, 2, true, true>(g, grid, s, ak, bk);
+      else launch_pp<128, 2, true, true>(g, grid, s, ak, bk);
+    } else if (d->precision == 4) {   // (band-limited products: one K-step per interval; plane strides unchanged)
       if (p.BM == 256) launch_pp<256, 1, true>(g, grid, s, ak, bk);
       else if (p.BM == 192) launch_pp<192, 1, true>(g, grid, s, ak, bk);
       else launch_pp<128, 1, true>(g, grid, s, ak, bk);

@@ -31,7 +31,7 @@ from . import _lib, ops
 
 class GraphedStep:
     def __init__(self, model, optimizer=None, clip_grad_l2norm=-1.0, eager_steps=2, between=None, enabled=True,
-                 gt_pad=8, max_graphs=8, reducer=None):
+                 gt_pad=8, max_graphs=16, reducer=None):
         """optimizer: a FusedOptimizer (None: forward + backward only, gradients left in p.grad);
         eager_steps: iterations of a new signature run eagerly before its capture (>= 1 with an optimizer: the capture
         must follow an eager update, whose max|w| partials scale the captured weight packs);
@@ -75,14 +75,15 @@ class GraphedStep:
         key = (inp.signature(), int(task_id), self._param_sig(), int(model.n_known > 0))
         ent = self._graphs.get(key)
         if ent is None:
-            if sum(1 for e in self._graphs.values() if 'graph' in e) >= self.max_graphs:
-                self.reset()
             ent = self._graphs[key] = {'seen': 0}
         if 'graph' in ent and not self._still_valid(ent):
             self.reset()
             ent = self._graphs[key] = {'seen': 0}
         if 'graph' not in ent:
-            if ent['seen'] < self.eager_steps:
+            # a signature is captured once it has come back often enough, and only while there is room: batches whose
+            # shapes keep changing (ragged text lengths) stay eager instead of evicting the graphs of the common shapes
+            full = sum(1 for e in self._graphs.values() if 'graph' in e) >= self.max_graphs
+            if ent['seen'] < self.eager_steps or full:
                 ent['seen'] += 1
                 return self._eager(inp, video_list, task_id, prev_out_cls_logits)
             self._capture(ent, inp, task_id)
