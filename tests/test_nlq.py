@@ -228,3 +228,36 @@ def test_meta_arch_training_step_and_inference_vs_reference_golden(dev):
         assert res['segments'].shape == e['segments'].shape
         assert rel_err(res['scores'], e['scores']) < TOL and rel_err(res['segments'], e['segments']) < TOL
         assert torch.equal(res['labels'].cpu(), e['labels'])
+
+
+@pytest.mark.gpu
+def test_meta_arch_training_replayed_as_hipgraphs(dev):
+    """BASELINE configs[3]'s model under vilco_amd.graph.GraphedStep: the replayed training iterations (sliding-window
+    attention, two-stream backbone, fused labels / losses, AdamW) equal the eager ones"""
+    import vilco_amd.modeling_nlq as nlq
+    from vilco_amd.graph import GraphedStep
+    from vilco_amd.utils.train_utils import make_optimizer
+    g, cfg = _gold_model(), cases.nlq_model_cfg()
+    runs = []
+    for use_graph in (False, True):
+        model = nlq.make_meta_arch('LocPointTransformer', **cfg)
+        model.load_state_dict(g['state'], strict=True)
+        model = model.to(dev).train()
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if hasattr(mod, "drop_prob"):
+                mod.drop_prob = 0.0
+        opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-3))
+        step = GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=1, enabled=use_graph)
+        batch = [dict(x) for x in cases.nlq_model_batch()]
+        losses = [float(step(batch)['final_loss']) for _ in range(4)]
+        if use_graph:
+            assert step.stats['replayed'] == 3 and step.stats['captured'] == 1, step.stats
+        runs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (la, sa), (lb, sb) = runs
+    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(la, lb)), (la, lb)
+    assert la[-1] < la[0]                                       # it trains
+    for k in sa:
+        if sa[k].is_floating_point() and not k.endswith(NOISE):
+            assert torch.equal(sa[k], sb[k]) or rel_err(sb[k], sa[k], 1e-7) < 1e-5, k

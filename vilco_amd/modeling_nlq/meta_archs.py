@@ -158,6 +158,13 @@ class PtTransformer(mq.PtTransformer):
         vl = [x if 'prompt_feature' in x else dict(x, prompt_feature=x['query_feats']) for x in video_list]
         return super()._query_batch_cf(vl, padding_val)
 
+    def prepare(self, video_list, is_training=True, gt_pad=None):
+        """the host half of the step (PtTransformer.prepare) over NLQ's batch dictionaries: class indices come from the
+        one-hot rows, the text from `query_feats` -- also what vilco_amd.graph.GraphedStep calls"""
+        if self.training and is_training and video_list and 'labels' not in video_list[0]:
+            video_list = self._with_labels(video_list)
+        return super().prepare(video_list, is_training, gt_pad)
+
     def forward(self, video_list, task_id=-1, ensemble=False, hidden_state=False, is_training=True,
                 prev_out_cls_logits=None, get_emb=False, val_qilDatasetList=None):
         if self.training and not get_emb:
