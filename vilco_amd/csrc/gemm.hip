@@ -288,6 +288,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   }
   const long stepA = AKM ? (long)BK * g.a.row_stride : BK;   // elements per K-step
   const long stepB = BKM ? (long)BK * g.b.row_stride : BK;
+  // The staging loads are BUFFER loads: a 128-bit resource (base of this workgroup's operand matrix, one per part) in
+  // SGPRs + this lane's constant 32-bit byte offset + the K-step's byte offset as the instruction's scalar offset -- one
+  // instruction per chunk and no vector address arithmetic at all.  In the MEM phase every instruction counts: the SIMD's
+  // other wave issues MFMAs back to back at raised priority, which leaves this wave about one issue slot per MFMA
+  // (~16 cycles) -- in-kernel stamps (tools/lab/stamps.py, r03): the 6 global loads with their 14 64-bit address VALUs
+  // and 6 hazard nops took ~580 of a ~1100-cycle MEM phase.  (Host side: one operand matrix is < 2^31 bytes.)
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t rsA[NP], rsB[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    rsA[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pa + (K2 ? 0 : q * g.a.plane_stride)), 0, -1, 0x00020000);
+    rsB[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pb + (K2 ? 0 : q * g.b.plane_stride)), 0, -1, 0x00020000);
+  }
+  unsigned voffA[RA], voffB[RB];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) voffA[r] = (unsigned)(offA[r] * 2);
+#pragma unroll
+  for (int r = 0; r < RB; ++r) voffB[r] = (unsigned)(offB[r] * 2);
   // fragment addresses (elements inside one part's tile)
   int fbA[MI], fbB[4];
   {
@@ -334,18 +352,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 
   bf16x8 stA[NP][RA], stB[NP][RB];
   auto gload = [&](int kt) {
-    const __bf16* ka = pa + (long)(K2 ? 2 * kt : kt) * stepA;
-    const __bf16* kb = pb + (long)(K2 ? 2 * kt : kt) * stepB;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       // slot q: part q of this K-step, or (K2) part 0 of K-step 2 kt + q -- zeros beyond an odd count of steps
-      const long qa = K2 ? q * stepA : q * g.a.plane_stride, qb = K2 ? q * stepB : q * g.b.plane_stride;
+      const int sa = (int)(2 * (long)(K2 ? 2 * kt + q : kt) * stepA), sb = (int)(2 * (long)(K2 ? 2 * kt + q : kt) * stepB);
       const bool live = !K2 || 2 * kt + q < nk32;
 #pragma unroll
       for (int r = 0; r < RA; ++r)
-        if (r + 1 < RA || tailA) stA[q][r] = live ? *reinterpret_cast<const bf16x8*>(ka + qa + offA[r]) : bf16x8{};
+        if (r + 1 < RA || tailA)
+          stA[q][r] = live ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsA[q], (int)voffA[r], sa, 0)) : bf16x8{};
 #pragma unroll
-      for (int r = 0; r < RB; ++r) stB[q][r] = live ? *reinterpret_cast<const bf16x8*>(kb + qb + offB[r]) : bf16x8{};
+      for (int r = 0; r < RB; ++r)
+        stB[q][r] = live ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB[q], (int)voffB[r], sb, 0)) : bf16x8{};
     }
   };
   auto lstore = [&](int st) {
