@@ -250,6 +250,277 @@ __global__ __launch_bounds__(256) void qkv_pre_fwd_kernel(QkvArgs a) {
     }
 }
 
+// Forward, fourth version (r03): a ROW RING in LDS, producer / consumer waves, every wave channel-split.
+// One workgroup walks a run of `seg` consecutive output tokens of one clip; 3 + C/256 waves:
+//   * A-waves (3): each owns every third 256-channel chunk of every input row.  Rows travel global -> registers KS row
+//     groups ahead (a group = the S new rows one output token needs; nothing waits on a load that was not issued ~KS
+//     barrier intervals earlier), then: LayerNorm-1 statistics as per-wave shifted sums, combined over the three waves
+//     with the exact pairwise mean / M2 update -> h = LN1(x) written ONCE into a two-group LDS ring (and to HBM when
+//     another consumer wants h).
+//   * B-waves (C/256): each owns ONE 256-channel chunk of every output token, its 15 per-channel parameters live in
+//     registers for the whole run.  Per interval: read the new h rows of its chunk from the ring (the previous two stay in
+//     registers), the three convs, six partial sums -> LDS; one interval later the combined statistics normalise the
+//     token and q, k, v leave as three 1 KB stores per wave.
+// ONE workgroup barrier per token; x is read once (plus two halo rows per run), nothing is recomputed, no row is
+// re-fetched.  Pipeline (interval i): A finalises group i, B convolves token i - D and writes token i - D - 1.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void stg4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NCH>
+__device__ __forceinline__ float sum_parts(const float* p) {      // p[0 .. NCH): fixed order, the same in every wave
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  float s = NCH >= 4 ? (a.x + a.y) + (a.z + a.w) : NCH == 3 ? (a.x + a.y) + a.z : NCH == 2 ? a.x + a.y : a.x;
+  if (NCH > 4) {
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    s += NCH >= 8 ? (b.x + b.y) + (b.z + b.w) : NCH == 7 ? (b.x + b.y) + b.z : NCH == 6 ? b.x + b.y : b.x;
+  }
+  if (NCH > 8) s += p[8];
+  return s;
+}
+
+// Joint wavefront sums: v_permlane32_swap / v_permlane16_swap exchange half the lanes of TWO registers in one instruction,
+// so each step halves the number of live registers instead of spending a full butterfly per value (18 instructions for
+// six sums instead of 66).  Results land in 16-lane rows: wave_sum4 -> row 0: sum v0, row 1: sum v2, row 2: sum v1, row 3:
+// sum v3; wave_sum2 -> rows 0-1: sum v0, rows 2-3: sum v1.  Fixed order, bitwise reproducible.
+__device__ __forceinline__ void swap32(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]); y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float row_sum(float s) {
+  s += vilco_dpp<0xB1>(s); s += vilco_dpp<0x4E>(s); s += vilco_dpp<0x141>(s); s += vilco_dpp<0x140>(s);
+  return s;
+}
+__device__ __forceinline__ float wave_sum4(float v0, float v1, float v2, float v3) {
+  swap32(v0, v1); float s01 = v0 + v1;
+  swap32(v2, v3); float s23 = v2 + v3;
+  swap16(s01, s23);
+  return row_sum(s01 + s23);
+}
+__device__ __forceinline__ float wave_sum2(float v0, float v1) {
+  swap32(v0, v1);
+  float s = v0 + v1, t = s;
+  swap16(s, t);
+  return row_sum(s + t);
+}
+
+constexpr int RING_NA = 3;
+template <int NCH, int S>
+__global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(QkvArgs a, int npart) {
+  constexpr int NA = RING_NA, ACH = (NCH + NA - 1) / NA, KS = (S == 1) ? 7 : 4, D = (S == 1) ? 3 : 2, C = NCH * 256;
+  __shared__ __align__(16) float ring[2][S][C];
+  __shared__ __align__(16) float bfin[2][3][2];                // (mean, rstd) of a token's three conv rows, combined by the A-waves
+  __shared__ __align__(16) float apart[2][S][NA][4];
+  __shared__ __align__(16) float bpart[2][6][12];
+  __shared__ float wmax[3][12];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nseg = (a.Tout + a.seg - 1) / a.seg;
+  const int b = blockIdx.x / nseg, t0 = (blockIdx.x % nseg) * a.seg;
+  const int t1 = t0 + a.seg < a.Tout ? t0 + a.seg : a.Tout, nsteps = t1 - t0;
+  const int NI = nsteps + D + 2, NQ = nsteps + (S == 1 ? 2 : 1);        // barrier intervals; row groups the run needs
+  const int T = a.T, rb = S * t0 - 1;                                    // group q = rows rb + q S + u, u < S
+  const float invC = 1.f / (float)C;
+
+  if (wave < NA) {
+    // ------------------------------------------------------------------------------------------------ A: x -> h ring
+    // The row loads are inline asm with hand-placed s_waitcnt vmcnt(N): the compiler's counter model merges control-flow
+    // joins conservatively (a conditional store between issue and use costs one load of prefetch depth each), and the
+    // whole point of these waves is loads that stay in flight for KS - 1 barrier intervals.
+    const int aw = wave;
+    bool cv[ACH]; int co[ACH];
+#pragma unroll
+    for (int m = 0; m < ACH; ++m) { const int ch = aw + NA * m; cv[m] = ch < NCH; co[m] = (cv[m] ? ch : 0) * 256 + lane * 4; }
+    float4 g1v[ACH], b1v[ACH];
+#pragma unroll
+    for (int m = 0; m < ACH; ++m) { g1v[m] = a.g1 ? ldg4(a.g1 + co[m]) : f4(1.f); b1v[m] = a.b1 ? ldg4(a.b1 + co[m]) : f4(0.f); }
+    const float* xb = a.x + (long)b * T * C;
+    f32x4 xs[KS][S][ACH];
+    auto load = [&](int q, f32x4 (&dst)[S][ACH]) {
+      q = q < NQ - 1 ? q : NQ - 1;                            // past the run: the last group again (cache hits, no new bytes)
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        int r = rb + q * S + u;
+        r = r < 0 ? 0 : (r >= T ? T - 1 : r);                 // padding rows: loaded from the clamped row, discarded
+        const float* p = xb + (long)r * C;
+#pragma unroll
+        for (int m = 0; m < ACH; ++m) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[u][m]) : "v"(p + co[m]) : "memory");
+      }
+    };
+    auto arrived = [&](f32x4 (&v)[S][ACH]) {                  // all but the (KS - 1) younger groups' loads have landed
+#pragma unroll
+      for (int u = 0; u < S; ++u)
+#pragma unroll
+        for (int m = 0; m < ACH; ++m) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[u][m]) : "n"((KS - 1) * S * ACH));
+    };
+    auto stats = [&](int q, f32x4 (&v)[S][ACH]) {
+      arrived(v);
+      float ks[S], p1[S], p2[S];
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const float k = vilco_lane(v[u][0].x, 0);              // shift: the first element of this wave's slice
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < ACH; ++m)
+          if (cv[m]) {
+            const float d0 = v[u][m].x - k, d1 = v[u][m].y - k, d2 = v[u][m].z - k, d3 = v[u][m].w - k;
+            s1 += (d0 + d1) + (d2 + d3);
+            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          }
+        ks[u] = k; p1[u] = s1; p2[u] = s2;
+      }
+      if (S == 1) {
+        const float r = wave_sum2(p1[0], p2[0]);               // lanes < 32: s1, lanes >= 32: s2
+        if (lane == 0) { apart[q & 1][0][aw][0] = ks[0]; apart[q & 1][0][aw][1] = r; }
+        if (lane == 32) apart[q & 1][0][aw][2] = r;
+      } else {
+        const float r = wave_sum4(p1[0], p2[0], p1[S - 1], p2[S - 1]);     // rows: s1 of row 0, s1 of row 1, s2 of row 0, s2 of row 1
+        if ((lane & 15) == 0) {
+          const int row = lane >> 4;
+          apart[q & 1][row & 1][aw][1 + (row >> 1)] = r;
+          if (row < 2) apart[q & 1][row][aw][0] = row ? ks[S - 1] : ks[0];
+        }
+      }
+    };
+    auto finalize = [&](int q, const f32x4 (&v)[S][ACH]) {
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const int r = rb + q * S + u;
+        const bool in = r >= 0 && r < T, own = in && r >= S * t0 && r < S * t1;
+        float mw[NA], m2[NA], tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NA; ++w) {
+          const int nv = (NCH - w + NA - 1) / NA;              // chunks of A-wave w (0 when w >= NCH)
+          if (nv > 0) {
+            const float4 p = *reinterpret_cast<const float4*>(apart[q & 1][u][w]);
+            const float n = 256.f * nv, d = p.y * (1.f / n);
+            mw[w] = p.x + d; m2[w] = p.z - p.y * d; tot += n * mw[w];
+          }
+        }
+        const float mu = tot * invC;
+        float M2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NA; ++w) {
+          const int nv = (NCH - w + NA - 1) / NA;
+          if (nv > 0) { const float d = mw[w] - mu; M2 += m2[w] + 256.f * nv * d * d; }
+        }
+        const float rs = __builtin_amdgcn_rsqf(fmaxf(M2 * invC, 0.f) + a.eps1);
+#pragma unroll
+        for (int m = 0; m < ACH; ++m)
+          if (cv[m]) {
+            float4 h;
+            h.x = in ? (v[u][m].x - mu) * rs * g1v[m].x + b1v[m].x : 0.f; h.y = in ? (v[u][m].y - mu) * rs * g1v[m].y + b1v[m].y : 0.f;
+            h.z = in ? (v[u][m].z - mu) * rs * g1v[m].z + b1v[m].z : 0.f; h.w = in ? (v[u][m].w - mu) * rs * g1v[m].w + b1v[m].w : 0.f;
+            *reinterpret_cast<float4*>(&ring[q & 1][u][co[m]]) = h;
+            if (a.h && own) stg4(a.h + ((long)b * T + r) * C + co[m], h);
+          }
+        if (aw == 0 && lane == 0 && a.mean1 && own) { a.mean1[(long)b * T + r] = mu; a.rstd1[(long)b * T + r] = rs; }
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < KS; ++u) load(u, xs[u]);
+    stats(0, xs[0]);                                           // (waits for group 0 only: KS - 1 groups stay in flight)
+    lds_barrier();
+    for (int i0 = 0; i0 < NI; i0 += KS) {                      // NI rounded up to whole rounds of the KS register slots:
+#pragma unroll
+      for (int u = 0; u < KS; ++u) {                           // the surplus intervals touch nothing that is used
+        const int i = i0 + u;
+        finalize(i, xs[u]);
+        load(i + KS, xs[u]);
+        {                                                      // the B-waves' partial sums of interval i - 1 -> (mean, rstd) of conv aw
+          const float m = sum_parts<NCH>(bpart[(i - 1) & 1][2 * aw]) * invC, q2 = sum_parts<NCH>(bpart[(i - 1) & 1][2 * aw + 1]) * invC;
+          const float rs = __builtin_amdgcn_rsqf(fmaxf(q2 - m * m, 0.f) + a.eps);
+          if (lane == 0) { bfin[i & 1][aw][0] = m; bfin[i & 1][aw][1] = rs; }
+        }
+        stats(i + 1, xs[(u + 1) % KS]);
+        lds_barrier();
+      }
+    }
+    lds_barrier();                                             // the B-waves' amax hand-over
+  } else {
+    // ------------------------------------------------------------------------------------------- B: ring -> q, k, v
+    const int c = wave - NA, co = c * 256 + lane * 4;
+    float4 wa[3], wb[3], wc[3], gm[3], bt[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float* wp = a.w[j] + co * 3;
+      wa[j] = ldg4(wp); wb[j] = ldg4(wp + 4); wc[j] = ldg4(wp + 8);
+      gm[j] = a.gam[j] ? ldg4(a.gam[j] + co) : f4(1.f);
+      bt[j] = a.bet[j] ? ldg4(a.bet[j] + co) : f4(0.f);
+    }
+    const int len = a.len[b];
+    float4 p0 = f4(0.f), p1 = f4(0.f), cp[3] = {f4(0.f), f4(0.f), f4(0.f)}, cpp[3] = {f4(0.f), f4(0.f), f4(0.f)};
+    float omax[3] = {0.f, 0.f, 0.f};
+    lds_barrier();
+    const int NIp = (NI + KS - 1) / KS * KS;
+    for (int i = 0; i < NIp; ++i) {
+      const int sf = i - D - 2;
+      if (sf >= 0 && sf < nsteps) {                             // token sf: statistics complete -> normalise, write
+        const long row = (long)b * a.Tout + t0 + sf;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float m = bfin[(i - 1) & 1][j][0], rs = bfin[(i - 1) & 1][j][1];
+          float4 o;
+          o.x = (cpp[j].x - m) * rs * gm[j].x + bt[j].x; o.y = (cpp[j].y - m) * rs * gm[j].y + bt[j].y;
+          o.z = (cpp[j].z - m) * rs * gm[j].z + bt[j].z; o.w = (cpp[j].w - m) * rs * gm[j].w + bt[j].w;
+          omax[j] = fmaxf(fmaxf(omax[j], fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+          stg4(a.y[j] + row * C + co, o);
+          if (c == 0 && lane == 0 && a.mean[j]) { a.mean[j][row] = m; a.rstd[j][row] = rs; }
+        }
+      }
+      if (i >= 1) {
+        const float4 n0 = *reinterpret_cast<const float4*>(&ring[(i - 1) & 1][0][co]);
+        float4 n1 = n0;
+        if (S == 2) n1 = *reinterpret_cast<const float4*>(&ring[(i - 1) & 1][S - 1][co]);
+        const int s = i - D;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cpp[j] = cp[j];
+        if (s >= 0 && s < nsteps) {                             // token s: rows (p0, p1, n0)
+          float sm[6];
+          if (S * (t0 + s) < len) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              float4 cj;
+              cj.x = wa[j].x * p0.x + wa[j].y * p1.x + wa[j].z * n0.x;
+              cj.y = wa[j].w * p0.y + wb[j].x * p1.y + wb[j].y * n0.y;
+              cj.z = wb[j].z * p0.z + wb[j].w * p1.z + wc[j].x * n0.z;
+              cj.w = wc[j].y * p0.w + wc[j].z * p1.w + wc[j].w * n0.w;
+              cp[j] = cj;
+              sm[2 * j] = (cj.x + cj.y) + (cj.z + cj.w);
+              sm[2 * j + 1] = (cj.x * cj.x + cj.y * cj.y) + (cj.z * cj.z + cj.w * cj.w);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { cp[j] = f4(0.f); sm[2 * j] = 0.f; sm[2 * j + 1] = 0.f; }
+          }
+          const float r4 = wave_sum4(sm[0], sm[1], sm[2], sm[3]);      // rows: sm0, sm2, sm1, sm3
+          const float r2 = wave_sum2(sm[4], sm[5]);                    // rows 0-1: sm4, rows 2-3: sm5
+          if ((lane & 15) == 0) {
+            const int row = lane >> 4;
+            bpart[i & 1][((row & 1) << 1) | (row >> 1)][c] = r4;
+            if (!(row & 1)) bpart[i & 1][4 + (row >> 1)][c] = r2;
+          }
+        }
+        if (S == 1) { p0 = p1; p1 = n0; } else { p0 = n0; p1 = n1; }
+      }
+      lds_barrier();
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const float m = wave_max(omax[j]); if (lane == 0) wmax[j][c] = m; }
+    lds_barrier();
+    float* ap = lane == 0 ? a.amax[0] : lane == 1 ? a.amax[1] : a.amax[2];
+    if (c == 0 && lane < 3 && ap) {                             // one partial per workgroup; unused slots of the table: 0
+      float m = 0.f;
+      for (int k = 0; k < NCH; ++k) m = fmaxf(m, wmax[lane][k]);
+      ap[blockIdx.x] = m;
+      for (int k = gridDim.x + blockIdx.x; k < npart; k += gridDim.x) ap[k] = 0.f;
+    }
+  }
+}
+
 // Two other forward structures were built and measured at [8, 2304, 2304] (r02; this kernel: 230 us) and removed:
 //   * rows of a 4-token tile normalised once into LDS, one token per wave: 288 us -- x is read 1.5x instead of 6x, but
 //     every wave re-loads the 17 per-channel parameter quads per token and pass;
@@ -492,8 +763,41 @@ int forced_tb() {
   return forced;
 }
 
-bool launch_fwd(const QkvArgs& a, hipStream_t s) {
+// Ring kernel (fourth version): one workgroup per run of `seg` output tokens; runs sized so that one round of workgroups
+// covers the 256 CUs (a run pays D + 1 pipeline intervals and two halo rows, so short runs are worth nothing).
+int ring_seg(int B, int Tout) {
+  int per_clip = 256 / B;
+  if (per_clip < 1) per_clip = 1;
+  int seg = (Tout + per_clip - 1) / per_clip;
+  return seg < 8 ? 8 : seg;
+}
+int ring_mode() {          // VILCO_QKV_RING: 1 = always, 0 = never, unset = where it measured faster
+  static const int m = [] { const char* e = getenv("VILCO_QKV_RING"); return e ? atoi(e) : -1; }();
+  return m;
+}
+bool use_ring(const QkvArgs& a) {
+  const int m = ring_mode();
+  if (m >= 0) return m != 0;
+  return false;
+}
+template <int S>
+void launch_ring(QkvArgs a, int npart, hipStream_t s) {
+  a.seg = ring_seg(a.B, a.Tout);
+  const dim3 grid((unsigned)(a.B * ((a.Tout + a.seg - 1) / a.seg)));
+#define RING_CASE(N) case N: hipLaunchKernelGGL((qkv_pre_fwd_ring_kernel<N, S>), grid, dim3((RING_NA + N) * 64), 0, s, a, npart); break
+  switch (a.C / 256) {
+    RING_CASE(1); RING_CASE(2); RING_CASE(3); RING_CASE(4); RING_CASE(5); RING_CASE(6); RING_CASE(7); RING_CASE(8);
+    default: RING_CASE(9);
+  }
+#undef RING_CASE
+}
+
+bool launch_fwd(const QkvArgs& a, hipStream_t s, int npart) {
   if (a.C % 256 != 0) return false;
+  if (use_ring(a)) {
+    if (a.stride == 1) launch_ring<1>(a, npart, s); else launch_ring<2>(a, npart, s);
+    return true;
+  }
   const int forced = forced_tb();
   if (a.stride == 1) {
     int tb = forced ? forced : 2;
@@ -532,7 +836,7 @@ extern "C" int vilco_qkv_pre_fwd(const float* x, const float* ln1_g, const float
   }
   a.B = B; a.T = T; a.Tout = T / stride; a.C = C; a.stride = stride; a.seg = 0;
   a.eps1 = eps1; a.eps = eps;
-  if (!launch_fwd(a, s)) return VILCO_ERR_UNSUPPORTED;
+  if (!launch_fwd(a, s, a.amax[0] ? vilco_qkv_pre_amax_parts(B, T, stride) : 0)) return VILCO_ERR_UNSUPPORTED;
   return vilco_launch_status();
 }
 
