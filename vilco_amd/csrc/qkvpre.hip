@@ -309,9 +309,18 @@ __device__ __forceinline__ float wave_sum2(float v0, float v1) {
 }
 
 constexpr int RING_NA = 3;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lo2(const f32x4& v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(const f32x4& v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ f32x4 ld4s(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+
 template <int NCH, int S>
 __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(QkvArgs a, int npart) {
-  constexpr int NA = RING_NA, ACH = (NCH + NA - 1) / NA, KS = (S == 1) ? 7 : 4, D = (S == 1) ? 3 : 2, C = NCH * 256;
+  // KS: register slots of row groups per A-wave = unroll of both loops (the B-waves' row window rotates with period 3 at
+  // stride 1, their conv rows with period 2; KS = 6 / 4 is a multiple of both)
+  constexpr int NA = RING_NA, ACH = (NCH + NA - 1) / NA, KS = (S == 1) ? 6 : 4, D = (S == 1) ? 3 : 2, C = NCH * 256;
+  constexpr bool ALLV = NCH % NA == 0;                         // every A-wave owns ACH whole chunks
   __shared__ __align__(16) float ring[2][S][C];
   __shared__ __align__(16) float bfin[2][3][2];                // (mean, rstd) of a token's three conv rows, combined by the A-waves
   __shared__ __align__(16) float apart[2][S][NA][4];
@@ -322,21 +331,23 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
   const int b = blockIdx.x / nseg, t0 = (blockIdx.x % nseg) * a.seg;
   const int t1 = t0 + a.seg < a.Tout ? t0 + a.seg : a.Tout, nsteps = t1 - t0;
   const int NI = nsteps + D + 2, NQ = nsteps + (S == 1 ? 2 : 1);        // barrier intervals; row groups the run needs
+  const int NIp = (NI + KS - 1) / KS * KS;                              // whole rounds of the KS slots: the surplus intervals touch nothing that is used
   const int T = a.T, rb = S * t0 - 1;                                    // group q = rows rb + q S + u, u < S
   const float invC = 1.f / (float)C;
 
   if (wave < NA) {
     // ------------------------------------------------------------------------------------------------ A: x -> h ring
-    // The row loads are inline asm with hand-placed s_waitcnt vmcnt(N): the compiler's counter model merges control-flow
-    // joins conservatively (a conditional store between issue and use costs one load of prefetch depth each), and the
-    // whole point of these waves is loads that stay in flight for KS - 1 barrier intervals.
+    // The row loads are inline asm (uniform row base in SGPRs + the lane's constant byte offset) with hand-placed
+    // s_waitcnt vmcnt(N): the compiler's counter model merges control-flow joins conservatively (a conditional store
+    // between issue and use costs one load of prefetch depth each), and the whole point of these waves is loads that stay
+    // in flight for KS - 1 barrier intervals.
     const int aw = wave;
     bool cv[ACH]; int co[ACH];
 #pragma unroll
-    for (int m = 0; m < ACH; ++m) { const int ch = aw + NA * m; cv[m] = ch < NCH; co[m] = (cv[m] ? ch : 0) * 256 + lane * 4; }
-    float4 g1v[ACH], b1v[ACH];
+    for (int m = 0; m < ACH; ++m) { const int ch = aw + NA * m; cv[m] = ALLV || ch < NCH; co[m] = (cv[m] ? ch : 0) * 256 + lane * 4; }
+    f32x4 g1v[ACH], b1v[ACH];
 #pragma unroll
-    for (int m = 0; m < ACH; ++m) { g1v[m] = a.g1 ? ldg4(a.g1 + co[m]) : f4(1.f); b1v[m] = a.b1 ? ldg4(a.b1 + co[m]) : f4(0.f); }
+    for (int m = 0; m < ACH; ++m) { g1v[m] = a.g1 ? ld4s(a.g1 + co[m]) : splat4(1.f); b1v[m] = a.b1 ? ld4s(a.b1 + co[m]) : splat4(0.f); }
     const float* xb = a.x + (long)b * T * C;
     f32x4 xs[KS][S][ACH];
     auto load = [&](int q, f32x4 (&dst)[S][ACH]) {
@@ -347,7 +358,8 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
         r = r < 0 ? 0 : (r >= T ? T - 1 : r);                 // padding rows: loaded from the clamped row, discarded
         const float* p = xb + (long)r * C;
 #pragma unroll
-        for (int m = 0; m < ACH; ++m) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[u][m]) : "v"(p + co[m]) : "memory");
+        for (int m = 0; m < ACH; ++m)
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[u][m]) : "v"(co[m] * 4), "s"(p) : "memory");
       }
     };
     auto arrived = [&](f32x4 (&v)[S][ACH]) {                  // all but the (KS - 1) younger groups' loads have landed
@@ -356,21 +368,23 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
 #pragma unroll
         for (int m = 0; m < ACH; ++m) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[u][m]) : "n"((KS - 1) * S * ACH));
     };
-    auto stats = [&](int q, f32x4 (&v)[S][ACH]) {
+    auto stats = [&](int q, f32x4 (&v)[S][ACH]) {             // shifted sums of this wave's slice of the group's rows
       arrived(v);
       float ks[S], p1[S], p2[S];
 #pragma unroll
       for (int u = 0; u < S; ++u) {
         const float k = vilco_lane(v[u][0].x, 0);              // shift: the first element of this wave's slice
-        float s1 = 0.f, s2 = 0.f;
+        const f32x2 k2 = {k, k};
+        f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < ACH; ++m)
           if (cv[m]) {
-            const float d0 = v[u][m].x - k, d1 = v[u][m].y - k, d2 = v[u][m].z - k, d3 = v[u][m].w - k;
-            s1 += (d0 + d1) + (d2 + d3);
-            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            const f32x2 d0 = lo2(v[u][m]) - k2, d1 = hi2(v[u][m]) - k2;
+            s1 += d0 + d1;
+            s2 = __builtin_elementwise_fma(d0, d0, s2);
+            s2 = __builtin_elementwise_fma(d1, d1, s2);
           }
-        ks[u] = k; p1[u] = s1; p2[u] = s2;
+        ks[u] = k; p1[u] = s1.x + s1.y; p2[u] = s2.x + s2.y;
       }
       if (S == 1) {
         const float r = wave_sum2(p1[0], p2[0]);               // lanes < 32: s1, lanes >= 32: s2
@@ -385,7 +399,7 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
         }
       }
     };
-    auto finalize = [&](int q, const f32x4 (&v)[S][ACH]) {
+    auto finalize = [&](int q, const f32x4 (&v)[S][ACH]) {    // the three waves' sums -> mean, rstd (pairwise update) -> h
 #pragma unroll
       for (int u = 0; u < S; ++u) {
         const int r = rb + q * S + u;
@@ -408,14 +422,15 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
           if (nv > 0) { const float d = mw[w] - mu; M2 += m2[w] + 256.f * nv * d * d; }
         }
         const float rs = __builtin_amdgcn_rsqf(fmaxf(M2 * invC, 0.f) + a.eps1);
+        const f32x2 mu2 = {mu, mu}, rs2 = {rs, rs};
 #pragma unroll
         for (int m = 0; m < ACH; ++m)
-          if (cv[m]) {
-            float4 h;
-            h.x = in ? (v[u][m].x - mu) * rs * g1v[m].x + b1v[m].x : 0.f; h.y = in ? (v[u][m].y - mu) * rs * g1v[m].y + b1v[m].y : 0.f;
-            h.z = in ? (v[u][m].z - mu) * rs * g1v[m].z + b1v[m].z : 0.f; h.w = in ? (v[u][m].w - mu) * rs * g1v[m].w + b1v[m].w : 0.f;
-            *reinterpret_cast<float4*>(&ring[q & 1][u][co[m]]) = h;
-            if (a.h && own) stg4(a.h + ((long)b * T + r) * C + co[m], h);
+          if (cv[m]) {                                           // rows outside [0, T) (the conv's zero padding) are zeroed by their readers
+            const f32x2 hl = __builtin_elementwise_fma((lo2(v[u][m]) - mu2) * rs2, lo2(g1v[m]), lo2(b1v[m]));
+            const f32x2 hh = __builtin_elementwise_fma((hi2(v[u][m]) - mu2) * rs2, hi2(g1v[m]), hi2(b1v[m]));
+            const f32x4 h = __builtin_shufflevector(hl, hh, 0, 1, 2, 3);
+            *reinterpret_cast<f32x4*>(&ring[q & 1][u][co[m]]) = h;
+            if (a.h && own) *reinterpret_cast<f32x4*>(a.h + ((long)b * T + r) * C + co[m]) = h;
           }
         if (aw == 0 && lane == 0 && a.mean1 && own) { a.mean1[(long)b * T + r] = mu; a.rstd1[(long)b * T + r] = rs; }
       }
@@ -424,16 +439,22 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
     for (int u = 0; u < KS; ++u) load(u, xs[u]);
     stats(0, xs[0]);                                           // (waits for group 0 only: KS - 1 groups stay in flight)
     lds_barrier();
-    for (int i0 = 0; i0 < NI; i0 += KS) {                      // NI rounded up to whole rounds of the KS register slots:
+    for (int i0 = 0; i0 < NIp; i0 += KS) {
 #pragma unroll
-      for (int u = 0; u < KS; ++u) {                           // the surplus intervals touch nothing that is used
+      for (int u = 0; u < KS; ++u) {
         const int i = i0 + u;
         finalize(i, xs[u]);
         load(i + KS, xs[u]);
         {                                                      // the B-waves' partial sums of interval i - 1 -> (mean, rstd) of conv aw
           const float m = sum_parts<NCH>(bpart[(i - 1) & 1][2 * aw]) * invC, q2 = sum_parts<NCH>(bpart[(i - 1) & 1][2 * aw + 1]) * invC;
           const float rs = __builtin_amdgcn_rsqf(fmaxf(q2 - m * m, 0.f) + a.eps);
-          if (lane == 0) { bfin[i & 1][aw][0] = m; bfin[i & 1][aw][1] = rs; }
+          const int s = i - 1 - D;
+          if (lane == 0) {
+            bfin[i & 1][aw][0] = m; bfin[i & 1][aw][1] = rs;
+            float* mp = aw == 0 ? a.mean[0] : aw == 1 ? a.mean[1] : a.mean[2];
+            float* rp = aw == 0 ? a.rstd[0] : aw == 1 ? a.rstd[1] : a.rstd[2];
+            if (mp && s >= 0 && s < nsteps) { mp[(long)b * a.Tout + t0 + s] = m; rp[(long)b * a.Tout + t0 + s] = rs; }
+          }
         }
         stats(i + 1, xs[(u + 1) % KS]);
         lds_barrier();
@@ -443,59 +464,83 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
   } else {
     // ------------------------------------------------------------------------------------------- B: ring -> q, k, v
     const int c = wave - NA, co = c * 256 + lane * 4;
-    float4 wa[3], wb[3], wc[3], gm[3], bt[3];
+    f32x4 w0[3], w1[3], w2[3], gm[3], bt[3];                   // taps as per-channel vectors
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float* wp = a.w[j] + co * 3;
-      wa[j] = ldg4(wp); wb[j] = ldg4(wp + 4); wc[j] = ldg4(wp + 8);
-      gm[j] = a.gam[j] ? ldg4(a.gam[j] + co) : f4(1.f);
-      bt[j] = a.bet[j] ? ldg4(a.bet[j] + co) : f4(0.f);
+      const f32x4 wa = ld4s(wp), wb = ld4s(wp + 4), wc = ld4s(wp + 8);   // channel 0: wa.xyz | 1: wa.w wb.xy | 2: wb.zw wc.x | 3: wc.yzw
+      w0[j] = f32x4{wa.x, wa.w, wb.z, wc.y}; w1[j] = f32x4{wa.y, wb.x, wb.w, wc.z}; w2[j] = f32x4{wa.z, wb.y, wc.x, wc.w};
+      gm[j] = a.gam[j] ? ld4s(a.gam[j] + co) : splat4(1.f);
+      bt[j] = a.bet[j] ? ld4s(a.bet[j] + co) : splat4(0.f);
     }
     const int len = a.len[b];
-    float4 p0 = f4(0.f), p1 = f4(0.f), cp[3] = {f4(0.f), f4(0.f), f4(0.f)}, cpp[3] = {f4(0.f), f4(0.f), f4(0.f)};
-    float omax[3] = {0.f, 0.f, 0.f};
+    constexpr int NH = (S == 1) ? 3 : 2;
+    f32x4 hw[NH][S];                                           // stride 1: the last three rows; stride 2: the last two groups
+    f32x4 cw[2][3];                                            // conv rows of the two tokens in flight
+    float om[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NH; ++k)
+#pragma unroll
+      for (int u = 0; u < S; ++u) hw[k][u] = splat4(0.f);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) cw[k][j] = splat4(0.f);
+    float* yb[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) yb[j] = a.y[j] + ((long)b * a.Tout + t0) * C + co;
     lds_barrier();
-    const int NIp = (NI + KS - 1) / KS * KS;
-    for (int i = 0; i < NIp; ++i) {
-      const int sf = i - D - 2;
-      if (sf >= 0 && sf < nsteps) {                             // token sf: statistics complete -> normalise, write
-        const long row = (long)b * a.Tout + t0 + sf;
+    for (int i0 = 0; i0 < NIp; i0 += KS) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const float m = bfin[(i - 1) & 1][j][0], rs = bfin[(i - 1) & 1][j][1];
-          float4 o;
-          o.x = (cpp[j].x - m) * rs * gm[j].x + bt[j].x; o.y = (cpp[j].y - m) * rs * gm[j].y + bt[j].y;
-          o.z = (cpp[j].z - m) * rs * gm[j].z + bt[j].z; o.w = (cpp[j].w - m) * rs * gm[j].w + bt[j].w;
-          omax[j] = fmaxf(fmaxf(omax[j], fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-          stg4(a.y[j] + row * C + co, o);
-          if (c == 0 && lane == 0 && a.mean[j]) { a.mean[j][row] = m; a.rstd[j][row] = rs; }
+      for (int u = 0; u < KS; ++u) {
+        const int i = i0 + u;
+        const int sf = i - D - 2;
+        const bool wr = sf >= 0 && sf < nsteps;
+        f32x4 o[3];
+        if (wr) {                                               // token sf: statistics complete -> normalise
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float2 fin = *reinterpret_cast<const float2*>(bfin[(i - 1) & 1][j]);
+            const f32x2 m2 = {fin.x, fin.x}, r2 = {fin.y, fin.y};
+            const f32x2 ol = __builtin_elementwise_fma((lo2(cw[u % 2][j]) - m2) * r2, lo2(gm[j]), lo2(bt[j]));
+            const f32x2 oh = __builtin_elementwise_fma((hi2(cw[u % 2][j]) - m2) * r2, hi2(gm[j]), hi2(bt[j]));
+            om[j] = fmaxf(fmaxf(fabsf(ol.x), fabsf(ol.y)), fmaxf(fmaxf(fabsf(oh.x), fabsf(oh.y)), om[j]));
+            o[j] = __builtin_shufflevector(ol, oh, 0, 1, 2, 3);
+          }
         }
-      }
-      if (i >= 1) {
-        const float4 n0 = *reinterpret_cast<const float4*>(&ring[(i - 1) & 1][0][co]);
-        float4 n1 = n0;
-        if (S == 2) n1 = *reinterpret_cast<const float4*>(&ring[(i - 1) & 1][S - 1][co]);
-        const int s = i - D;
+        // The three 1 KB stores of a wave are spread over the interval (start / after the convs / before the barrier): issued
+        // together, the nine B-waves' 27 KB overran the CU's store queue and the waves sat in the issue of the burst
+        // instead of computing (stores only: 117 us against 97 us for a bare fill of the same bytes).
+        auto put = [&](int j) { if (wr) __builtin_nontemporal_store(o[j], reinterpret_cast<f32x4*>(yb[j] + (long)sf * C)); };
+        put(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // group i - 1 of the ring (interval 0 reads nothing that is used)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) cpp[j] = cp[j];
-        if (s >= 0 && s < nsteps) {                             // token s: rows (p0, p1, n0)
+        for (int r = 0; r < S; ++r) hw[(u + NH - 1) % NH][r] = *reinterpret_cast<const f32x4*>(&ring[(i - 1) & 1][r][co]);
+        const int s = i - D;
+        if (s >= 0 && s < nsteps) {                             // token s
+          f32x4 p0 = S == 1 ? hw[u % 3][0] : hw[u % 2][0], n0 = S == 1 ? hw[(u + 2) % 3][0] : hw[(u + 1) % 2][0];
+          const f32x4& p1 = S == 1 ? hw[(u + 1) % 3][0] : hw[u % 2][S - 1];
+          if (S * (t0 + s) - 1 < 0) p0 = splat4(0.f);           // the conv's zero padding: rows -1 and T (first / last token of a clip)
+          if (S * (t0 + s) + 1 >= T) n0 = splat4(0.f);
           float sm[6];
           if (S * (t0 + s) < len) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-              float4 cj;
-              cj.x = wa[j].x * p0.x + wa[j].y * p1.x + wa[j].z * n0.x;
-              cj.y = wa[j].w * p0.y + wb[j].x * p1.y + wb[j].y * n0.y;
-              cj.z = wb[j].z * p0.z + wb[j].w * p1.z + wc[j].x * n0.z;
-              cj.w = wc[j].y * p0.w + wc[j].z * p1.w + wc[j].w * n0.w;
-              cp[j] = cj;
-              sm[2 * j] = (cj.x + cj.y) + (cj.z + cj.w);
-              sm[2 * j + 1] = (cj.x * cj.x + cj.y * cj.y) + (cj.z * cj.z + cj.w * cj.w);
+              const f32x4 cj = w0[j] * p0 + w1[j] * p1 + w2[j] * n0;
+              cw[u % 2][j] = cj;
+              const f32x2 cl = lo2(cj), ch = hi2(cj);
+              const f32x2 s1 = cl + ch, s2 = __builtin_elementwise_fma(cl, cl, ch * ch);
+              sm[2 * j] = s1.x + s1.y;
+              sm[2 * j + 1] = s2.x + s2.y;
             }
           } else {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { cp[j] = f4(0.f); sm[2 * j] = 0.f; sm[2 * j + 1] = 0.f; }
+            for (int j = 0; j < 3; ++j) { cw[u % 2][j] = splat4(0.f); sm[2 * j] = 0.f; sm[2 * j + 1] = 0.f; }
           }
+          __builtin_amdgcn_sched_barrier(0);
+          put(1);
+          __builtin_amdgcn_sched_barrier(0);
           const float r4 = wave_sum4(sm[0], sm[1], sm[2], sm[3]);      // rows: sm0, sm2, sm1, sm3
           const float r2 = wave_sum2(sm[4], sm[5]);                    // rows 0-1: sm4, rows 2-3: sm5
           if ((lane & 15) == 0) {
@@ -503,13 +548,19 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
             bpart[i & 1][((row & 1) << 1) | (row >> 1)][c] = r4;
             if (!(row & 1)) bpart[i & 1][4 + (row >> 1)][c] = r2;
           }
+        } else {
+          put(1);
         }
-        if (S == 1) { p0 = p1; p1 = n0; } else { p0 = n0; p1 = n1; }
+        __builtin_amdgcn_sched_barrier(0);
+        put(2);
+        lds_barrier();
       }
-      lds_barrier();
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { const float m = wave_max(omax[j]); if (lane == 0) wmax[j][c] = m; }
+    for (int j = 0; j < 3; ++j) {
+      const float m = wave_max(om[j]);
+      if (lane == 0) wmax[j][c] = m;
+    }
     lds_barrier();
     float* ap = lane == 0 ? a.amax[0] : lane == 1 ? a.amax[1] : a.amax[2];
     if (c == 0 && lane < 3 && ap) {                             // one partial per workgroup; unused slots of the table: 0
