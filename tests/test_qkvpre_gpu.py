@@ -31,6 +31,14 @@ def test_qkv_pre_fwd_bwd(dev, C, stride, want_h):
     _check(dev, 2, 48, C, stride, want_h)
 
 
+@pytest.mark.parametrize("C", [256, 512, 768, 1024, 1280, 1536, 1792, 2048, 2304])
+@pytest.mark.parametrize("stride,want_h", [(1, False), (2, True)])
+def test_qkv_pre_ring_kernel_all_widths(dev, C, stride, want_h):
+    """2 x 320 tokens: enough rows for the ring kernel (producer / consumer waves around an LDS row ring; one instantiation
+    per C / 256 and stride), with several runs per clip, a ragged clip and the zero-padding rows at both clip ends"""
+    _check(dev, 2, 320, C, stride, want_h)
+
+
 @pytest.mark.parametrize("stride,want_h", [(1, True), (2, False)])
 def test_qkv_pre_at_the_target_shape(dev, stride, want_h):
     """the shape the north-star HBM target is quoted on (and bench.py times): [2, T = 2304, C = 2304], forward and

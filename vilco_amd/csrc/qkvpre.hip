@@ -826,10 +826,12 @@ int ring_mode() {          // VILCO_QKV_RING: 1 = always, 0 = never, unset = whe
   static const int m = [] { const char* e = getenv("VILCO_QKV_RING"); return e ? atoi(e) : -1; }();
   return m;
 }
-bool use_ring(const QkvArgs& a) {
+// Device time, forward, ring vs three-pass (r03, graph replays): [8,2304,2304] 112 vs 226 us, [2,2304,2304] 34 vs 66,
+// [2,2304,1024] 20 vs 31, [2,576,1024] stride 2 13.5 vs 18; only runs too short to fill the pipeline lose ([2,256,512]: 12 vs 10).
+bool use_ring(int B, int T, int stride) {
   const int m = ring_mode();
   if (m >= 0) return m != 0;
-  return false;
+  return (long)B * (T / stride) >= 256;
 }
 template <int S>
 void launch_ring(QkvArgs a, int npart, hipStream_t s) {
@@ -845,7 +847,7 @@ void launch_ring(QkvArgs a, int npart, hipStream_t s) {
 
 bool launch_fwd(const QkvArgs& a, hipStream_t s, int npart) {
   if (a.C % 256 != 0) return false;
-  if (use_ring(a)) {
+  if (use_ring(a.B, a.T, a.stride) && !forced_tb()) {
     if (a.stride == 1) launch_ring<1>(a, npart, s); else launch_ring<2>(a, npart, s);
     return true;
   }
@@ -865,6 +867,10 @@ bool launch_fwd(const QkvArgs& a, hipStream_t s, int npart) {
 
 extern "C" int vilco_qkv_pre_amax_parts(int32_t B, int32_t T, int32_t stride) {
   if (B <= 0 || T <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (use_ring(B, T, stride) && !forced_tb()) {                 // ring kernel: one partial per workgroup
+    const int Tout = T / stride;
+    return B * ((Tout + ring_seg(B, Tout) - 1) / ring_seg(B, Tout));
+  }
   const long waves = (long)B * ((T / stride + 1) / 2);          // TB = 2 tokens per wave, both strides (launch_fwd)
   return waves <= 4096 ? (int)waves : 0;                        // more partials than that cost the packs more than an amax launch
 }
