@@ -141,3 +141,54 @@ def test_sharded_validation_equals_single_rank():
     want = sorted(zip(single['video-id'], single['t-start'].tolist(), single['label'].tolist()))
     for rank, vids, starts, labels in got:
         assert sorted(zip(vids, starts, labels)) == want
+
+
+class _LossModel(torch.nn.Module):
+    """the `model(video_list) -> {'final_loss': ...}` contract of on_task_update"""
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(6, 3)
+        self.reg_params = {}
+
+    def forward(self, batch):
+        return {'final_loss': self.lin(batch).pow(2).sum()}
+
+
+def _ewc_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vilco_amd.cl_methods import regularizers
+    torch.manual_seed(0)
+    out = {}
+    for kind in ('ewc', 'mas'):
+        model = _LossModel()
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        loader = [torch.randn(4, 6, generator=torch.Generator().manual_seed(10 * rank + i)) for i in range(2)]
+        reg = regularizers.on_task_update(loader, 'cpu', opt, model, kind=kind, data_parallel=True)
+        key = 'fisher' if kind == 'ewc' else 'importance'
+        model.zero_grad(set_to_none=True)
+        model(loader[-1])['final_loss'].backward()          # this rank's own last-batch gradient
+        g = model.lin.weight.grad
+        out[kind] = (reg[key][-1]['lin.weight'].numpy(), (g.pow(2) if kind == 'ewc' else g.abs()).numpy())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ewc_mas_importance_is_averaged_over_ranks():
+    """under data parallelism every rank takes the importance from the last batch of ITS shard; the penalty is
+    applied after the gradient exchange, so the importances must agree -- on_task_update averages them over the group"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ewc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for kind in ('ewc', 'mas'):
+        want = (res[0][kind][1] + res[1][kind][1]) / 2
+        assert not np.allclose(res[0][kind][1], res[1][kind][1])          # the shards really differ
+        assert np.allclose(res[0][kind][0], want, atol=1e-6) and np.allclose(res[1][kind][0], want, atol=1e-6)

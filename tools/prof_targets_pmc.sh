@@ -6,5 +6,5 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ptf /tmp/ptw
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/ptf -o f -- python3 $R/tools/bench_targets.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/ptw -o w -- python3 $R/tools/bench_targets.py > /dev/null 2>&1
-python3 $R/tools/pmc_summary.py /tmp/ptf/f_counter_collection.csv $R/gpurun_out/${TAG:-r02_z}_targets_pmc_fetch.json | grep -i qkv
-python3 $R/tools/pmc_summary.py /tmp/ptw/w_counter_collection.csv $R/gpurun_out/${TAG:-r02_z}_targets_pmc_write.json | grep -i qkv
+python3 $R/tools/pmc_summary.py /tmp/ptf/f_counter_collection.csv $R/gpurun_out/${TAG:-r03_z}_targets_pmc_fetch.json | grep -i qkv
+python3 $R/tools/pmc_summary.py /tmp/ptw/w_counter_collection.csv $R/gpurun_out/${TAG:-r03_z}_targets_pmc_write.json | grep -i qkv

@@ -16,3 +16,4 @@ python3 tools/gemm_shapes.py 3 > gpurun_out/${TAG}_gemm_shapes.txt 2>/dev/null
 TAG=${TAG}_targets bash tools/prof_targets.sh > /dev/null 2>&1
 bash tools/prof_attn_pmc.sh > gpurun_out/${TAG}_attn_insts.txt 2>&1
 ls -la $R/gpurun_out | grep ${TAG}
+TAG=${TAG} bash tools/prof_targets_pmc.sh > gpurun_out/${TAG}_targets_pmc.txt 2>&1

@@ -74,10 +74,13 @@ def get_regularized_loss(loss, model, reg_lambda, kind='ewc'):
     return loss
 
 
-def on_task_update(loader_task, device, optimizer, model, kind='ewc'):
+def on_task_update(loader_task, device, optimizer, model, kind='ewc', group=None, data_parallel=False):
     """importance of the weights after a task (EWC.py:24-56 / MAS.py:23-57): one pass over the task's loader with
     zero_grad before every batch -- so, as in the reference, what is kept is the LAST batch's gradient (squared for
-    EWC, absolute for MAS) -- plus a copy of the parameters."""
+    EWC, absolute for MAS) -- plus a copy of the parameters.
+    data_parallel / group: the run is data parallel over `group` (None = the default group).  Every rank sees the last batch of ITS shard, so the importances
+    are averaged over the ranks (the reference wraps this pass in no DDP hook and lets them differ; the penalty is
+    applied after the gradient exchange, so different importances would pull the replicas apart)."""
     model.train()
     reg = model.reg_params
     key = 'fisher' if kind == 'ewc' else 'importance'
@@ -92,6 +95,11 @@ def on_task_update(loader_task, device, optimizer, model, kind='ewc'):
             opt_d[name] = p.data.clone()
             g = p.grad.data.clone()
             imp_d[name] = g.pow(2) if kind == 'ewc' else g.abs()
+    if data_parallel and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+        ws = float(torch.distributed.get_world_size(group))
+        for name in sorted(imp_d):                      # the same order on every rank
+            torch.distributed.all_reduce(imp_d[name], group=group)
+            imp_d[name].div_(ws)
     reg[key].append(imp_d)
     reg['optpar'].append(opt_d)
     return reg

@@ -8,11 +8,12 @@
 // each): 4*C*T read + 3*4*C*T' written per clip against 15 passes.  HBM-bound; the north-star target kernel
 // (">= 60 % of HBM bandwidth on the 1-D conv FPN at T = C = 2304").
 //
-// Mapping: a 256-thread block walks a segment of SEG consecutive output tokens of one clip; thread i owns channels
-// i, i + 256, ... (CPT = C / 256 of them), so every global access is a fully coalesced 1 KB line per instruction and a
-// token's LayerNorm statistics are two block reductions (exact two-pass mean / variance, as the stand-alone kernel).
-// The normalised input rows t-1, t, t+1 slide through registers: every x row is read once (plus one halo row per
-// segment side), every h row normalised once per segment.
+// Forward mapping (r03, qkv_pre_fwd_ring_kernel; the three-pass qkv_pre_fwd_kernel serves runs too short to fill the
+// pipeline): one workgroup of 3 + C/256 waves walks a run of consecutive output tokens of one clip.  Three producer
+// waves bring the x rows in (loads in flight for 5 barrier intervals), normalise them ONCE and park them in a two-group
+// LDS ring; C/256 consumer waves, each owning one 256-channel chunk with its 15 parameters in registers, read the ring,
+// convolve, reduce and write.  One workgroup barrier per token, every x row read once, every output row written once:
+// 111 us at [8, 2304, 2304] = 6.1 TB/s of algorithmic bytes = 0.77 of the 8 TB/s HBM peak (three-pass kernel: 226 us).
 //
 // Backward (qkv_pre_bwd_*): the conv outputs are never stored -- they are recomputed from h in registers.
 //   rows:    per output token, x_hat_j from (h, stats), LayerNorm backward -> d(conv out)_j written (3 tensors)
@@ -572,15 +573,15 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
   }
 }
 
-// Two other forward structures were built and measured at [8, 2304, 2304] (r02; this kernel: 230 us) and removed:
-//   * rows of a 4-token tile normalised once into LDS, one token per wave: 288 us -- x is read 1.5x instead of 6x, but
-//     every wave re-loads the 17 per-channel parameter quads per token and pass;
-//   * channel-split tiles (a wave owns 256 channels of 6 tokens, rows and parameters in registers, statistics combined
-//     across the waves through LDS): 295 us -- ~55 wavefront reductions and their bookkeeping per 72 outputs of a lane
-//     make it issue-bound (5600 instructions per wave).
-// What bounds THIS kernel is real HBM traffic: rocprofv3 FETCH_SIZE / WRITE_SIZE (profiles/r02_z_targets_pmc_*.json)
-// show x fetched 3.6x (the rows a wave re-reads in passes 1 and 2 have left the 4 MB L2 of its XCD: ~14 MB of rows are in
-// flight per XCD), i.e. 1.12 GB moved for 0.68 GB of algorithmic bytes, at 4.9 TB/s.
+// Other forward structures built and measured at [8, 2304, 2304] and removed (r02 / r03):
+//   * rows of a 4-token tile normalised once into LDS, one token per wave: 288 us -- every wave re-loads the 17
+//     per-channel parameter quads per token and pass;
+//   * channel-split tiles (a wave owns 256 channels of 6 tokens, statistics combined across the waves through LDS, every
+//     wave doing every stage): 295 us / 227 us -- ~55 wavefront reductions per 72 outputs of a lane, issue-bound; as a
+//     persistent sliding window it spilled.  The ring kernel keeps the channel split but separates the stages into
+//     producer and consumer waves and reduces six sums jointly (wave_sum4 / wave_sum2).
+// What bounded the three-pass kernel is real HBM traffic: rocprofv3 FETCH_SIZE / WRITE_SIZE (profiles/r02_z_targets_pmc_*.json)
+// show x fetched 3.6x (the rows a wave re-reads in passes 1 and 2 have left the 4 MB L2 of its XCD).
 
 // ---------------------------------------------------------------------------------------------------- backward, rows
 struct QkvBwdArgs {

@@ -153,9 +153,9 @@ def run_episodes(cfg, model, train_stream, validate=None, ckpt_folder=None, gpu_
         if num_next is not None:
             model.augment_classification(num_next, torch.device('cuda', gpu_id))
             if cfg['cl_cfg']['name'] == 'ewc':
-                model.reg_params = regularizers.on_task_update(loader, gpu_id, optimizer, model, kind='ewc')
+                model.reg_params = regularizers.on_task_update(loader, gpu_id, optimizer, model, kind='ewc', group=getattr(reducer, 'group', None), data_parallel=reducer is not None)
             elif cfg['cl_cfg']['name'] == 'mas':
-                model.reg_params = regularizers.on_task_update(loader, gpu_id, optimizer, model, kind='mas')
+                model.reg_params = regularizers.on_task_update(loader, gpu_id, optimizer, model, kind='mas', group=getattr(reducer, 'group', None), data_parallel=reducer is not None)
             optimizer = make_optimizer(model, cfg['opt'])
             scheduler = make_scheduler(optimizer, cfg['opt'], iters_per_epoch)
             if reducer is not None:

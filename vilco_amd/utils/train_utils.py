@@ -321,6 +321,19 @@ class AverageMeter(object):
             self.avg = self.sum / self.count
 
 
+def check_grid_sync():
+    """With VILCO_GRID_SYNC=1 the two-stage reductions finish inside their launch behind a device-wide barrier whose spin
+    is bounded (common.h: vilco_grid_barrier): a barrier that gave up leaves sums built from incomplete partials.  The
+    count of such give-ups is checked once per epoch (it synchronises the device) and is fatal."""
+    if os.environ.get("VILCO_GRID_SYNC", "0") != "1":
+        return
+    from .. import _lib
+    n = _lib.load().vilco_sync_timeouts_read()
+    if n != 0:
+        raise RuntimeError("vilco: %d in-launch grid barrier(s) timed out -- results of this epoch are invalid "
+                           "(run without VILCO_GRID_SYNC=1)" % n)
+
+
 def train_one_epoch(train_loader, model, optimizer, scheduler, curr_epoch, n_gpu=1, model_ema=None,
                     clip_grad_l2norm=-1, tb_writer=None, print_freq=20, logger=None, cl_name=None, reg_lambda=0.0,
                     prev_out_cls_logits_dict=None, current_task_id=0, reducer=None, graph=None, keep_history=True):
@@ -382,6 +395,7 @@ def train_one_epoch(train_loader, model, optimizer, scheduler, curr_epoch, n_gpu
                 curr_epoch, iter_idx, len(train_loader), tracker['final_loss'].val, tracker['final_loss'].avg))
     if logger is not None:
         logger.info("[Train]: Epoch {:d} finished with lr={:.8f}\n".format(curr_epoch, scheduler.get_last_lr()[0]))
+    check_grid_sync()
     return history
 
 
