@@ -383,9 +383,9 @@ int vilco_store_f32(float* dst, const float* vals, int32_t n, void* stream);
 /* weight, gam_j / bet_j the [C] LayerNorm affine (the reference's [1,C,1] tensors).  mean1 / rstd1 [B*T] and       */
 /* mean_j / rstd_j [B*T/stride] are kept for backward; h may be NULL.  C must be a multiple of 256, at most 2304.   */
 /* Backward recomputes the conv outputs from h: dc_j (scratch, [B][T/stride][C] each) receives the gradient wrt the  */
-/* masked conv outputs, dh = dh_ext (may be NULL) + the conv-transpose of the three; dparams [15][C] = d gam_q,     */
-/* d bet_q, d gam_k, d bet_k, d gam_v, d bet_v, then d w_j[tap] as [j][tap][C] planes.  LN1's own backward is         */
-/* vilco_layernorm_bwd on (dh, x, mean1, rstd1).                                                                    */
+/* masked conv outputs, dh = dh_ext (may be NULL) + the conv-transpose of the three; dparams (15 C floats) = d gam_q, */
+/* d bet_q, d gam_k, d bet_k, d gam_v, d bet_v as [6][C], then d w_q, d w_k, d w_v as [3][C][3] (each the weight's    */
+/* own [C][1][3] layout).  LN1's own backward is vilco_layernorm_bwd on (dh, x, mean1, rstd1).                       */
 /* ------------------------------------------------------------------------------------------ */
 int vilco_qkv_pre_supported(int32_t C);
 /* amax_parts (may be NULL): three device arrays of vilco_qkv_pre_amax_parts(B, T, stride) floats that receive the        */

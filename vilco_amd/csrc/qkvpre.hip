@@ -718,9 +718,15 @@ __global__ __launch_bounds__(QT) void qkv_pre_bwd_params_kernel(QkvBwdArgs a, fl
     use(r, x0); use(r + 1, x1);
   }
   if (r < r1) { RowIn x0; fetch(r, x0); use(r, x0); }
-  float* p = partial + (long)blockIdx.x * 15 * C + c;
+  // partial row: [6][C] LayerNorm gradients, then the tap gradients in the WEIGHT's own layout [j][C][3], so that the
+  // reduced row holds d w_j ready to be viewed as [C, 1, 3] (no transposing copy per weight on the host side)
+  float* p = partial + (long)blockIdx.x * 15 * C;
 #pragma unroll
-  for (int i = 0; i < 15; ++i) p[(long)i * C] = acc[i];
+  for (int i = 0; i < 6; ++i) p[(long)i * C + c] = acc[i];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[(long)(6 + 3 * j) * C + c * 3 + k] = acc[6 + 3 * j + k];
 }
 
 // dh[b][t][c] = dh_ext + sum_j sum_tap w_j[c][tap] * dc_j[b][t'][c],  s*t' + tap - 1 == t
@@ -903,8 +909,8 @@ extern "C" size_t vilco_qkv_pre_bwd_workspace(int32_t B, int32_t T, int32_t C, i
   return (size_t)param_blocks((long)B * (T / stride)) * 15 * (size_t)C * sizeof(float);
 }
 
-// dparams = [15][C]: d gamma_q, d beta_q, d gamma_k, d beta_k, d gamma_v, d beta_v, then d w_q[tap 0..2], d w_k, d w_v as
-// [j][tap][C] planes (the caller re-lays them to the [C][1][3] weight shape)
+// dparams = 15 C floats: d gamma_q, d beta_q, d gamma_k, d beta_k, d gamma_v, d beta_v as [6][C], then d w_q, d w_k, d w_v
+// as [j][C][3] -- each the weight's own [C][1][3] layout
 extern "C" int vilco_qkv_pre_bwd(const float* h, const float* const* w, const float* const* gam, const float* const* dy,
                                  const float* const* mean, const float* const* rstd, const int32_t* len,
                                  const float* dh_ext, float* const* dc, float* dh, float* dparams, int32_t B, int32_t T,

@@ -1374,7 +1374,7 @@ class _QkvPre(torch.autograd.Function):
         _lib.check(lib.vilco_layernorm_bwd(dh.data_ptr(), x.data_ptr(), None, _p(g1), stats1[0].data_ptr(), stats1[1].data_ptr(),
                                            dx.data_ptr(), dg1.data_ptr(), db1.data_ptr(), B * T, Cn, 0, ws1.data_ptr(),
                                            ws1.numel(), _stream()))
-        dws = [dpar[6 + 3 * j:9 + 3 * j].t().contiguous().view_as(w) for j, w in enumerate((wq, wk, wv))]
+        dws = [dpar[6 + 3 * j:9 + 3 * j].view_as(w) for j, w in enumerate((wq, wk, wv))]      # already [C][1][3] (qkvpre.hip)
         dgs = [dpar[2 * j].view_as(g) for j, g in enumerate((gq, gk, gv))]
         dbs = [dpar[2 * j + 1].view_as(g) for j, g in enumerate((gq, gk, gv))]
         return (dx, dg1.view_as(g1), db1.view_as(g1), dws[0], dws[1], dws[2], dgs[0], dbs[0], dgs[1], dbs[1], dgs[2], dbs[2],
