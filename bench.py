@@ -414,7 +414,7 @@ def main():
 def side_config(name, dev, steps=10, warm=2):
     """fwd+bwd clips/s of another BASELINE / SURVEY 8d configuration, a few steps only (side line, not the headline):
     "W" = config P with D = 2304 (hd = 144, no XLNet layer; 9874 GFLOP/clip), "cfg1" = BASELINE configs[0] (T = 256,
-    Cin = 512, D = 512, H = 4, XLNet layer, 53.4 GFLOP/clip).  Head dims above 64 run the materialised-score attention."""
+    Cin = 512, D = 512, H = 4, XLNet layer, 53.4 GFLOP/clip).  Both run the fused attention kernels (head dims up to 160)."""
     import vilco_amd.modeling as vm
     from vilco_amd.core.config import make_config
     if name == "W":

@@ -293,7 +293,8 @@ def _attn_ref(q, k, v, lens, H, scale, xl=False):
 @pytest.mark.parametrize("flash", [True, False])
 @pytest.mark.parametrize("B,Tq,Tk,H,hd", [(2, 64, 64, 4, 16), (2, 40, 77, 4, 16), (1, 130, 130, 2, 64), (2, 32, 5, 4, 8),
                                           (2, 200, 157, 3, 32), (1, 96, 300, 2, 64), (1, 64, 64, 2, 128), (2, 200, 157, 2, 128),
-                                          (1, 130, 300, 1, 96), (2, 77, 77, 3, 72)])
+                                          (1, 130, 300, 1, 96), (2, 77, 77, 3, 72),
+                                          (2, 200, 157, 2, 144), (1, 130, 300, 1, 160), (2, 70, 70, 2, 132)])      # 129..160: the 160-wide tiles (config W: 144)
 def test_attention(dev, B, Tq, Tk, H, hd, flash):
     from vilco_amd import ops
     ops.use_flash = flash
@@ -397,7 +398,7 @@ def test_dropout_op(dev):
     assert not torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("T,hd", [(100, 16), (130, 64), (130, 128)])
+@pytest.mark.parametrize("T,hd", [(100, 16), (130, 64), (130, 128), (130, 144)])
 def test_attention_prob_dropout(dev, T, hd):
     """attention with dropout on the probabilities == reference attention with the same mask (fwd + grads)."""
     from vilco_amd import ops

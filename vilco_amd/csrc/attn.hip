@@ -38,6 +38,10 @@ template <int W>
 __device__ __forceinline__ int swzc(int row, int chunk) {
   if (W == 32) return chunk ^ ((4 - ((row >> 2) & 3)) & 3);
   if (W == 64) return chunk ^ ((row >> 1) & 7);
+  // W == 160 (head dims 129..160, config W's 144): five 32-element groups, each swizzled like a W == 32 row.  The row
+  // stride is 80 dwords = 16 mod 64 banks -- the W == 32 tile's stride -- so a fragment read (16 rows x one group) meets
+  // exactly the W == 32 bank pattern, shifted by a constant.
+  if (W == 160) return (chunk & ~3) | ((chunk & 3) ^ ((4 - ((row >> 2) & 3)) & 3));
   return chunk ^ (row & 15);   // W == 128
 }
 template <int W>
@@ -153,6 +157,7 @@ __device__ __forceinline__ void lstore_tile(const TileStage<W, R, NP>& st, __bf1
 // the XOR of 4 chunks (32 elements), so every address is fb plus compile-time constants.
 template <int W>
 __device__ __forceinline__ bf16x8 frag(const __bf16* tile, int fb, int row_add, int ks) {
+  if (W == 160) return *reinterpret_cast<const bf16x8*>(tile + fb + row_add * W + (ks << 5));   // the group is not swizzled
   return *reinterpret_cast<const bf16x8*>(tile + ((fb + row_add * W) ^ (ks << 5)));
 }
 
@@ -184,8 +189,8 @@ __device__ __forceinline__ f32x4 mfma_parts(const bf16x8 (&a)[3], const bf16x8 (
 // which is < 2^15 because |dP|, |delta| <= hd * amax(dO) * amax(V) with hd <= 64 and amax * s < 2^15.
 constexpr float P_SCALE = 32768.f, P_INV = 1.f / 32768.f, DS_SCALE = 1.f / 4194304.f, DS_INV = 4194304.f;
 // the general kernels at head dims 65..128: |dP| <= hd * 2^30 doubles, so dS carries one more power of two (2^-23)
-template <int HDP> constexpr float ds_scale() { return HDP > 64 ? 0.5f * DS_SCALE : DS_SCALE; }
-template <int HDP> constexpr float ds_inv() { return HDP > 64 ? 2.f * DS_INV : DS_INV; }
+template <int HDP> constexpr float ds_scale() { return HDP > 128 ? 0.25f * DS_SCALE : (HDP > 64 ? 0.5f * DS_SCALE : DS_SCALE); }
+template <int HDP> constexpr float ds_inv() { return HDP > 128 ? 4.f * DS_INV : (HDP > 64 ? 2.f * DS_INV : DS_INV); }
 struct AttnScales { float iq, sq, ik, sk, iv, sv, ido, sdo; };    // {1/s, s} of q, k, v, dO (pack.h order)
 
 struct AttnArgs {
@@ -1491,9 +1496,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
   if (a.drop_thresh) a.drop_seed = vilco_step_seed(a.drop_seed, a.seed_word);
   constexpr int BKV = 64, BQ = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);          // [NP][64 keys][HDP]
-  __bf16* sV = sK + NP * BKV * HDP;                           // [NP][64 keys][HDP]
-  __bf16* sQ = sV + NP * BKV * HDP;                           // [NP][32 q][HDP]
+  // HDP > 128 (head dims 129..160): K and V tiles + the Q / dO tiles would need 180 KB of LDS.  The K fragments a wave
+  // uses never change (its 32 keys, all k-steps), so they are read into registers once -- through the region the Q / dO
+  // tiles take over afterwards -- and the kernel keeps 139 KB (both K and V in registers spilled).
+  constexpr bool KV_REG = HDP > 128;
+  __bf16* sV = reinterpret_cast<__bf16*>(smem_raw);          // [NP][64 keys][HDP]
+  __bf16* sK = sV + NP * BKV * HDP;                           // [NP][64 keys][HDP]
+  __bf16* sQ = KV_REG ? sK : sK + NP * BKV * HDP;             // [NP][32 q][HDP]
   __bf16* sdO = sQ + NP * BQ * HDP;                           // [NP][32 q][HDP]
   __bf16* sQt = sdO + NP * BQ * HDP;                          // [NP][HDP d][32 q]
   __bf16* sdOt = sQt + NP * HDP * BQ;                         // [NP][HDP d][32 q]
@@ -1531,6 +1540,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
 
   // S / dP tiles: wave -> (m-tile of 16 queries = wave & 1, key half = wave >> 1 : 2 n-tiles of 16 keys)
   const int mq = wave & 1, kh = wave >> 1;
+  bf16x8 kreg[KV_REG ? 2 : 1][KV_REG ? HDP / 32 : 1][3];
+  if constexpr (KV_REG) {
+    __syncthreads();
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int ks = 0; ks < HDP / 32; ++ks)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) kreg[nj][ks][q] = frag<HDP>(sK + q * BKV * HDP, fbH, kh * 32 + nj * 16, ks);
+  }
   // dV^T / dK^T accumulators: wave owns keys [wave*16, wave*16+16) (n-tile), all d (HDP/16 m-tiles)
   f32x4 dvacc[HDP / 16], dkacc[HDP / 16];
 #pragma unroll
@@ -1642,7 +1661,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkdv_kernel(AttnArgs a) 
         for (int q = 0; q < NP; ++q) {
           qa[q] = frag<HDP>(sQ + q * BQ * HDP, fbH, mq * 16, ks);
           da[q] = frag<HDP>(sdO + q * BQ * HDP, fbH, mq * 16, ks);
-          kb[q] = frag<HDP>(sK + q * BKV * HDP, fbH, ncol, ks);
+          if constexpr (KV_REG) kb[q] = kreg[nj][ks][q];
+          else kb[q] = frag<HDP>(sK + q * BKV * HDP, fbH, ncol, ks);
           vb[q] = frag<HDP>(sV + q * BKV * HDP, fbH, ncol, ks);
         }
         s = mfma_parts<NP, F16>(qa, kb, s);        // S  = Q K^T
@@ -1720,7 +1740,9 @@ size_t fwd_lds() { return (size_t)NP * (64 * HDP + HDP * 64 + 4 * 16 * 64) * siz
 template <int HDP, int NP>
 size_t dq_lds() { return (size_t)NP * (3 * 64 * HDP + 4 * 16 * 64) * sizeof(__bf16); }
 template <int HDP, int NP>
-size_t dkdv_lds() { return (size_t)NP * (2 * 64 * HDP + 4 * 32 * HDP + 2 * 64 * 32) * sizeof(__bf16); }
+size_t dkdv_lds() {        // HDP > 128: the K tile is staged through the Q / dO region (attn_bwd_dkdv_kernel: KV_REG)
+  return (size_t)NP * ((HDP > 128 ? 64 * HDP : 2 * 64 * HDP) + 4 * 32 * HDP + 2 * 64 * 32) * sizeof(__bf16);
+}
 
 template <typename K>
 void set_lds(K kernel, size_t bytes) {
@@ -1830,18 +1852,20 @@ int dispatch(const AttnArgs& a, int precision, bool bwd, hipStream_t s) {
   if (precision == 1) return bwd ? launch_bwd<HDP, 1>(a, s) : launch_fwd<HDP, 1>(a, s);
   if (precision == 0) return bwd ? launch_bwd<HDP, 2>(a, s) : launch_fwd<HDP, 2>(a, s);
   if (precision == 3) return bwd ? launch_bwd<HDP, 2, true>(a, s) : launch_fwd<HDP, 2, true>(a, s);
-  return bwd ? launch_bwd<HDP, 3>(a, s) : launch_fwd<HDP, 3>(a, s);
+  if constexpr (HDP <= 64) return bwd ? launch_bwd<HDP, 3>(a, s) : launch_fwd<HDP, 3>(a, s);
+  else return VILCO_ERR_UNSUPPORTED;               // three bf16 planes of a wider tile exceed the LDS (check_common)
 }
 
 int check_common(int B, int H, int Tq, int Tk, int hd, int mode, int precision, int window = 0) {
   if (B < 0 || H <= 0 || Tq < 0 || Tk < 0 || hd <= 0) return VILCO_ERR_BADARG;
   if (mode < 0 || mode > 4 || precision < 0 || precision > 3 || (mode == 4 && (window < 0 || Tq != Tk))) return VILCO_ERR_BADARG;
-  if (hd > 128 || (hd % 4) != 0) return VILCO_ERR_UNSUPPORTED;      // head dims 4..128 (P: 64, cfg1: 128, tests: 8, 16, 32)
+  if (hd > 160 || (hd % 4) != 0) return VILCO_ERR_UNSUPPORTED;      // head dims 4..160 (P: 64, cfg1: 128, W: 144, tests: 8, 16, 32)
   if (hd > 64 && precision == 2) return VILCO_ERR_UNSUPPORTED;      // three bf16 planes of a 128-wide tile exceed the 160 KB LDS (dkdv)
   return VILCO_OK;
 }
 
 inline long up(long x, long a) { return (x + a - 1) / a * a; }
+inline int hdp_of(int hd) { return hd <= 32 ? 32 : (hd <= 64 ? 64 : (hd <= 128 ? 128 : 160)); }   // padded head width of the tiles
 inline int np_of(int precision) { return precision == 1 ? 1 : ((precision == 0 || precision == 3) ? 2 : 3); }
 constexpr long ATT_SCALE_BYTES = 4 * AMAX_MAX_BLOCKS * 4 + 256;    // fp16 x2: amax partials of q, k, v, dO + AttnScales
 
@@ -1965,7 +1989,7 @@ extern "C" int vilco_lab_attn_read(unsigned long long* out) {
 }
 #endif
 
-extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 128 && (hd % 4) == 0; }
+extern "C" int vilco_attn_supported(int32_t hd) { return hd > 0 && hd <= 160 && (hd % 4) == 0; }
 
 extern "C" int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_t hd, int32_t mode, int32_t precision,
                                          int32_t has_bias, float drop_p, int32_t key_side) {
@@ -1984,7 +2008,7 @@ extern "C" int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_
 }
 
 extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
-  const int HDP = hd <= 32 ? 32 : (hd <= 64 ? 64 : 128), NP = np_of(precision);
+  const int HDP = hdp_of(hd), NP = np_of(precision);
   return (size_t)(planes_bytes(spec_nat(B, H, Tq, HDP), NP) + planes_bytes(spec_nat(B, H, Tk, HDP), NP) +
                   planes_bytes(spec_tr(B, H, Tk, hd), NP) + 1024 + ATT_SCALE_BYTES);
 }
@@ -2003,7 +2027,7 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   if (Tk == 0) return VILCO_ERR_BADARG;
   if (!workspace || workspace_bytes < vilco_attn_fwd_workspace(B, H, Tq, Tk, hd, precision)) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int HDP = hd <= 32 ? 32 : (hd <= 64 ? 64 : 128), NP = np_of(precision);
+  const int HDP = hdp_of(hd), NP = np_of(precision);
   AttnArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = o; a.lse = lse; a.kv_len = kv_len;
   a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.hd = hd; a.C = H * hd; a.scale = scale; a.mode = mode; a.window = window;
@@ -2029,11 +2053,11 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   else
     a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
   flush_packs(pq, sw, precision == 3, NP, B * H, s);
-  return hd <= 32 ? dispatch<32>(a, precision, false, s) : (hd <= 64 ? dispatch<64>(a, precision, false, s) : dispatch<128>(a, precision, false, s));
+  return hd <= 32 ? dispatch<32>(a, precision, false, s) : (hd <= 64 ? dispatch<64>(a, precision, false, s) : (hd <= 128 ? dispatch<128>(a, precision, false, s) : dispatch<160>(a, precision, false, s)));
 }
 
 extern "C" size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
-  const int HDP = hd <= 32 ? 32 : (hd <= 64 ? 64 : 128), NP = np_of(precision);
+  const int HDP = hdp_of(hd), NP = np_of(precision);
   long bytes = 2 * planes_bytes(spec_nat(B, H, Tq, HDP), NP) + 2 * planes_bytes(spec_tr(B, H, Tq, hd), NP) +
                2 * planes_bytes(spec_nat(B, H, Tk, HDP), NP) + planes_bytes(spec_tr(B, H, Tk, hd), NP);
   bytes += up((long)B * H * (Tq > 0 ? Tq : 1) * 4, 256) + 1024 + ATT_SCALE_BYTES;
@@ -2055,7 +2079,7 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   if (Tk == 0) return VILCO_ERR_BADARG;
   if (!workspace || workspace_bytes < vilco_attn_bwd_workspace(B, H, Tq, Tk, hd, precision)) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int HDP = hd <= 32 ? 32 : (hd <= 64 ? 64 : 128), NP = np_of(precision);
+  const int HDP = hdp_of(hd), NP = np_of(precision);
   unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
   float* delta = reinterpret_cast<float*>(wsb);
   wsb += up((long)B * H * Tq * 4, 256);
@@ -2091,5 +2115,5 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   a.vn = pack_operand(v, w, spec_nat(B, H, Tk, HDP), false, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
   if (!nat_only) a.kt = pack_operand(k, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[1], sw.n[1], so + 2, &pq);
   flush_packs(pq, sw, precision == 3, NP, B * H, s);
-  return hd <= 32 ? dispatch<32>(a, precision, true, s) : (hd <= 64 ? dispatch<64>(a, precision, true, s) : dispatch<128>(a, precision, true, s));
+  return hd <= 32 ? dispatch<32>(a, precision, true, s) : (hd <= 64 ? dispatch<64>(a, precision, true, s) : (hd <= 128 ? dispatch<128>(a, precision, true, s) : dispatch<160>(a, precision, true, s)));
 }

@@ -1031,9 +1031,9 @@ def attention(q, k, v, kv_len, n_head, scale=None, mode=MASK_KEYS, drop_p=0.0, w
             _FlashAttention.last_amax = None
         return o
     if mode == MASK_LOCAL:
-        raise NotImplementedError("local-window attention needs the fused kernels (head dim <= 128, multiple of 4)")
+        raise NotImplementedError("local-window attention needs the fused kernels (head dim <= 160, multiple of 4)")
     if drop_p > 0.0:
-        raise NotImplementedError("attention dropout needs the fused kernels (head dim <= 128, multiple of 4)")
+        raise NotImplementedError("attention dropout needs the fused kernels (head dim <= 160, multiple of 4)")
     return _Attention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode))
 
 
@@ -1162,7 +1162,7 @@ def rel_attention(qw, qr, k, v, kr, kv_len, n_head, scale, drop_p=0.0):
     if use_flash and flash_supported(qw.shape[-1] // n_head):
         return _FlashRelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale), float(drop_p))
     if drop_p > 0.0 or kr.dim() == 3:
-        raise NotImplementedError("XLNet dropout needs the fused attention kernels (head dim <= 128, multiple of 4)")
+        raise NotImplementedError("XLNet dropout needs the fused attention kernels (head dim <= 160, multiple of 4)")
     return _RelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale))
 
 
