@@ -228,7 +228,7 @@ int vilco_relshift_bwd(const float* ds, float* dbd, float scale, int32_t B, int3
 /* mask modes as vilco_softmax_fwd (+ 3: XLNet mask with the bias given as unshifted position scores [B,H,Tq,Tq+Tk]; */
 /* + 4: sliding window |i - j| <= window below kv_len, Tq == Tk -- NLQ's LocalMaskedMHCA, NLQ/libs/modeling/blocks.py   */
 /* :417-755; only the key tiles a query tile's windows reach are visited);                                           */
-/* precision as vilco_gemm.  hd <= 128 (<= 64 in bf16 x3), hd % 4 == 0.  drop_p > 0: inverted dropout on the attention probabilities      */
+/* precision as vilco_gemm.  hd <= 160 (<= 64 in bf16 x3), hd % 4 == 0.  drop_p > 0: inverted dropout on the attention probabilities      */
 /* (after the softmax, before P V) with the counter-based mask of vilco_dropout: element (bh*Tq + i)*Tk + j of stream   */
 /* drop_seed; forward and backward must be given the same (drop_p, drop_seed).                                         */
 /* ------------------------------------------------------------------------------------------ */
