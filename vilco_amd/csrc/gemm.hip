@@ -20,6 +20,7 @@
 #include <mutex>
 #include <utility>
 #include <vector>
+#include <type_traits>
 #include "common.h"
 #include "pack.h"
 
@@ -350,6 +351,38 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   const int kt0b = kb;
   const int nk = kt1 - kt0b;
 
+#ifndef VILCO_GEMM_DEPTH2
+#define VILCO_GEMM_DEPTH2 1
+#endif
+  // D2: staging loads issued TWO K-steps ahead into a second register set (tiles alternate between the sets); every load
+  // is unconditional (the K offset is clamped to the last tile) so that the compiler's vmcnt model sees no join between a
+  // load and its use and leaves exactly the younger tile's loads in flight at the wait.
+  constexpr bool D2 = VILCO_GEMM_DEPTH2 && !K2 && BM <= 192 && NP == 2 && F16;
+  bf16x8 stA2[D2 ? NP : 1][D2 ? RA : 1], stB2[D2 ? NP : 1][D2 ? RB : 1];
+  auto gload2 = [&](int kt, auto& sa_, auto& sb_) {
+    if (kt > kt1 - 1) kt = kt1 - 1;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int sa = (int)(2 * (long)kt * stepA), sb = (int)(2 * (long)kt * stepB);
+#pragma unroll
+      for (int r = 0; r < RA; ++r)
+        sa_[q][r] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsA[q], (int)voffA[r], sa, 0));
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+        sb_[q][r] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB[q], (int)voffB[r], sb, 0));
+    }
+  };
+  auto lstore2 = [&](int st, const auto& sa_, const auto& sb_) {
+    __bf16* s = smem + st * NP * TILE;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int r = 0; r < RA; ++r)
+        if (r + 1 < RA || tailA) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsA[r]) = sa_[q][r];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) *reinterpret_cast<bf16x8*>(s + q * TILE + ldsB[r]) = sb_[q][r];
+    }
+  };
   bf16x8 stA[NP][RA], stB[NP][RB];
   auto gload = [&](int kt) {
 #pragma unroll
@@ -378,7 +411,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
     }
   };
 
-  if (nk > 0) {
+  if constexpr (D2) {
+    if (nk > 0) {                          // tile 0 -> LDS; tiles 1 (set "stA2") and 2 (set "stA") in flight
+      gload2(kt0b, stA, stB);
+      lstore2(0, stA, stB);
+      gload2(kt0b + 1, stA2, stB2);
+      __builtin_amdgcn_sched_barrier(0);   // the two tiles' loads stay in tile order (the loop's vmcnt waits count on it)
+      gload2(kt0b + 2, stA, stB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if (nk > 0) {
     gload(kt0b);
     lstore(0);
     if (nk > 1) gload(kt0b + 1);
@@ -468,9 +510,63 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 #endif
   };
 
-  // ONE barrier per K-step.  Group 0 runs [MEM(t) MFMA(t)] between barriers, group 1 [MFMA(t-1) MEM(t)]: the two
-  // waves of a SIMD are always in opposite phases, and the barrier sits exactly where the LDS hazards are
-  // (tile t+1 complete / tile t fully consumed before anyone starts MEM(t+1)).
+  // D2 MEM phase of K-step t (odd tiles live in stA2 / stB2, even ones in stA / stB): tile t+1 -> LDS from its set, then
+  // that set takes tile t+3.  Past the end the last tile is loaded / stored again: its LDS stage is never read.
+  auto mem_phase2 = [&](int t, auto odd_) {
+    const bool odd = decltype(odd_)::value;
+    frag_reads(t);
+    __builtin_amdgcn_sched_barrier(0);
+    if (odd) { lstore2((t + 1) & 1, stA, stB); gload2(kt0b + t + 3, stA, stB); }
+    else { lstore2((t + 1) & 1, stA2, stB2); gload2(kt0b + t + 3, stA2, stB2); }
+  };
+  if constexpr (D2) {
+    // pairs of K-steps with NO conditional inside the loop body (a skipped second half would reach the loop header with
+    // the two register sets' loads in the opposite age order, and the compiler's vmcnt model would drain both); an odd
+    // last K-step runs after the loop
+    int t = 0;
+    if (!late) {
+      for (; t + 1 < nk; t += 2) {
+        mem_phase2(t, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        mem_phase2(t + 1, std::true_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+      }
+      if (t < nk) {
+        mem_phase2(t, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+      }
+    } else {
+      for (; t + 1 < nk; t += 2) {
+        if (t > 0) mfma_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        mem_phase2(t, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        mfma_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        mem_phase2(t + 1, std::true_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+      }
+      if (t < nk) {
+        if (t > 0) mfma_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        mem_phase2(t, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+      }
+      if (nk > 0) mfma_phase();
+    }
+  } else
   if (!late) {
     for (int t = 0; t < nk; ++t) {
       STAMP(0);
