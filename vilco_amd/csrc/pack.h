@@ -93,6 +93,14 @@ struct PackArgs {
   float* inv_scale;    // fmt 1: where block 0 leaves {1/s, s} for the consumer kernel
 };
 
+// workgroups of a kc pack: every block folds the amax partials before it can scale anything (a load round trip, a block
+// reduction and a barrier), so more blocks than the chip holds at once only repeat that prologue: 768 = three per CU
+// (r03, tools/lab/pack_time.py, [4608, 1024]: 2048 -> 14.3 us, 1024 -> 13.7, 768 -> 13.4, 512 -> 13.6, 256 -> 14.4)
+inline long kc_cap() {
+  static const long cap = [] { const char* e = getenv("VILCO_PACK_CAP"); const long v = e ? atol(e) : 0; return v > 0 ? v : 768L; }();
+  return cap;
+}
+
 template <int NP>
 __device__ __forceinline__ void pack_kc_body(const PackArgs& a, int z, int bx, int nbx) {
   const int zo = z / a.nbi, zi = z % a.nbi;
@@ -147,6 +155,33 @@ __device__ __forceinline__ void pack_kc_body(const PackArgs& a, int z, int bx, i
   };
   // The first item's source values are requested BEFORE the scale is folded out of the amax partials (a load, a block
   // reduction and a barrier of its own): the two round trips overlap instead of following each other.
+  if (a.tap == 0 && a.vec && a.K == a.Kp && a.out_rows <= a.rows && total < (1L << 31)) {
+    // the plain case (an activation or a weight, whole rows): 32-bit item arithmetic, two items of a thread in flight
+    const int tot = (int)total, st = nbx * (int)blockDim.x;
+    int i = bx * (int)blockDim.x + (int)threadIdx.x;
+    auto ld8 = [&](int it, float4& v0, float4& v1) {
+      const int row = it / chunks, k0 = (it - row * chunks) * 8;
+      const float* p = src + (long)row * a.ld + k0;
+      v0 = *reinterpret_cast<const float4*>(p); v1 = *reinterpret_cast<const float4*>(p + 4);
+    };
+    float4 a0, a1, b0, b1;
+    const int ic = i < tot ? i : tot - 1, jc = i + st < tot ? i + st : tot - 1;      // clamped: loads are unconditional
+    if (tot > 0) { ld8(ic, a0, a1); ld8(jc, b0, b1); }
+    const float fs = a.amax ? f16_scale_from(a.amax, a.namax, a.inv_scale, bx == 0 && z == 0 && threadIdx.x == 0) : 0.f;
+    while (i < tot) {
+      const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      bf16x8 part[3];
+      splitN<NP>(v, part, fs);
+      const long o = (long)i * 8;                                   // width == Kp == chunks * 8: item i starts at element 8 i
+      a0 = b0; a1 = b1;
+      const int nn = i + 2 * st < tot ? i + 2 * st : tot - 1;
+      ld8(nn, b0, b1);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(dst + q * a.plane_stride + o) = part[q];
+      i += st;
+    }
+    return;
+  }
   const long step = (long)nbx * blockDim.x;
   long i = (long)bx * blockDim.x + threadIdx.x;
   float v[8];
@@ -345,7 +380,7 @@ void launch_pack(const PackArgs& a, bool tr, int nbatch, hipStream_t s) {
   if (!tr) {
     const int width = (a.tap == 1) ? a.tapC : a.Kp;
     long blocks = ((long)a.out_rows * (width / 8) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > kc_cap()) blocks = kc_cap();
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((pack_kc_kernel<NP>), dim3((int)blocks, 1, nbatch), dim3(256), 0, s, a);
   } else {
@@ -359,7 +394,7 @@ void launch_pack(const PackArgs& a, bool tr, int nbatch, hipStream_t s) {
 inline int kc_blocks(const PackArgs& a) {
   const int width = (a.tap == 1) ? a.tapC : a.Kp;
   long blocks = ((long)a.out_rows * (width / 8) + 255) / 256;
-  return (int)(blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks));
+  return (int)(blocks > kc_cap() ? kc_cap() : (blocks < 1 ? 1 : blocks));
 }
 
 // ------------------------------------------------------------------------------------------ amax + pack in ONE launch
