@@ -39,6 +39,13 @@ def test_qkv_pre_ring_kernel_all_widths(dev, C, stride, want_h):
     _check(dev, 2, 320, C, stride, want_h)
 
 
+@pytest.mark.parametrize("B,T,C,stride", [(2, 322, 512, 2), (3, 100, 256, 1), (5, 97, 768, 1), (1, 514, 1024, 2), (2, 131, 2304, 1)])
+def test_qkv_pre_ring_kernel_odd_shapes(dev, B, T, C, stride):
+    """ring kernel at awkward sizes: runs that do not divide T, odd T at stride 1, a
+    single clip, more clips than pipeline depth"""
+    _check(dev, B, T, C, stride, True, lens=[T - 7 * (b % 3) for b in range(B)])
+
+
 @pytest.mark.parametrize("stride,want_h", [(1, True), (2, False)])
 def test_qkv_pre_at_the_target_shape(dev, stride, want_h):
     """the shape the north-star HBM target is quoted on (and bench.py times): [2, T = 2304, C = 2304], forward and
@@ -46,12 +53,13 @@ def test_qkv_pre_at_the_target_shape(dev, stride, want_h):
     _check(dev, 2, 2304, 2304, stride, want_h)
 
 
-def _check(dev, B, T, C, stride, want_h):
+def _check(dev, B, T, C, stride, want_h, lens=None):
     from vilco_amd import ops
     torch.manual_seed(C + stride)
     x = torch.randn(B, T, C, dtype=torch.float64)
-    lens = torch.tensor([T, T - 13])
-    x[1, T - 13:] = 0.0                                   # inputs are masked upstream
+    lens = torch.tensor([T, T - 13] if lens is None else lens)
+    for b in range(B):
+        x[b, int(lens[b]):] = 0.0                         # inputs are masked upstream
     g1, b1 = 1 + 0.1 * torch.randn(C, dtype=torch.float64), 0.1 * torch.randn(C, dtype=torch.float64)
     ws = [0.5 * torch.randn(C, 1, 3, dtype=torch.float64) for _ in range(3)]
     gs = [1 + 0.1 * torch.randn(C, dtype=torch.float64) for _ in range(3)]

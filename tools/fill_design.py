@@ -2,7 +2,7 @@
 python tools/fill_design.py r02_z   (profiles/<tag>_bench.json, profiles/<tag>_bench_kernel_stats.csv)."""
 import csv, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_z"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_z"
 d = json.loads(open(os.path.join(ROOT, "profiles", tag + "_bench.json")).read().strip().splitlines()[-1])
 r = d["roofline"]
 stats = os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv")
@@ -43,6 +43,6 @@ for k, v in rep.items():
     t = t.replace(k, v)
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-a, b = s.index("## 5. Measurement (round 2"), s.index("## 6. Next (ordered)")
+a, b = s.index("## 5. Measurement (round"), s.index("## 6. Next (ordered)")
 open(p, "w").write(s[:a] + t + s[b:])
 print("DESIGN.md section 5 filled from", tag, ": %.1f ms/step, %s launches/step" % (d["ms_per_step"], launches))
