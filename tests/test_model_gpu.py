@@ -146,6 +146,56 @@ def test_cfg1_shape_vs_oracle(dev):
     assert worst[0] < TOL, worst
 
 
+def test_w_head_width_vs_oracle(dev):
+    """config W's head width (hd = 144: D = 288 over H = 2 heads here, no XLNet layer as in W, T = 256, B = 2): the whole
+    model on the 160-wide fused attention tiles (self-attention at every level and the 77-key cross-attention), fwd + bwd
+    vs the float64 oracle"""
+    import vilco_amd.modeling as vm
+    from oracle import mq_oracle as O
+    from vilco_amd import ops
+    from vilco_amd.core.config import make_config
+    import cases
+    assert ops.flash_supported(144)
+    over = cases.overrides(D=288, T=256, Cin=384, Ctxt=768, H=2, use_xl=False, droppath=0.1)
+    cfg = make_config(**over)['model']
+    torch.manual_seed(0)
+    model = vm.make_meta_arch('LocPointTransformer', **cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if 'drop_path' in n_:
+                p_.fill_(0.3)
+    model.eval()
+    vl = cases.video_list(256, 384, 768, 77)
+    p64 = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in model.state_dict().items()}
+    vl64 = [{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()} for d in vl]
+    want, _ = O.forward_losses(p64, cfg, vl64)
+    want['final_loss'].backward()
+    model = model.to(dev)
+    model.loss_normalizer = cfg['train_cfg']['init_loss_norm']
+    losses = model(vl, is_training=True)
+    losses['final_loss'].backward()
+    for k in ('cls_loss', 'reg_loss', 'final_loss'):
+        assert rel_err(losses[k], want[k]) < TOL, (k, float(losses[k]), float(want[k]))
+    # Without the XLNet layer stem[0] is applied twice (backbones.py:276-278) and its second application sees the UNMASKED
+    # channel-attention output of the padded rows; the LayerNorm backward of such a near-constant row multiplies its
+    # gradient by rstd ~ 300 per norm, so the first padded row of the short clip carries gradients ~1e10 x the typical
+    # element (measured: dq max 5e3 against a 99th percentile of 2e-6).  fp32 carries that range per element; the fp16 x2
+    # planes carry ONE power-of-two scale per tensor, so everything else in that tensor keeps only a few bits.  The rows
+    # are multiplied by zeros further down (their inputs are masked constants), which is why every other gradient holds
+    # the 1e-3 bar -- the two weights fed directly by that tensor do not (DESIGN.md section 7).
+    loose = ('backbone.stem.0.channel_attn.attn.qkv.weight', 'backbone.stem.0.channel_attn.attn.proj.weight')
+    worst, worst_loose = (0.0, None), (0.0, None)
+    for k, p in model.named_parameters():
+        if p64[k].grad is not None and p.grad is not None:
+            e = rel_err(p.grad, p64[k].grad, GRAD_FLOOR)
+            if k in loose:
+                worst_loose = max(worst_loose, (e, k))
+            elif e > worst[0]:
+                worst = (e, k)
+    assert worst[0] < TOL, worst
+    assert worst_loose[0] < 2e-2, worst_loose
+
+
 def test_two_part_split_mode_accuracy(dev):
     """precision 'split' (3 MFMAs): forward matches to 1e-4; gradients are ~1e-5 in the median, but a
     pre-activation within ~1e-5 of zero can flip a ReLU derivative, which moves single rows of the
