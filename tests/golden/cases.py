@@ -232,3 +232,41 @@ def icarl_clip(idx, labels=(0, 1)):
 def icarl_memory():
     """{class: [exemplar clips]}: two per class, insertion order = class order"""
     return {c: [icarl_clip(10 * c + k, (c, (c + 1) % IC_NCLS)) for k in range(2)] for c in range(IC_NCLS)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# NLQ episode case (BASELINE configs[3] scaled down): 3 query-template tasks of the NLQ driver (NLQ/train_cl.py:177-342) on
+# the small model of nlq_model_cfg(): per task a fresh optimizer with the head / backbone learning-rate groups
+# (NLQ/libs/utils/train_utils.py:63-240, backbone_lr_weight != 1), warm-up + cosine schedule per iteration, replay memory
+# (memory_size // 13 queries per template), validation records in the evaluator's input format (:735-746).
+NLQ_EP_TASKS, NLQ_EP_PER_TASK, NLQ_EP_BATCH = 3, 4, 2
+NLQ_EP_MEMORY = 26                      # -> m = 26 // 13 = 2 queries kept per template
+
+
+def nlq_episode_opt(backbone_lr_weight=0.5):
+    return dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-3, backbone_lr_weight=backbone_lr_weight,
+                coef_lr=1, epochs=1, warmup=True, warmup_epochs=1, schedule_type="cosine", schedule_steps=[], schedule_gamma=0.1)
+
+
+def nlq_episode_query(task, k):
+    """query k of template `task`: clip features [Cv, t], query tokens [Ct, L], one or two moments, evaluator ids"""
+    idx = 10 * task + k
+    g = torch.Generator().manual_seed(7000 + idx)
+    t = NLQ_M_T - 7 * (idx % 4)
+    L = 5 + idx % 5
+    s0 = 4.0 + 3 * (idx % 6)
+    segs = [[s0, s0 + 6.5 + idx % 3]] + ([[50.0, 70.25 + idx % 4]] if idx % 2 else [])
+    return {'video_id': 'clip%02d' % idx, 'query_id': 'ann%02d_%d' % (idx, k), 'feats': torch.randn(NLQ_CV, t, generator=g),
+            'query_feats': torch.randn(NLQ_CT, L, generator=g), 'segments': torch.tensor(segs),
+            'one_hot_labels': torch.ones(len(segs), 1), 'fps': 30.0, 'duration': 60.0 + idx, 'feat_stride': 16.043,
+            'feat_num_frames': 16.043}
+
+
+def nlq_episode_data(task):
+    """{template name: [query dicts]} of task `task` (the value of the reference's data['train'][template])"""
+    return {'template_%d' % task: [nlq_episode_query(task, k) for k in range(NLQ_EP_PER_TASK)]}
+
+
+def nlq_episode_metric(results):
+    """stand-in for ReferringRecall (the evaluator is outside the hot path): mean top-1 confidence of the records"""
+    return float(sum(r['predicted_times'][0][2] for r in results) / max(len(results), 1))

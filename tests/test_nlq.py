@@ -261,3 +261,150 @@ def test_meta_arch_training_replayed_as_hipgraphs(dev):
     for k in sa:
         if sa[k].is_floating_point() and not k.endswith(NOISE):
             assert torch.equal(sa[k], sb[k]) or rel_err(sb[k], sa[k], 1e-7) < 1e-5, k
+
+
+# ------------------------------------------------------------------------------------------------------- episode (f-2)
+def _gold_episode():
+    return torch.load(os.path.join(HERE, "golden", "nlq_episode.pt"), weights_only=False)
+
+
+def test_param_groups_and_schedule_vs_reference():
+    """NLQ's make_optimizer in both modes (default: decay / no-decay / encoder twins; head_backbone_group: four head /
+    backbone groups with their own learning rates) against the membership lists, decay and LR values recorded from the
+    imported NLQ/libs/utils/train_utils.py, and the per-iteration LR sequence of every group over the first task"""
+    import json
+    import vilco_amd.modeling_nlq as nlq
+    from vilco_amd.utils import train_utils_nlq as tu
+    with open(os.path.join(HERE, "golden", "nlq_train_glue.json")) as f:
+        glue = json.load(f)
+    model = nlq.make_meta_arch('LocPointTransformer', **cases.nlq_model_cfg())
+    names = {id(p): n for n, p in model.named_parameters()}
+    for mode, (hb, w) in (('default', (False, 1)), ('head_backbone', (True, 0.5))):
+        opt = tu.make_optimizer(model, cases.nlq_episode_opt(w), head_backbone_group=hb)
+        assert len(opt.param_groups) == len(glue[mode]) == 4
+        for g, want in zip(opt.param_groups, glue[mode]):
+            assert [names[id(p)] for p in g['params']] == want['names']
+            assert g['weight_decay'] == want['weight_decay'] and abs(g['lr'] - want['lr']) <= 1e-12
+    opt = tu.make_optimizer(model, cases.nlq_episode_opt(0.5), head_backbone_group=True)
+    gold = _gold_episode()['tasks'][0]
+    sch = tu.make_scheduler(opt, cases.nlq_episode_opt(0.5), gold['n_batches'])
+    for want in gold['lrs']:
+        got = [g['lr'] for g in opt.param_groups]
+        assert all(abs(a - b) <= 1e-12 + 1e-9 * abs(b) for a, b in zip(got, want)), (got, want)
+        sch.step()
+    # a parameter no rule classifies: the head / backbone mode refuses it (:199-202), the default mode leaves it out (:208-213)
+    model.stray = torch.nn.Parameter(torch.zeros(3))
+    with pytest.raises(AssertionError):
+        tu.param_groups(model, True)
+    assert all('stray' not in n for g in tu.param_groups(model, False) for n in g)
+    # the "constant" schedule of NLQ's make_scheduler: linear warm-up, then the base rate
+    del model.stray
+    opt = tu.make_optimizer(model, cases.nlq_episode_opt(1))
+    sch = tu.make_scheduler(opt, dict(cases.nlq_episode_opt(1), schedule_type="constant", warmup_epochs=2), 2)
+    seq = []
+    for _ in range(6):
+        seq.append(opt.param_groups[0]['lr'])
+        sch.step()
+    assert all(abs(a - b) < 1e-12 for a, b in zip(seq, [0.0, 1e-3 / 3, 2e-3 / 3, 1e-3, 1e-3, 1e-3])), seq
+
+
+class _ValTasks:
+    def get_valSet_by_taskNum(self, n):
+        return [([[q] for q in list(cases.nlq_episode_data(k).values())[0]], 1) for k in range(n)]
+
+
+class _Recorder:
+    dataset = "ego4d_cl"
+
+    def __init__(self):
+        self.calls = []
+
+    def evaluate(self, results, verbose=True):
+        import numpy as np
+        self.calls.append([dict(r) for r in results])
+        return np.array([[cases.nlq_episode_metric(results)]]), ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_nlq_episode_reproduces_reference(dev, tmp_path, use_graph):
+    """BASELINE configs[3] scaled down: three query-template tasks through vilco_amd.train_cl.run_episodes_nlq (head / backbone
+    optimizer groups, warm-up + cosine per iteration, validation records, best-checkpoint files, replay memory) against the
+    recording of the imported reference driving its own make_optimizer / train_one_epoch / valid_one_epoch_cl_single_gpu /
+    final_validate (tests/golden/make_golden_nlq_episode.py)"""
+    import random
+    import vilco_amd.modeling_nlq as nlq
+    from parity_util import delta_err
+    from vilco_amd.train_cl import run_episodes_nlq
+    from vilco_amd.utils.cl_stream import InMemoryQILStream
+    gold = _gold_episode()
+    mcfg = cases.nlq_model_cfg()
+    cfg = {'opt': cases.nlq_episode_opt(0.5), 'train_cfg': mcfg['train_cfg'],
+           'cl_cfg': dict(mcfg['cl_cfg'], memory_size=cases.NLQ_EP_MEMORY, path_memory='mem.pkl')}
+    model = nlq.make_meta_arch('LocPointTransformer', **mcfg)
+    model.load_state_dict(gold['init_state'], strict=True)
+    model = model.to(dev)
+    stream = InMemoryQILStream([cases.nlq_episode_data(j) for j in range(cases.NLQ_EP_TASKS)], batch_size=cases.NLQ_EP_BATCH,
+                               shuffle=False)
+    rec = _Recorder()
+    last_epoch = cfg['opt']['epochs'] + cfg['opt']['warmup_epochs'] - 1
+    lrs = {}
+
+    def on_validate(kind, j, epoch, r1):
+        if kind == 'epoch' and epoch == last_epoch:
+            random.seed(1000 + j)                        # the memory shuffle that follows (the recording seeds it the same way)
+
+    import vilco_amd.utils.train_utils_nlq as tu
+    make0 = tu.make_scheduler
+
+    def rec_make(optimizer, *a, **k):
+        sch = make0(optimizer, *a, **k)
+        step0 = sch.step
+
+        def step(*aa, **kk):                             # the rates the iteration that just ran was stepped with
+            lrs.setdefault(id(sch), []).append([g['lr'] for g in optimizer.param_groups])
+            return step0(*aa, **kk)
+        sch.step = step
+        return sch
+    tu.make_scheduler = rec_make
+    try:
+        model, opt, sch, log = run_episodes_nlq(cfg, model, stream, _ValTasks(), rec, ckpt_folder=str(tmp_path), ckpt_freq=2,
+                                                use_graph=use_graph, on_validate=on_validate)
+    finally:
+        tu.make_scheduler = make0
+    assert len(log) == cases.NLQ_EP_TASKS
+    init = gold['init_state']
+    call = 0
+    for j, (entry, want) in enumerate(zip(log, gold['tasks'])):
+        assert abs(entry['init_R1'] - want['init_R1']) <= 2e-2 * abs(want['init_R1']), (j, entry['init_R1'], want['init_R1'])
+        for e, (hist, wl) in enumerate(zip(entry['history'], want['losses'])):
+            assert len(hist) == len(wl)
+            for i, (h, w) in enumerate(zip(hist, wl)):
+                for k in w:
+                    assert abs(float(h[k]) - w[k]) <= 5e-3 * max(abs(w[k]), 1e-3), (j, e, i, k, float(h[k]), w[k])
+        assert [ep for ep, _ in entry['R1']] == list(range(len(want['R1'])))
+        for (_, a), b in zip(entry['R1'], want['R1']):
+            assert abs(a - b) <= 2e-2 * abs(b), (j, a, b)
+        assert entry['best_epoch'] == want['best_epoch']
+        assert os.path.exists(os.path.join(str(tmp_path), 'Best_task_%02d.pth.tar' % j))
+        ck = torch.load(os.path.join(str(tmp_path), 'Best_task_%02d.pth.tar' % j), weights_only=False)
+        assert set(ck) == {'epoch', 'state_dict', 'scheduler', 'optimizer', 'current_task', 'reg_params'} and ck['current_task'] == j
+        # the task's best state (what every later task starts from) against the reference's, as the error of the UPDATE
+        errs = sorted(((delta_err(ck['state_dict'][k].cpu(), init[k], w, init[k]), k) for k, w in want['state'].items()
+                       if w.is_floating_point() and not k.endswith(NOISE)), reverse=True)
+        assert errs[0][0] < 0.2 and errs[len(errs) // 2][0] < 2e-2, (j, errs[:6], errs[len(errs) // 2])
+    # learning rates of all four groups, every optimisation step of the episode
+    got_lrs = [x for seq in lrs.values() for x in seq]
+    want_lrs = [x for t in gold['tasks'] for x in t['lrs']]
+    assert len(got_lrs) == len(want_lrs)
+    assert all(abs(a - b) <= 1e-12 + 1e-9 * abs(b) for g, w in zip(got_lrs, want_lrs) for a, b in zip(g, w))
+    # replay memory after the last task and the records of the last final validation (the evaluator's input format)
+    assert {c: [v['query_id'] for v in vs] for c, vs in model.memory.items()} == gold['tasks'][-1]['memory_ids']
+    assert model.n_known == cases.NLQ_EP_TASKS
+    got, want = rec.calls[-1], gold['tasks'][-1]['results']
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert set(a) == set(b) == {'query_idx', 'annotation_uid', 'predicted_times', 'clip_uid'}
+        assert (a['query_idx'], a['annotation_uid'], a['clip_uid']) == (b['query_idx'], b['annotation_uid'], b['clip_uid'])
+        assert len(a['predicted_times']) == len(b['predicted_times']) and all(len(r) == 3 for r in a['predicted_times'])
+        assert abs(a['predicted_times'][0][2] - b['predicted_times'][0][2]) <= 5e-2 * abs(b['predicted_times'][0][2])

@@ -162,3 +162,112 @@ def run_episodes(cfg, model, train_stream, validate=None, ckpt_folder=None, gpu_
                 reducer.rebuild()          # the class head and the gaussian parameters are new tensors
             graph = make_graph(optimizer)  # new parameters, new optimizer: the old task's graphs are dropped
     return model, optimizer, scheduler, log
+
+
+def run_episodes_nlq(cfg, model, train_stream, val_stream, evaluator, ckpt_folder=None, gpu_id=0, start_task=0,
+                     start_epoch=0, ckpt_freq=2, reducer=None, print_freq=100, use_graph=False, keep_history=True,
+                     on_validate=None):
+    """Episode loop of the NLQ driver (BASELINE configs[3]; NLQ/train_cl.py:113-342), which differs from the MQ loop in
+    what surrounds the training iterations:
+
+      optimizer: NLQ's make_optimizer, with the head / backbone learning-rate groups when opt.backbone_lr_weight != 1
+          (:115-118), created anew for every task (:331-336); the scheduler keeps the FIRST task's iterations per epoch (:123)
+      per task j: R@1 of the incoming model over templates 0..j (:181-183) is the bar the epochs have to reach
+          (is_best = R1 >= best_R1, :265); validation after epoch e when e is the last one or e % ckpt_freq == 0 (:216-222);
+          the best state goes to 'Best_task_{j:02d}.pth.tar' (keys epoch / state_dict / scheduler / optimizer / current_task /
+          reg_params, :269-276)
+      replay memory: m = memory_size // 13 queries per template (:293-299 -- 13 is the benchmark's template count,
+          hard-wired there), add_samples_to_mem, stream.memory = model.memory, n_known = j + 1 (:303-308), memory pickle
+      reload of the task's best checkpoint (:315), final validation over all learnt templates (:317-318), and -- when
+          another task follows -- EWC / MAS consolidation (:325-329); no class-head growth (one query class)
+
+    val_stream: `get_valSet_by_taskNum(n)` -> [(loader with batch size 1, #templates), ...] (cl_benchmark.py:60-74);
+    evaluator: `.dataset`, `.evaluate(records, verbose) -> (performance[[R@1, ...]], str)` (libs/utils/metrics.py
+    ReferringRecall; outside the hot path).  on_validate(kind, task, epoch, r1) is called after every validation.
+    Returns (model, optimizer, scheduler, log)."""
+    from .utils import train_utils_nlq as tu
+    is_main = int(os.environ.get("LOCAL_RANK", "0")) == 0
+    hb = cfg['opt']["backbone_lr_weight"] != 1
+
+    def new_optimizer():
+        return tu.make_optimizer(model, cfg['opt'], head_backbone_group=hb)
+
+    def make_graph(opt):
+        if not use_graph:
+            return None
+        from .graph import GraphedStep
+        return GraphedStep(model, opt, clip_grad_l2norm=cfg['train_cfg']['clip_grad_l2norm'], reducer=reducer)
+    optimizer = new_optimizer()
+    graph = make_graph(optimizer)
+    it = iter(train_stream)
+    num_tasks = train_stream.num_tasks
+    data, loader, num_next = next(it)
+    iters_per_epoch = len(loader)
+    scheduler = tu.make_scheduler(optimizer, cfg['opt'], iters_per_epoch)
+    max_epochs = cfg['opt'].get('early_stop_epochs', cfg['opt']['epochs'] + cfg['opt']['warmup_epochs'])
+    memory_size = cfg['cl_cfg']['memory_size']
+    recalls = {'val': [], 'test': []}
+    log = []
+
+    def validate(kind, j, epoch):
+        fn = tu.final_validate if kind == 'final' else tu.valid_one_epoch_cl_single_gpu
+        kw = dict(list_val_recall_ii=recalls, type_val='val') if kind == 'final' else {}
+        r1 = fn(val_stream, model, epoch, j, evaluator=evaluator, print_freq=print_freq, **kw)
+        model.train()
+        if on_validate is not None:
+            on_validate(kind, j, epoch, r1)
+        return r1
+
+    for j in range(start_task, num_tasks):
+        if j != 0:
+            data, loader, num_next = next(it)
+        entry = {'task': j, 'history': [], 'R1': []}
+        best = entry['init_R1'] = validate('init', j, 0)
+        best_epoch = -1
+        prev_logits = cache_prev_logits(model, loader, j, as_numpy=True) if model.type_sampling == 'icarl' else {}
+        ck_name = 'Best_task_{:02d}.pth.tar'.format(j)
+        for epoch in range(start_epoch, max_epochs):
+            sampler = getattr(loader, 'sampler', None)
+            if sampler is not None and hasattr(sampler, 'set_epoch'):
+                sampler.set_epoch(epoch)
+            if model.use_adapter:
+                model.pre_train_epoch(task_id=j, current_epoch=epoch)
+            hist = tu.train_one_epoch(loader, model, optimizer, scheduler, epoch, model_ema=None,
+                                      clip_grad_l2norm=cfg['train_cfg']['clip_grad_l2norm'], print_freq=print_freq,
+                                      cl_name=cfg['cl_cfg']['name'], reg_lambda=cfg['cl_cfg']['reg_lambda'],
+                                      prev_out_cls_logits_dict=prev_logits, current_task_id=j, reducer=reducer, graph=graph,
+                                      keep_history=keep_history)
+            if keep_history:
+                entry['history'].append(hist)
+            if epoch == max_epochs - 1 or (ckpt_freq > 0 and epoch % ckpt_freq == 0):
+                r1 = validate('epoch', j, epoch)
+                entry['R1'].append((epoch, r1))
+                if r1 >= best:
+                    best, best_epoch = r1, epoch
+                    if is_main and ckpt_folder is not None:
+                        save_checkpoint({'epoch': epoch, 'state_dict': model.state_dict(), 'scheduler': scheduler.state_dict(),
+                                         'optimizer': optimizer.state_dict(), 'current_task': j, 'reg_params': model.reg_params},
+                                        file_folder=ckpt_folder, file_name=ck_name)
+                _barrier(reducer)
+        entry['best_R1'], entry['best_epoch'] = best, best_epoch
+        if memory_size != 0:
+            model.add_samples_to_mem(val_stream, data, 'ALL' if memory_size == 'ALL' else memory_size // 13)
+        train_stream.memory = model.memory
+        model.n_known = j + 1
+        if ckpt_folder is not None:
+            if is_main:
+                os.makedirs(ckpt_folder, exist_ok=True)
+                with open(os.path.join(ckpt_folder, cfg['cl_cfg']['path_memory']), 'wb') as h:
+                    pickle.dump(model.memory, h)
+            _barrier(reducer)
+            model = load_best_checkpoint(model, ckpt_folder, ck_name, j, gpu_id)
+        entry['final_R1'] = validate('final', j, max_epochs - 1)
+        log.append(entry)
+        if num_next is not None:
+            if cfg['cl_cfg']['name'] in ('ewc', 'mas'):
+                model.reg_params = regularizers.on_task_update(loader, gpu_id, optimizer, model, kind=cfg['cl_cfg']['name'],
+                                                               group=getattr(reducer, 'group', None), data_parallel=reducer is not None)
+            optimizer = new_optimizer()
+            scheduler = tu.make_scheduler(optimizer, cfg['opt'], iters_per_epoch)
+            graph = make_graph(optimizer)
+    return model, optimizer, scheduler, log

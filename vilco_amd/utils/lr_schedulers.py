@@ -46,3 +46,20 @@ class LinearWarmupMultiStepLR(LRScheduler):
         return [self._at(b, self.last_epoch) for b in self.base_lrs]
 
     _get_closed_form_lr = get_lr
+
+
+class WarmupLRScheduler(LRScheduler):
+    """linear warm-up to the base rates, constant afterwards (NLQ/libs/utils/lr_schedulers.py:123-185, schedule_type
+    "constant" of NLQ's make_scheduler)"""
+
+    def __init__(self, optimizer, warmup_epochs, warmup_start_lr=0.0, last_epoch=-1):
+        self.warmup_epochs, self.warmup_start_lr = warmup_epochs, warmup_start_lr
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        e, W = self.last_epoch, self.warmup_epochs
+        if e < W:
+            return [self.warmup_start_lr + e * (b - self.warmup_start_lr) / max(W - 1, 1) for b in self.base_lrs]
+        return list(self.base_lrs)
+
+    _get_closed_form_lr = get_lr
