@@ -270,3 +270,29 @@ def nlq_episode_data(task):
 def nlq_episode_metric(results):
     """stand-in for ReferringRecall (the evaluator is outside the hot path): mean top-1 confidence of the records"""
     return float(sum(r['predicted_times'][0][2] for r in results) / max(len(results), 1))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Evaluator-format case (SURVEY 8f-4): two validation tasks of two clips each on the "xl" golden model
+def eval_clips(task):
+    okw, L = CASES['xl']
+    o = overrides(**okw)
+    vl = video_list(o['dataset']['max_seq_len'], o['dataset']['input_dim'], o['model']['n_txt_in'], L, seed=50 + task)
+    for i, v in enumerate(vl):
+        v['video_id'] = 'val%d_%d' % (task, i)
+    return vl
+
+
+def eval_fake_map(results):
+    """stand-in for ANETdetection.evaluate (outside the hot path): a number determined by the records"""
+    import numpy as np
+    return float(np.mean(results['score'])) if len(results['score']) else 0.0
+
+
+def eval_fake_recall(json_obj):
+    """stand-in for evaluation_retrieval: a [5 tIoU, 2 ranks] table determined by the JSON the path wrote"""
+    import numpy as np
+    rows = [r for v in json_obj['results'].values() for r in v]
+    s = float(np.mean([r['score'] for r in rows])) if rows else 0.0
+    d = float(np.mean([r['segment'][1] - r['segment'][0] for r in rows])) if rows else 0.0
+    return np.array([[s * (i + 1) / 5.0, d / (10.0 * (i + 1))] for i in range(5)])

@@ -400,9 +400,10 @@ def train_one_epoch(train_loader, model, optimizer, scheduler, curr_epoch, n_gpu
 
 
 @torch.no_grad()
-def collect_results(val_loader, model, task_id=0):
+def collect_results(val_loader, model, task_id=0, restore_mode=True):
     """the evaluator's input format (train_utils.py:1049-1098 / 749-752): a dict of flat per-segment columns
-    {'video-id': [...], 't-start', 't-end', 'label', 'score': numpy arrays}, from eval-mode forwards (batch size 1)."""
+    {'video-id': [...], 't-start', 't-end', 'label', 'score': numpy arrays}, from eval-mode forwards (batch size 1).
+    restore_mode=False leaves the model in eval mode, as the reference's validation functions do."""
     was_training = model.training
     model.eval()
     res = {'video-id': [], 't-start': [], 't-end': [], 'label': [], 'score': []}
@@ -417,18 +418,102 @@ def collect_results(val_loader, model, task_id=0):
                 res['score'].append(out['scores'])
     for k, dt in (('t-start', torch.float32), ('t-end', torch.float32), ('label', torch.int64), ('score', torch.float32)):
         res[k] = torch.cat(res[k]).numpy() if res[k] else torch.zeros(0, dtype=dt).numpy()
-    model.train(was_training)
+    if restore_mode:
+        model.train(was_training)
     return res
 
 
-def results_to_anet_json(results, version="vilco_amd"):
-    """the ActivityNet-style submission dict the reference dumps with `output_file` (train_utils.py:771-774 via
-    libs/utils/postprocessing): {"version", "results": {video_id: [{"label", "score", "segment": [s, e]}]}, ...}"""
+def results_to_anet_json(results, idx_classes=None, version="1.0"):
+    """the ActivityNet-style object the reference dumps for the retrieval metric (train_utils.py:1118-1127, :771-774):
+    {"version": "1.0", "external_data": "", "results": {video_id: [{"segment": [s, e], "score", "label"}, ...]}} with the
+    rows of a video in result order.  idx_classes: {label id: class name} -- the reference labels rows with the NAME from
+    the Ego4D MQ class table hard-wired there (:1104); that table is dataset metadata, so it is an argument here (None keeps
+    the integer id)."""
     out = {}
     for vid, s, e, l, sc in zip(results['video-id'], results['t-start'], results['t-end'], results['label'],
                                 results['score']):
-        out.setdefault(vid, []).append({"label": int(l), "score": float(sc), "segment": [float(s), float(e)]})
-    return {"version": version, "results": out, "external_data": {}}
+        out.setdefault(vid, []).append({"segment": [float(s), float(e)], "score": float(sc),
+                                        "label": int(l) if idx_classes is None else idx_classes[int(l)]})
+    return {"version": version, "external_data": "", "results": out}
+
+
+def _validate_tasks(val_qilDatasetList, model, current_task_id, evaluator, retrieval_eval, idx_classes, ext_score_file,
+                    logger, dataset_name):
+    """the loop valid_one_epoch_cl_single_gpu and final_validate share (train_utils.py:1049-1160 / 1213-1323): every task
+    learnt so far is validated on its own loader; per task the records go (a) as the ANet JSON object to the retrieval
+    metric and (b) as the flat result dict to the evaluator.  Yields (n_task, num_queries, recall table [5 tIoU, 2 ranks]
+    or None, avg_mAP)."""
+    model.eval()
+    for b in getattr(model, 'list_bias_layers', ()):
+        b.eval()
+    for n_task, (val_loader, num_queries) in enumerate(val_qilDatasetList.get_valSet_by_taskNum(current_task_id + 1)):
+        results = collect_results(val_loader, model, task_id=current_task_id, restore_mode=False)
+        eval_result = None
+        if dataset_name in ("ego4d", "ego4d_cl") and retrieval_eval is not None:
+            eval_result = retrieval_eval(results_to_anet_json(results, idx_classes), current_task_id=n_task)
+            if logger is not None:
+                for i, t in enumerate((0.1, 0.2, 0.3, 0.4, 0.5)):
+                    for j, r in enumerate((1, 5)):
+                        logger.info(f'Task {n_task} Rank {r}x @ tIoU {t} is {eval_result[i, j]}')
+        assert evaluator is not None
+        if ext_score_file is not None and isinstance(ext_score_file, str):
+            raise NotImplementedError("external classification scores (postprocess_results) are outside the hot path")
+        mAP, avg_mAP, tious = evaluator.evaluate(results, current_task_id=current_task_id, verbose=False)
+        if logger is not None:
+            for tiou, m in zip(tious, mAP):
+                logger.info(f'Task {n_task} tIoU = {tiou:.1f}: mAP = {m * 100:.2f} %')
+            logger.info(f'Task {n_task} Average Map is :{avg_mAP * 100: .2f} %')
+        yield n_task, num_queries, eval_result, avg_mAP
+
+
+def _meters():
+    return {k: AverageMeter() for k in ('R1_0_3', 'R5_0_3', 'R1_0_5', 'R5_0_5', 'mAP')}
+
+
+def _update(m, eval_result, avg_mAP, n):
+    if eval_result is not None:
+        for k, (i, j) in (('R1_0_3', (2, 0)), ('R5_0_3', (2, 1)), ('R1_0_5', (4, 0)), ('R5_0_5', (4, 1))):
+            m[k].update(eval_result[i, j], n)
+    m['mAP'].update(avg_mAP, n)
+
+
+@torch.no_grad()
+def valid_one_epoch_cl_single_gpu(val_qilDatasetList, model, curr_epoch, current_task_id, ext_score_file=None, evaluator=None,
+                                  output_file=None, tb_writer=None, print_freq=20, logger=None, dataset_name='ego4d_cl',
+                                  retrieval_eval=None, idx_classes=None):
+    """Validation over the tasks learnt so far, the reference's signature and return value (train_utils.py:1016-1173):
+    query-weighted means (R1@0.3, R5@0.3, R1@0.5, R5@0.5, mAP).  Two hooks stand where the reference reaches outside the
+    path: `retrieval_eval(json_obj, current_task_id=n_task) -> recall[5, 2]` takes the place of the JSON file +
+    `evaluation_retrieval` round trip (:1128-1143: the object is the file's content), `idx_classes` is the class-name table."""
+    assert (evaluator is not None) or (output_file is not None)
+    m = _meters()
+    for n_task, nq, er, avg_mAP in _validate_tasks(val_qilDatasetList, model, current_task_id, evaluator, retrieval_eval,
+                                                   idx_classes, ext_score_file, logger, dataset_name):
+        _update(m, er, avg_mAP, nq)
+    return m['R1_0_3'].avg, m['R5_0_3'].avg, m['R1_0_5'].avg, m['R5_0_5'].avg, m['mAP'].avg
+
+
+@torch.no_grad()
+def final_validate(val_qilDatasetList, model, curr_epoch, current_task_id, ext_score_file=None, evaluator=None, output_file=None,
+                   tb_writer=None, print_freq=20, logger=None, dataset_name='ego4d_cl', list_val_recall_ii=None,
+                   list_val_mAP_ii=None, type_val='val', retrieval_eval=None, idx_classes=None):
+    """train_utils.py:1176-1352: as above plus the forgetting bookkeeping -- the newest task's R1@0.5 / mAP are appended to
+    list_val_recall_ii / list_val_mAP_ii[type_val], older tasks contribute (value when learnt - value now) to the
+    backward-forgetting means.  Returns the five means + (BWF R1@0.5, BWF mAP)."""
+    assert (evaluator is not None) or (output_file is not None)
+    list_val_recall_ii = {'val': []} if list_val_recall_ii is None else list_val_recall_ii
+    list_val_mAP_ii = {'val': []} if list_val_mAP_ii is None else list_val_mAP_ii
+    m, bwf_r, bwf_m = _meters(), AverageMeter(), AverageMeter()
+    for n_task, nq, er, avg_mAP in _validate_tasks(val_qilDatasetList, model, current_task_id, evaluator, retrieval_eval,
+                                                   idx_classes, ext_score_file, logger, dataset_name):
+        _update(m, er, avg_mAP, nq)
+        if n_task == current_task_id:
+            list_val_recall_ii[type_val].append(er[4, 0])
+            list_val_mAP_ii[type_val].append(avg_mAP)
+        elif n_task < current_task_id:
+            bwf_r.update(list_val_recall_ii[type_val][n_task] - er[4, 0], nq)
+            bwf_m.update(list_val_mAP_ii[type_val][n_task] - avg_mAP, nq)
+    return (m['R1_0_3'].avg, m['R5_0_3'].avg, m['R1_0_5'].avg, m['R5_0_5'].avg, m['mAP'].avg, bwf_r.avg, bwf_m.avg)
 
 
 def merge_results(parts):
