@@ -43,6 +43,19 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.vilco_nms_1d(None, None, None, -1, 0, 0.5, None, None, None, 0, None) == -1
     with pytest.raises(RuntimeError, match="bad argument"):
         _lib.check(-1)
+    # an operand matrix of 2^31 bytes or more is refused (the kernel's staging loads carry 32-bit byte offsets); the check
+    # comes before anything touches memory, so dummy addresses do
+    d = _lib.GemmDesc()
+    d.A = d.B = d.C = 4096
+    d.M, d.N, d.K = 70000, 128, 20000
+    d.a_kcontig = d.b_kcontig = 1
+    d.lda = d.ldb = 20000
+    d.ldc = 128
+    d.batch_outer = d.batch_inner = 1
+    d.precision = 3
+    assert lib.vilco_gemm(ctypes.byref(d), None) == -2
+    d.M = 7000                                                  # the same call with a legal size gets as far as the workspace check
+    assert lib.vilco_gemm(ctypes.byref(d), None) == -4
 
 
 def test_ops_refuse_cpu_tensors():

@@ -69,6 +69,68 @@ def test_grad_reducer_gloo_world2():
             assert np.allclose(r1[k], want, atol=1e-6), k
 
 
+def _replay_worker(rank, world, port, q):
+    """the exchange protocol of a REPLAYED step (vilco_amd/graph.py): backward with the hooks silenced (`begin(hooks=False)`,
+    what a capture does), a zero gradient for every planned parameter this rank's step did not reach, `reduce_now()` --
+    against the hook-driven `finish()` of the eager step, same data"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vilco_amd import ops
+    from vilco_amd.dist import GradReducer
+    res = {}
+    for mode in ("eager", "replay"):
+        torch.manual_seed(0)
+        model = Tiny()
+        red = GradReducer(model, bucket_mb=0.0001)
+        outs = []
+        for step in range(3):
+            x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 * step + rank))
+            model.zero_grad(set_to_none=True)
+            skip = rank == 1 and step >= 1
+            if mode == "eager" or step == 0:              # (the plan is built by an eager step in both modes)
+                red.begin()
+                model(x, use_sometimes=not skip).pow(2).sum().backward()
+                red.finish()
+            else:
+                red.begin(hooks=False)
+                launched = len(red._pending)
+                model(x, use_sometimes=not skip).pow(2).sum().backward()
+                assert len(red._pending) == launched == 0          # no collective from the hooks
+                red.end_capture()
+                for p in red.planned():
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                held = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+                red.reduce_now()
+                assert all(p.grad is held[k] for k, p in model.named_parameters() if p.grad is not None)   # averaged IN PLACE
+            assert ops.grad_slot_provider is None                  # nothing may write into the buckets between steps
+            outs.append({k: p.grad.clone().numpy() for k, p in model.named_parameters() if p.grad is not None})
+        res[mode] = outs
+        red.remove()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replayed_step_exchange_equals_eager_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 29) % 2000)
+    procs = [ctx.Process(target=_replay_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(3):
+        e0, r0, e1, r1 = res[0]["eager"][step], res[0]["replay"][step], res[1]["eager"][step], res[1]["replay"][step]
+        assert set(e0) == set(r0) == set(e1) == set(r1) and "sometimes.weight" in r1      # the same set is stepped on every rank
+        for k in e0:
+            assert np.array_equal(e0[k], r0[k]) and np.array_equal(e1[k], r1[k]), k           # replay protocol == eager, bit for bit
+            assert np.array_equal(r0[k], r1[k]), k                                            # replicas hold the same average
+
+
 def test_bench_protocol_two_ranks():
     """`bench.py --gpus 2` under torch.distributed.run terminates and rank 0 prints ONE JSON line: the rank /
     collective protocol of bench.py exercised on CPU + gloo (VILCO_BENCH_DRYRUN swaps the HIP model for a small torch

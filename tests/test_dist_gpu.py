@@ -88,3 +88,65 @@ def test_reducer_paths_reproduce_the_single_process_run(dev, one_rank_group):
             # (key / key-norm biases: analytically zero gradients, 1e-12-level noise that Adam turns into +-lr steps)
             if s0[k].is_floating_point() and not k.endswith(('key_norm.bias', '.key.bias')):
                 assert torch.equal(other_s[k], s0[k]) or rel_err(other_s[k], s0[k], 1e-7) < 1e-5, k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two REAL replicas on the one GPU of the box: two processes, both on cuda:0, gloo carrying the device tensors (RCCL refuses
+# two ranks on one device).  Everything else is the production path: HIP model, FusedOptimizer, GradReducer, GraphedStep.
+def _w2_worker(rank, world, port, mode, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vilco_amd.dist import GradReducer
+        from vilco_amd.graph import GraphedStep
+        from vilco_amd.utils.train_utils import make_optimizer
+        from parity_util import cases
+        dev = torch.device("cuda:0")
+        gold, model = _model(dev)
+        m = gold['overrides']
+        batch = cases.video_list(m['dataset']['max_seq_len'], m['dataset']['input_dim'], m['model']['n_txt_in'], gold['L'],
+                                 seed=40 + rank)                      # every replica trains on its own clips
+        opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-3))
+        red = GradReducer(model, bucket_mb=0.05)
+        step = GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=2, reducer=red, enabled=(mode == "graph"))
+        losses = [float(step(batch, task_id=gold['task_id'])['final_loss']) for _ in range(5)]
+        in_place = sum(1 for b in red.buckets for p, v in zip(b["params"], b["views"]) if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
+        q.put((rank, losses, {k: v.detach().cpu() for k, v in model.state_dict().items()}, dict(step.stats), in_place))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _w2_run(mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + ((os.getpid() + (17 if mode == "graph" else 0)) % 500)
+    procs = [ctx.Process(target=_w2_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(2):
+        r = q.get(timeout=600)
+        out[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return out
+
+
+def test_world2_graph_replay_equals_eager_and_replicas_stay_identical(dev):
+    eager, graph = _w2_run("eager"), _w2_run("graph")
+    assert graph[0][2]['replayed'] == 3 and graph[1][2]['replayed'] == 3, (graph[0][2], graph[1][2])
+    assert graph[0][3] >= 40                       # the captured weight-gradient kernels wrote into the bucket slots
+    noise = ('key_norm.bias', '.key.bias')
+    for rank in (0, 1):
+        assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(graph[rank][0], eager[rank][0])), (graph[rank][0], eager[rank][0])
+        for k, v in eager[rank][1].items():
+            if v.is_floating_point() and not k.endswith(noise):
+                assert torch.equal(graph[rank][1][k], v) or rel_err(graph[rank][1][k], v, 1e-7) < 1e-5, (rank, k)
+    assert eager[0][0] != eager[1][0]              # different clips per replica ...
+    for k, v in graph[0][1].items():               # ... the same parameters after five averaged steps, bit for bit
+        if v.is_floating_point():
+            assert torch.equal(v, graph[1][1][k]), k

@@ -348,30 +348,25 @@ def test_nlq_episode_reproduces_reference(dev, tmp_path, use_graph):
                                shuffle=False)
     rec = _Recorder()
     last_epoch = cfg['opt']['epochs'] + cfg['opt']['warmup_epochs'] - 1
-    lrs = {}
 
     def on_validate(kind, j, epoch, r1):
         if kind == 'epoch' and epoch == last_epoch:
             random.seed(1000 + j)                        # the memory shuffle that follows (the recording seeds it the same way)
 
-    import vilco_amd.utils.train_utils_nlq as tu
-    make0 = tu.make_scheduler
+    from torch.optim.lr_scheduler import LRScheduler
+    step0 = LRScheduler.step
+    lrs = []
 
-    def rec_make(optimizer, *a, **k):
-        sch = make0(optimizer, *a, **k)
-        step0 = sch.step
-
-        def step(*aa, **kk):                             # the rates the iteration that just ran was stepped with
-            lrs.setdefault(id(sch), []).append([g['lr'] for g in optimizer.param_groups])
-            return step0(*aa, **kk)
-        sch.step = step
-        return sch
-    tu.make_scheduler = rec_make
+    def rec_step(self, *a, **k):                         # (patched on the class: an instance attribute would end up in the
+        if self._step_count >= 1:                        # scheduler's state_dict and the checkpoint could not pickle it)
+            lrs.append([g['lr'] for g in self.optimizer.param_groups])    # the rates the iteration that just ran was stepped with
+        return step0(self, *a, **k)
+    LRScheduler.step = rec_step
     try:
         model, opt, sch, log = run_episodes_nlq(cfg, model, stream, _ValTasks(), rec, ckpt_folder=str(tmp_path), ckpt_freq=2,
                                                 use_graph=use_graph, on_validate=on_validate)
     finally:
-        tu.make_scheduler = make0
+        LRScheduler.step = step0
     assert len(log) == cases.NLQ_EP_TASKS
     init = gold['init_state']
     call = 0
@@ -394,7 +389,7 @@ def test_nlq_episode_reproduces_reference(dev, tmp_path, use_graph):
                        if w.is_floating_point() and not k.endswith(NOISE)), reverse=True)
         assert errs[0][0] < 0.2 and errs[len(errs) // 2][0] < 2e-2, (j, errs[:6], errs[len(errs) // 2])
     # learning rates of all four groups, every optimisation step of the episode
-    got_lrs = [x for seq in lrs.values() for x in seq]
+    got_lrs = lrs
     want_lrs = [x for t in gold['tasks'] for x in t['lrs']]
     assert len(got_lrs) == len(want_lrs)
     assert all(abs(a - b) <= 1e-12 + 1e-9 * abs(b) for g, w in zip(got_lrs, want_lrs) for a, b in zip(g, w))

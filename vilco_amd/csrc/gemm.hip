@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   // instruction per chunk and no vector address arithmetic at all.  In the MEM phase every instruction counts: the SIMD's
   // other wave issues MFMAs back to back at raised priority, which leaves this wave about one issue slot per MFMA
   // (~16 cycles) -- in-kernel stamps (tools/lab/stamps.py, r03): the 6 global loads with their 14 64-bit address VALUs
-  // and 6 hazard nops took ~580 of a ~1100-cycle MEM phase.  (Host side: one operand matrix is < 2^31 bytes.)
+  // and 6 hazard nops took ~580 of a ~1100-cycle MEM phase.  (Host side: vilco_gemm refuses an operand matrix of 2^31 bytes or more.)
   typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
   __amdgpu_buffer_rsrc_t rsA[NP], rsB[NP];
 #pragma unroll
@@ -1141,6 +1141,14 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   }
   Plan p;
   make_plan(d, p);
+  // the kernel's staging loads address one operand matrix (one batch element of one part) with 32-bit byte offsets
+  // (buffer loads: lane offset + K-step offset, gemm_pp_kernel); the last K-step may over-read one tile
+  {
+    const long lim = (1L << 31) - (1L << 20);
+    const long a_el = p.a_batch > (long)align_up(d->M, 32) * p.Kp ? p.a_batch : (long)align_up(d->M, 32) * p.Kp;
+    const long b_el = p.b_batch > (long)align_up(d->N, 32) * p.Kp ? p.b_batch : (long)align_up(d->N, 32) * p.Kp;
+    if (a_el * 2 >= lim || b_el * 2 >= lim) return VILCO_ERR_UNSUPPORTED;
+  }
   const size_t need = (size_t)(p.a_bytes + p.b_bytes + p.part_bytes + 512 + SCALE_BYTES);
   if (!d->workspace || d->workspace_bytes < need) return VILCO_ERR_WORKSPACE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -155,7 +155,8 @@ __device__ __forceinline__ void pack_kc_body(const PackArgs& a, int z, int bx, i
   };
   // The first item's source values are requested BEFORE the scale is folded out of the amax partials (a load, a block
   // reduction and a barrier of its own): the two round trips overlap instead of following each other.
-  if (a.tap == 0 && a.vec && a.K == a.Kp && a.out_rows <= a.rows && total < (1L << 31)) {
+  if (a.tap == 0 && a.vec && a.K == a.Kp && a.out_rows <= a.rows &&
+      total < (1L << 31) - 2L * nbx * (long)blockDim.x) {      // i + 2 * st below stays inside an int
     // the plain case (an activation or a weight, whole rows): 32-bit item arithmetic, two items of a thread in flight
     const int tot = (int)total, st = nbx * (int)blockDim.x;
     int i = bx * (int)blockDim.x + (int)threadIdx.x;

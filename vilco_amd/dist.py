@@ -53,6 +53,7 @@ class GradReducer:
         self._slot = {}              # id(param) -> (bucket index, view)
         self._slot_by_ptr = {}       # param.data_ptr() -> (bucket index, view)
         self._handed = set()
+        self._hooks_live = True
         self._next = 0               # index of the next bucket to launch (strict order)
 
     # -- plan -------------------------------------------------------------------------------
@@ -104,7 +105,7 @@ class GradReducer:
 
     def _make_hook(self, bi):
         def hook(param):
-            if not self.enabled:
+            if not self.enabled or not self._hooks_live:
                 return
             b = self.buckets[bi]
             if id(param) in b["done"]:
@@ -133,8 +134,12 @@ class GradReducer:
         self._pending.append(b)
 
     # -- per step ---------------------------------------------------------------------------
-    def begin(self):
+    def begin(self, hooks=True):
+        """start of a step's backward.  hooks=False (a hipGraph capture, vilco_amd/graph.py): the dW kernels still write
+        into the bucket slots -- a replayed backward then leaves the large gradients where the collective reads them --
+        but no collective is issued from the autograd hooks; `end_capture()` undoes it."""
         from . import ops
+        self._hooks_live = bool(hooks)
         ops.grad_slot_provider = self.grad_slot if self.enabled else None      # dW kernels write into the bucket slots
         self._handed = set()
         self._next = 0
@@ -147,6 +152,7 @@ class GradReducer:
         """wait for the collectives and leave the averaged gradient in every planned p.grad (views of the flat
         buckets: nothing is copied back)"""
         if not self.enabled:
+            self._release_slots()
             return
         if self.buckets is None:
             self._build()
@@ -161,6 +167,22 @@ class GradReducer:
                 for p, v in zip(b["params"], b["views"]):
                     p.grad = v
         self._pending = []
+        self._release_slots()
+
+    def _release_slots(self):
+        """no kernel outside a begin() ... finish() / reduce_now() bracket may write into the buckets (a backward run for
+        another purpose, e.g. the EWC / MAS importance pass, would otherwise put its dW into the flat buffers)"""
+        from . import ops
+        if getattr(ops.grad_slot_provider, "__self__", None) is self:
+            ops.grad_slot_provider = None
+        self._hooks_live = True
+
+    def end_capture(self):
+        self._release_slots()
+
+    def planned(self):
+        """the parameters of the bucket plan (None before the first finish())"""
+        return None if self.buckets is None else [p for b in self.buckets for p in b["params"]]
 
     def reduce_now(self):
         """Average the gradients that are already complete in p.grad -- a step replayed as a hipGraph (vilco_amd/graph.py)
@@ -171,7 +193,7 @@ class GradReducer:
             return
         if self.buckets is None:
             self._build()
-        self.begin()
+        self.begin(hooks=False)
         for b in self.buckets:
             self._launch(b)
         self._next = len(self.buckets)
@@ -190,6 +212,7 @@ class GradReducer:
                 if src:
                     torch._foreach_copy_(dst, src)
         self._pending = []
+        self._release_slots()
 
     def profile_buckets(self, iters=3):
         """Every rank calls this (it issues collectives): each bucket's all-reduce alone, fenced by device syncs ->

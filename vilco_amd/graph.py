@@ -79,6 +79,8 @@ class GraphedStep:
         if 'graph' in ent and not self._still_valid(ent):
             self.reset()
             ent = self._graphs[key] = {'seen': 0}
+        if 'graph' not in ent and self.reducer is not None and self.reducer.enabled and self.reducer.planned() is None:
+            return self._eager(inp, video_list, task_id, prev_out_cls_logits)      # no bucket plan yet: it is built by an eager finish()
         if 'graph' not in ent:
             # a signature is captured once it has come back often enough, and only while there is room: batches whose
             # shapes keep changing (ragged text lengths) stay eager instead of evicting the graphs of the common shapes
@@ -133,9 +135,10 @@ class GraphedStep:
         gc.collect()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        hooks_on = self.reducer.enabled if self.reducer is not None else False
         if self.reducer is not None:
-            self.reducer.enabled = False     # no collectives inside the capture: replays exchange after graph 1
+            # no collectives inside the capture (replays exchange after graph 1), but the captured weight-gradient kernels
+            # write into the reducer's bucket slots: a replayed backward leaves the large gradients in place
+            self.reducer.begin(hooks=False)
         try:
             with torch.cuda.graph(g, pool=self._pool):
                 _lib.check(lib.vilco_seed_word_bump(ops._stream()))
@@ -146,15 +149,31 @@ class GraphedStep:
                 out = torch.stack([losses[k].detach().reshape(()).float() for k in keys])
         finally:
             if self.reducer is not None:
-                self.reducer.enabled = hooks_on
+                self.reducer.end_capture()
         del losses
         blocks.reset_drop_pool()
         if self._pool is None:
             self._pool = g.pool()
+        ent['fill'] = []
+        if self.reducer is not None and self.reducer.enabled:
+            # The exchange covers the reducer's plan (the union over ranks of the gradient-bearing parameters), the captured
+            # update covers what has a gradient HERE.  The two must be the same set on every rank or replicas drift apart:
+            # a planned parameter this rank's step does not reach gets a zero gradient of its own (re-zeroed before every
+            # replay; the exchange writes the other ranks' average into it), exactly what the eager finish() leaves in
+            # p.grad; a gradient outside the plan cannot be averaged at all.
+            planned = {id(p) for p in self.reducer.planned()}
+            stray = [i for i, p in enumerate(self.params) if p.grad is not None and id(p) not in planned]
+            if stray:
+                raise RuntimeError("GraphedStep: %d parameter(s) received a gradient but are not in the GradReducer's plan "
+                                   "(the set of trained parameters changed: call reducer.rebuild())" % len(stray))
+            for p in self.params:
+                if p.grad is None and id(p) in planned:
+                    p.grad = torch.zeros_like(p)
+                    ent['fill'].append(p.grad)
         ent.update(graph=g, static=static, out=out, keys=keys, grads=[p.grad for p in self.params])
         if self.optimizer is not None:
             opt = self.optimizer
-            opt.prepare_step()               # plans + pointer tables for THESE gradient tensors, built outside the capture
+            opt.prepare_step(pin=True)       # plans + pointer tables for THESE gradient tensors, built outside the capture
             if self._lr_dev is None:
                 self._lr_dev = torch.zeros(16, dtype=torch.float32, device=self.params[0].device)
             g2 = torch.cuda.CUDAGraph()
@@ -180,6 +199,8 @@ class GraphedStep:
             if p.grad is not g:
                 p.grad = g
         if self.reducer is not None:
+            if ent['fill']:
+                torch._foreach_zero_(ent['fill'])
             self.reducer.reduce_now()
         if self.between is not None:
             self.between()

@@ -913,14 +913,14 @@ class PtTransformer(nn.Module):
     # ------------------------------------------------------------------ iCaRL nearest-exemplar-mean classification
     @torch.no_grad()
     def _pyramid_features(self, video_list):
-        """backbone + neck of an inference batch (one clip): list over levels of token-major [1, T_l, C]"""
+        """backbone + neck of an inference batch (one clip): list over levels of token-major [1, T_l, C].
+        The text goes in RAW: the reference's classify hands query_preprocessing's tokens and mask straight to the backbone
+        (meta_archs.py:1077-1079, 1108-1110), also on a model with an L2P prompt pool."""
         inp = self.prepare(video_list, is_training=False)
         x_tm = ops.transpose(inp.feats_cf)
         text_tm = text_lens = None
         if self.use_cross_modal:
             text_tm, text_lens = ops.transpose(inp.text_cf), inp.text_lens
-            if hasattr(self, 'prompt'):
-                text_tm = self.prompt(text_tm, prompt_mask=None, cls_features=None)['prompted_embedding'].contiguous()
         feats, all_lens = self.backbone.forward_tm(x_tm, inp.lens, text_tm, text_lens)
         return self.neck.forward_tm(feats, all_lens)[0]
 

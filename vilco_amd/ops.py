@@ -123,9 +123,10 @@ class _DwFork:
     seen in the current backward (a weight used twice accumulates its gradients on the main stream: keep those ordered)"""
 
     def __init__(self, w):
-        self.on = fork_enabled("dw") and id(w) not in _dw_seen
+        key = w.data_ptr()          # inside autograd the weight arrives as a fresh saved-tensor alias per use: id() never repeats
+        self.on = fork_enabled("dw") and key not in _dw_seen
         if fork_enabled("dw"):
-            _dw_seen.add(id(w))
+            _dw_seen.add(key)
         self.ctx = None
 
     def __enter__(self):

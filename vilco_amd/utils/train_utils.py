@@ -158,10 +158,15 @@ class FusedOptimizer(optim.Optimizer):
                 else:
                     st['momentum_buffer'] = torch.zeros_like(p)
 
-    def prepare_step(self):
+    MAX_EAGER_TABLES = 2        # pointer tables kept per pass outside captured graphs
+
+    def prepare_step(self, pin=False):
         """(re)build whatever the next step() needs that costs a host -> device copy: chunk plans when the set of stepped
         parameters changed, pointer tables when a tensor moved.  step() calls it itself; a caller about to CAPTURE step()
-        calls it first, outside the capture."""
+        calls it first, outside the capture, with pin=True: a captured launch holds the table's address, so pinned tables
+        are never evicted.  Unpinned tables (plain eager training, where gradient addresses change with the allocation
+        pattern, e.g. ragged text lengths) are a small LRU; every table is keyed by the tuple of all four pointer rows
+        and uploaded from page-locked memory without blocking the host."""
         passes, occ = self._passes()
         key = tuple(tuple(id(p) for p, _ in items) for items in passes)
         if key != self._plans_key:
@@ -175,16 +180,25 @@ class FusedOptimizer(optim.Optimizer):
         tables = []
         for pl in self._plans:
             items = pl['items']
-            rows = ([p.data_ptr() for p, _ in items], [p.grad.data_ptr() for p, _ in items],
-                    [self.state[p][s1].data_ptr() for p, _ in items],
-                    [self.state[p]['exp_avg_sq'].data_ptr() if adam else 0 for p, _ in items])
-            tkey = hash((tuple(rows[0]), tuple(rows[1])))
-            tab = pl['tables'].get(tkey)
-            if tab is None:
+            tkey = (tuple(p.data_ptr() for p, _ in items), tuple(p.grad.data_ptr() for p, _ in items),
+                    tuple(self.state[p][s1].data_ptr() for p, _ in items),
+                    tuple(self.state[p]['exp_avg_sq'].data_ptr() if adam else 0 for p, _ in items))
+            cache = pl['tables']
+            ent = cache.pop(tkey, None)
+            if ent is None:
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("FusedOptimizer.step() under stream capture needs prepare_step() before the capture")
-                tab = pl['tables'][tkey] = torch.tensor(rows, dtype=torch.int64).to(items[0][0].device)
-            tables.append(tab)
+                host = torch.tensor(tkey, dtype=torch.int64)
+                dev = items[0][0].device
+                if dev.type == 'cuda':
+                    host = host.pin_memory()
+                ent = {'dev': host.to(dev, non_blocking=True), 'host': host, 'pinned': False}
+            ent['pinned'] = ent['pinned'] or bool(pin)
+            cache[tkey] = ent                     # (re)inserted last: dict order is the LRU order
+            loose = [k for k, e in cache.items() if not e['pinned']]
+            for k in loose[:max(len(loose) - self.MAX_EAGER_TABLES, 0)]:
+                del cache[k]
+            tables.append(ent['dev'])
         return tables
 
     @torch.no_grad()
