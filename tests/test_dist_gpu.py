@@ -112,7 +112,7 @@ def _w2_worker(rank, world, port, mode, q):
         step = GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=2, reducer=red, enabled=(mode == "graph"))
         losses = [float(step(batch, task_id=gold['task_id'])['final_loss']) for _ in range(5)]
         in_place = sum(1 for b in red.buckets for p, v in zip(b["params"], b["views"]) if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
-        q.put((rank, losses, {k: v.detach().cpu() for k, v in model.state_dict().items()}, dict(step.stats), in_place))
+        q.put((rank, losses, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, dict(step.stats), in_place))    # (numpy: by value)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -122,13 +122,13 @@ def _w2_run(mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29400 + ((os.getpid() + (17 if mode == "graph" else 0)) % 500)
+    port = 30100 + ((os.getpid() + (250 if mode == "graph" else 0)) % 500)
     procs = [ctx.Process(target=_w2_worker, args=(r, 2, port, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
     out = {}
     for _ in range(2):
-        r = q.get(timeout=600)
+        r = q.get(timeout=240)
         out[r[0]] = r[1:]
     for p in procs:
         p.join(timeout=120)
@@ -144,9 +144,10 @@ def test_world2_graph_replay_equals_eager_and_replicas_stay_identical(dev):
     for rank in (0, 1):
         assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(graph[rank][0], eager[rank][0])), (graph[rank][0], eager[rank][0])
         for k, v in eager[rank][1].items():
-            if v.is_floating_point() and not k.endswith(noise):
-                assert torch.equal(graph[rank][1][k], v) or rel_err(graph[rank][1][k], v, 1e-7) < 1e-5, (rank, k)
+            if v.dtype.kind == 'f' and not k.endswith(noise):
+                g = graph[rank][1][k]
+                assert (g == v).all() or rel_err(torch.from_numpy(g), torch.from_numpy(v), 1e-7) < 1e-5, (rank, k)
     assert eager[0][0] != eager[1][0]              # different clips per replica ...
     for k, v in graph[0][1].items():               # ... the same parameters after five averaged steps, bit for bit
-        if v.is_floating_point():
-            assert torch.equal(v, graph[1][1][k]), k
+        if v.dtype.kind == 'f':
+            assert (v == graph[1][1][k]).all(), k

@@ -80,6 +80,7 @@ class GraphedStep:
             self.reset()
             ent = self._graphs[key] = {'seen': 0}
         if 'graph' not in ent and self.reducer is not None and self.reducer.enabled and self.reducer.planned() is None:
+            ent['seen'] += 1
             return self._eager(inp, video_list, task_id, prev_out_cls_logits)      # no bucket plan yet: it is built by an eager finish()
         if 'graph' not in ent:
             # a signature is captured once it has come back often enough, and only while there is room: batches whose
