@@ -46,12 +46,13 @@ int vilco_sync_timeouts_read(void);
 /* attention contractions.  C[m][n] = epilogue(alpha * sum_k A(m,k) B(k,n)).                    */
 /* Replaces aten::convolution / addmm / bmm / einsum under blocks.py:79,217-226,340-349,420-435, */
 /* 533-539, meta_archs.py:216-235,309-331, modeling_xlnet_x.py:284-325,437-443,474-489.         */
-/* Operands are first split into bf16 planes (pack kernels, transposing where needed), then one */
-/* NT MFMA kernel (256x128 / 128x128 tiles, optional split-K) runs on the planes.                */
-/* bf16 MFMA (v_mfma_f32_16x16x32_bf16) with fp32 accumulate; precision 0 = split-bf16 (hi+lo, */
-/* 3 MFMAs, ~2^-17 relative), 1 = single bf16 pass, 2 = three-part split (6 MFMAs, ~2^-25:    */
-/* numerically an fp32 GEMM), 3 = two fp16 parts of operands scaled by a per-tensor power of   */
-/* two (v_mfma_f32_16x16x32_f16, 3 MFMAs, ~2^-22; the default); 4 = the same fp16 x2 planes, but the  */
+/* Operands are split once into 16-bit planes in their natural row-major layout (vilco_pack; the same planes serve    */
+/* the k-contiguous and the k-major use, the latter through transposing LDS reads), then ONE MFMA kernel runs on the  */
+/* planes: 256 / 192 / 128 x 128 x 32 tiles chosen per problem, 8 waves in a ping-pong schedule, optional split-K.    */
+/* Default precision 3: two fp16 parts of operands scaled by a per-tensor power of two (v_mfma_f32_16x16x32_f16,     */
+/* 3 MFMAs per product, ~2^-22, fp32 accumulate).  Others: 0 = split-bf16 (hi+lo, 3 MFMAs, ~2^-17 relative),           */
+/* 1 = single bf16 pass, 2 = three-part bf16 split (6 MFMAs, ~2^-25: numerically an fp32 GEMM, 8 exponent bits per    */
+/* element -- the format of call sites whose tensors span too much range for one scale);  4 = the fp16 x2 planes, but the */
 /* product takes their leading parts only (1 MFMA, 11-bit operands, fp32 accumulate): for the weight-  */
 /* gradient products dW = dY^T X, whose rounding errors average over the B*T contraction and feed   */
 /* nothing downstream (ops.py: dw_precision).                                                        */
@@ -449,6 +450,17 @@ int vilco_mq_loss_bwd(const vilco_loss_desc* d, const float* g_cls, const float*
 int vilco_cl_penalty(const int64_t* ptrs, const int64_t* numel, const int32_t* chunk_tensor,
                      const int64_t* chunk_off, int32_t n, int32_t nchunks, int32_t chunk, float lambda,
                      int32_t shared_params, float* partial, float* out, void* stream);
+
+/* Deferred finishing (csrc/defer.hip).  The second stage of every two-stage column reduction (LayerNorm d-gamma / d-beta,  */
+/* bias and scale gradients, depthwise-tap gradients: reference autograd sums under blocks.py:152-166, 106-130, 628-641)  */
+/* and the slab sum of a split-K product with a plain epilogue are small dependent launches whose results -- parameter     */
+/* gradients -- nothing reads before backward ends.  While vilco_defer_set(1) is in force on the calling thread they are   */
+/* recorded instead of launched; vilco_defer_flush(stream) issues all recorded items as a few batched launches (same       */
+/* arithmetic, same order: bitwise the results of the individual launches) and switches recording off.  The partial buffers */
+/* (workspaces) of recorded calls must stay alive until the flush.                                                        */
+int vilco_defer_set(int32_t on);
+int64_t vilco_defer_pending(void);
+int vilco_defer_flush(void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* 1-D NMS on the device, replacing nms_1d_cpu (MQ/libs/utils/csrc/nms_cpu.cpp).                 */

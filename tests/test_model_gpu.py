@@ -179,21 +179,13 @@ def test_w_head_width_vs_oracle(dev):
     # Without the XLNet layer stem[0] is applied twice (backbones.py:276-278) and its second application sees the UNMASKED
     # channel-attention output of the padded rows; the LayerNorm backward of such a near-constant row multiplies its
     # gradient by rstd ~ 300 per norm, so the first padded row of the short clip carries gradients ~1e10 x the typical
-    # element (measured: dq max 5e3 against a 99th percentile of 2e-6).  fp32 carries that range per element; the fp16 x2
-    # planes carry ONE power-of-two scale per tensor, so everything else in that tensor keeps only a few bits.  The rows
-    # are multiplied by zeros further down (their inputs are masked constants), which is why every other gradient holds
-    # the 1e-3 bar -- the two weights fed directly by that tensor do not.
-    loose = ('backbone.stem.0.channel_attn.attn.qkv.weight', 'backbone.stem.0.channel_attn.attn.proj.weight')
-    worst, worst_loose = (0.0, None), (0.0, None)
-    for k, p in model.named_parameters():
-        if p64[k].grad is not None and p.grad is not None:
-            e = rel_err(p.grad, p64[k].grad, GRAD_FLOOR)
-            if k in loose:
-                worst_loose = max(worst_loose, (e, k))
-            elif e > worst[0]:
-                worst = (e, k)
+    # element (measured: dq max 5e3 against a 99th percentile of 2e-6).  One power-of-two scale per tensor cannot carry that
+    # range in fp16 x2 planes, so the backward products of THAT channel-attention block run on bf16 x3 operands
+    # (blocks.ChannelAttention.wide_range, set by the backbone): every gradient at the 1e-3 bar, no exemption.
+    assert model.backbone.stem[0].channel_attn.attn.wide_range and not model.backbone.stem[1].channel_attn.attn.wide_range
+    worst = max((rel_err(p.grad, p64[k].grad, GRAD_FLOOR), k) for k, p in model.named_parameters()
+                if p64[k].grad is not None and p.grad is not None)
     assert worst[0] < TOL, worst
-    assert worst_loose[0] < 2e-2, worst_loose
 
 
 def test_two_part_split_mode_accuracy(dev):
@@ -365,3 +357,39 @@ def test_train_mode_vs_oracle_with_replayed_masks(dev):
             if e > worst[1]:
                 worst = (k, e)
     assert worst[1] < TOL, worst
+
+
+@pytest.mark.parametrize("name", ["xl", "noxl"])
+def test_deferred_finish_is_bitwise_the_individual_launches(dev, name):
+    """ops._Deferring / csrc/defer.hip: the second stages of the backward pass's column reductions and split-K weight-gradient
+    sums, recorded and issued as a few batched launches at the end of backward, give bit for bit the gradients of the
+    individual launches -- also in the configuration that applies stem[0] twice ("noxl": a parameter whose second gradient
+    arrives while the first is still pending forces a flush in the middle of backward)"""
+    from vilco_amd import _lib, ops
+    gold = load_golden(name)
+    lib = _lib.load()
+    grads, counts = {}, {}
+    flush0 = ops._defer_flush
+    for mode in (False, True):
+        model = build_hip_model(gold)
+        model.loss_normalizer = golden_cfg(gold)['train_cfg']['init_loss_norm']
+        seen = []
+
+        def counting_flush():
+            seen.append(int(lib.vilco_defer_pending()))
+            flush0()
+        ops.defer_finish, ops._defer_flush = mode, counting_flush
+        try:
+            losses = model(golden_inputs(gold), task_id=gold['task_id'], is_training=True)
+            losses['final_loss'].backward()
+        finally:
+            ops.defer_finish, ops._defer_flush = True, flush0
+        assert lib.vilco_defer_pending() == 0 and not ops._defer["keep"] and not ops._defer["pending"]
+        grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        counts[mode] = seen
+    assert counts[False] == [] and sum(counts[True]) >= 60, counts          # the reductions really were recorded
+    if name == "noxl":
+        assert len(counts[True]) >= 2, counts                                # ... and a twice-used parameter flushed early
+    assert grads[True].keys() == grads[False].keys()
+    for k in grads[True]:
+        assert torch.equal(grads[True][k], grads[False][k]), k

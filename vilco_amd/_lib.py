@@ -66,6 +66,9 @@ SIGNATURES = {
     "vilco_status_str": (C.c_char_p, [C.c_int]),
     "vilco_version": (C.c_char_p, []),
     "vilco_sync_timeouts_read": (C.c_int, []),
+    "vilco_defer_set": (C.c_int, [i32]),
+    "vilco_defer_pending": (i64, []),
+    "vilco_defer_flush": (C.c_int, [c_fp]),
     "vilco_gemm_workspace": (sz, [C.POINTER(GemmDesc)]),
     "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
     "vilco_gemm_amax_parts": (i32, [C.POINTER(GemmDesc)]),

@@ -192,3 +192,8 @@ __device__ __forceinline__ void vilco_finish_colsum(const float* __restrict__ ws
     }
   }
 }
+
+// deferred second stages of two-stage reductions (defer.hip)
+bool vilco_defer_active();
+void vilco_defer_push_rr(const float* ws, float* out0, float* out1, int nrows, int ncols, int split);
+void vilco_defer_push_sk(const float* part, float* out, long split_stride, long ldc, int M, int N, int ksplit);

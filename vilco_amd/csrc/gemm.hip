@@ -1288,7 +1288,12 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     prof().ev.emplace_back(ev0, ev1);
     prof().rec.push_back(ProfRec{{d->M, d->N, d->K, nz, p.BM, p.ksplit, d->precision, p.a_km, p.b_km, p.a_tap | (p.b_tap << 4)}});
   }
-  if (p.ksplit > 1 && !p.fixup) {
+  if (p.ksplit > 1 && !p.fixup && vilco_defer_active() && nz == 1 && d->alpha == 1.f && d->beta == 0.f && !d->bias &&
+      !d->preact && d->act == VILCO_ACT_NONE && !d->row_len && !d->colscale && !d->residual && d->drop_p == 0.f &&
+      !d->amax_out) {
+    // a plain sum of the split slabs whose result nothing reads before the end of backward (a weight gradient): recorded
+    vilco_defer_push_sk(g.c, g.cfinal, g.split_stride, g.ldc, d->M, d->N, p.ksplit);
+  } else if (p.ksplit > 1 && !p.fixup) {
     long blocks = ((long)d->M * d->N * nz + 255) / 256;       // == amax_out_parts(): one max|C| partial per block, either form
     if (blocks > 2048) blocks = 2048;
     if (g.vec_out) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((int)blocks), dim3(256), 0, s, g, nz);

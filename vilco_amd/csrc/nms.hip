@@ -401,7 +401,188 @@ __global__ __launch_bounds__(NT) void softnms_kernel(const float* __restrict__ s
   if (threadIdx.x == 0) out_cnt[cls] = i;
 }
 
+
+// ------------------------------------------------------------------------------------ soft NMS, row-strided (round 4)
+// Same array semantics as softnms_kernel above, restructured around what bounded it (76 us per pick at n = 30 000, i.e. one
+// memory round trip per loop iteration): position p of the remaining range belongs to thread (p - first) % 1024 -- every
+// access of a wavefront is one coalesced line -- and every loop requests the values of several rows before it uses the
+// first (clamped, unconditional loads; the stores follow the loads of a batch).  The ordered prefix "alive before p" that
+// the swap-with-last emulation needs comes from wavefront ballots: count per (row, wave) -> one exclusive scan in LDS.
+// n <= SROWS * 1024; larger classes take softnms_kernel.
+constexpr int SROWS = 64;
+
+__global__ __launch_bounds__(NT) void softnms_rows_kernel(const float* __restrict__ segs,
+                                                          const float* __restrict__ scores,
+                                                          const long* __restrict__ seg_off, float thr,
+                                                          float sigma, float min_score, int method,
+                                                          long max_num, float* __restrict__ dets,
+                                                          long* __restrict__ out_idx,
+                                                          long* __restrict__ out_cnt, void* ws_raw,
+                                                          long n_total) {
+  __shared__ int s_cnt[SROWS * NW + 1];
+  __shared__ float s_val[NW];
+  __shared__ int s_pos[NW];
+  __shared__ float s_pick[3];
+  const int cls = blockIdx.x;
+  const long off = seg_off[cls];
+  const int n = (int)(seg_off[cls + 1] - off);
+  if (n <= 0) {
+    if (threadIdx.x == 0) out_cnt[cls] = 0;
+    return;
+  }
+  Ws w = carve(ws_raw, n_total, off);
+  float* __restrict__ X1 = w.x1; float* __restrict__ X2 = w.x2; float* __restrict__ SC = w.sc; float* __restrict__ AR = w.ar;
+  int* __restrict__ IND = w.ind; int* __restrict__ TMP = w.tmp;
+  const float* sg = segs + off * 2;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const float a = sg[2 * i], b = sg[2 * i + 1];
+    X1[i] = a; X2[i] = b; AR[i] = b - a + 1e-6f; SC[i] = scores[off + i]; IND[i] = i;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  int nsegs = n;  // uniform
+  int i = 0;
+  for (; i < nsegs; ++i) {
+    if (max_num > 0 && i >= max_num) break;
+    // (a) first maximum of sc[i:nsegs)  (nms_cpu.cpp:91-101: strict '<' keeps the lowest position)
+    float bv = -INFINITY;
+    int bp = 0x7fffffff;
+    for (int p0 = i + (int)threadIdx.x; p0 < nsegs; p0 += 8 * NT) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = SC[min(p0 + u * NT, nsegs - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + u * NT;
+        if (p < nsegs && (bp == 0x7fffffff || v[u] > bv)) { bv = v[u]; bp = p; }   // ascending p per thread: ties keep lowest
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int op = __shfl_xor(bp, o, 64);
+      if (op != 0x7fffffff && (bp == 0x7fffffff || ov > bv || (ov == bv && op < bp))) { bv = ov; bp = op; }
+    }
+    if (lane == 0) { s_val[wave] = bv; s_pos[wave] = bp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = s_val[0];
+      int p = s_pos[0];
+      for (int k = 1; k < NW; ++k) {
+        const int op = s_pos[k];
+        const float ov = s_val[k];
+        if (op != 0x7fffffff && (p == 0x7fffffff || ov > v || (ov == v && op < p))) { v = ov; p = op; }
+      }
+      // (b) swap slot i <-> p, emit det row i  (nms_cpu.cpp:103-121): all ten values requested before the first store
+      const float ax1 = X1[p], ax2 = X2[p], asc = SC[p], aar = AR[p];
+      const int aind = IND[p];
+      const float bx1 = X1[i], bx2 = X2[i], bsc = SC[i], bar = AR[i];
+      const int bind = IND[i];
+      X1[p] = bx1; X2[p] = bx2; SC[p] = bsc; AR[p] = bar; IND[p] = bind;
+      X1[i] = ax1; X2[i] = ax2; SC[i] = asc; AR[i] = aar; IND[i] = aind;
+      float* d = dets + (off + i) * 3;
+      d[0] = ax1; d[1] = ax2; d[2] = asc;
+      out_idx[off + i] = (long)aind;
+      s_pick[0] = ax1; s_pick[1] = ax2; s_pick[2] = aar;
+    }
+    __syncthreads();
+    // (c) decay every remaining score once (nms_cpu.cpp:124-143); row r = positions first + r * 1024 + thread
+    const float ix1 = s_pick[0], ix2 = s_pick[1], ia = s_pick[2];
+    const int first = i + 1;
+    const int span = nsegs - first;
+    const int rows = (span + NT - 1) / NT;
+    unsigned long long deadmask = 0, inmask = 0;          // bit r: this thread's candidate of row r is dead / exists
+    for (int r0 = 0; r0 < rows; r0 += 8) {
+      float jx1[8], jx2[8], ja[8], js[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = min(first + (r0 + u) * NT + (int)threadIdx.x, nsegs - 1);
+        jx1[u] = X1[p]; jx2[u] = X2[p]; ja[u] = AR[p]; js[u] = SC[p];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        const int p = first + r * NT + (int)threadIdx.x;
+        const bool in = r < rows && p < nsegs;
+        bool dd = false;
+        if (in) {
+          const float ovr = iou_1d(ix1, ix2, ia, jx1[u], jx2[u], ja[u]);
+          float weight = 1.f;
+          if (method == 0) { if (ovr >= thr) weight = 0.f; }
+          else if (method == 1) { if (ovr >= thr) weight = 1.f - ovr; }
+          else if (method == 2) { weight = expf_libm(-(ovr * ovr) / sigma); }
+          const float ns = js[u] * weight;
+          SC[p] = ns;
+          dd = ns < min_score;
+        }
+        if (r < rows) {                                    // (uniform)
+          const unsigned long long al = __ballot(in && !dd);
+          if (lane == 0) s_cnt[r * NW + wave] = __popcll(al);
+          if (in) inmask |= 1ull << r;
+          if (dd) deadmask |= 1ull << r;
+        }
+      }
+    }
+    __syncthreads();
+    // exclusive scan of the (row, wave) counts in position order, by wave 0
+    const int ent = rows * NW;
+    if (wave == 0) {
+      const int per = (ent + 63) / 64;
+      const int e0 = lane * per, e1 = min(ent, e0 + per);
+      int sum = 0;
+      for (int e = e0; e < e1; ++e) sum += s_cnt[e];
+      int inc = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      int run = inc - sum;
+      for (int e = e0; e < e1; ++e) { const int t = s_cnt[e]; s_cnt[e] = run; run += t; }
+      if (lane == 63) s_cnt[ent] = inc;
+    }
+    __syncthreads();
+    const int n_alive = s_cnt[ent];
+    const int new_n = first + n_alive;
+    // (d) swap-with-last removals (nms_cpu.cpp:146-154) as: k-th hole (ascending) <- k-th surviving element from the end
+    if (n_alive != span) {
+      for (int r = 0; r < rows; ++r) {
+        const bool in = (inmask >> r) & 1ull, dd = (deadmask >> r) & 1ull;
+        const unsigned long long al = __ballot(in && !dd);
+        const int p = first + r * NT + (int)threadIdx.x;
+        if (in && !dd && p >= new_n) {
+          const int a = s_cnt[r * NW + wave] + __popcll(al & lt);
+          TMP[n_alive - a - 1] = p;
+        }
+      }
+      __syncthreads();
+      for (int r = 0; r < rows; ++r) {
+        const bool in = (inmask >> r) & 1ull, dd = (deadmask >> r) & 1ull;
+        const unsigned long long al = __ballot(in && !dd);
+        const int p = first + r * NT + (int)threadIdx.x;
+        if (in && dd && p < new_n) {
+          const int a = s_cnt[r * NW + wave] + __popcll(al & lt);
+          const int src = TMP[(p - first) - a];
+          const float mx1 = X1[src], mx2 = X2[src], msc = SC[src], mar = AR[src];
+          const int mind = IND[src];
+          X1[p] = mx1; X2[p] = mx2; SC[p] = msc; AR[p] = mar; IND[p] = mind;
+        }
+      }
+      nsegs = new_n;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_cnt[cls] = i;
+}
+
 }  // namespace
+
+static bool soft_legacy() {
+  static const bool v = [] { const char* e = getenv("VILCO_SOFTNMS_LEGACY"); return e && e[0] == '1'; }();
+  return v;
+}
 
 extern "C" size_t vilco_nms_workspace(int64_t n_total, int32_t nseg) {
   // 7 words per candidate (x1, x2, score, area, index, keep list / scratch, dead flag) + one counter per class
@@ -448,9 +629,16 @@ extern "C" int vilco_softnms_1d(const float* segs, const float* scores, const in
   if (nseg == 0) return VILCO_OK;
   if (!segs || !scores || !dets || !out_idx || !workspace) return VILCO_ERR_BADARG;
   if (n_total < 0 || workspace_bytes < vilco_nms_workspace(n_total, nseg)) return VILCO_ERR_WORKSPACE;
-  hipLaunchKernelGGL(softnms_kernel, dim3(nseg), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), segs,
-                     scores, reinterpret_cast<const long*>(seg_off), iou_threshold, sigma, min_score, method,
-                     (long)max_num, dets, reinterpret_cast<long*>(out_idx), reinterpret_cast<long*>(out_cnt),
-                     workspace, (long)n_total);
+  // (the host knows the total only: every class fits the row-strided kernel when the total does)
+  if (n_total <= (int64_t)SROWS * NT && !soft_legacy())
+    hipLaunchKernelGGL(softnms_rows_kernel, dim3(nseg), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), segs,
+                       scores, reinterpret_cast<const long*>(seg_off), iou_threshold, sigma, min_score, method,
+                       (long)max_num, dets, reinterpret_cast<long*>(out_idx), reinterpret_cast<long*>(out_cnt),
+                       workspace, (long)n_total);
+  else
+    hipLaunchKernelGGL(softnms_kernel, dim3(nseg), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), segs,
+                       scores, reinterpret_cast<const long*>(seg_off), iou_threshold, sigma, min_score, method,
+                       (long)max_num, dets, reinterpret_cast<long*>(out_idx), reinterpret_cast<long*>(out_cnt),
+                       workspace, (long)n_total);
   return vilco_launch_status();
 }

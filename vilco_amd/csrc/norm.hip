@@ -227,6 +227,10 @@ int ln_blocks(long rows, long cap = 256) {
 // shared with the other translation units
 void vilco_reduce_rows(const float* ws, float* out0, float* out1, int nrows, int ncols, int split,
                        hipStream_t s) {
+  if (vilco_defer_active()) {          // recorded; issued with the others by vilco_defer_flush (defer.hip)
+    vilco_defer_push_rr(ws, out0, out1, nrows, ncols, split);
+    return;
+  }
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, ws, out0, out1,
                      nrows, ncols, split);
 }

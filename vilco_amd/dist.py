@@ -140,6 +140,9 @@ class GradReducer:
         but no collective is issued from the autograd hooks; `end_capture()` undoes it."""
         from . import ops
         self._hooks_live = bool(hooks)
+        # live hooks launch a bucket's all-reduce as soon as its last gradient arrives: every gradient must be complete when
+        # autograd hands it over, so the deferred finishing of ops.py (_Deferring) is off for such a backward
+        ops.defer_blocked = bool(hooks) and self.enabled
         ops.grad_slot_provider = self.grad_slot if self.enabled else None      # dW kernels write into the bucket slots
         self._handed = set()
         self._next = 0
@@ -175,6 +178,7 @@ class GradReducer:
         from . import ops
         if getattr(ops.grad_slot_provider, "__self__", None) is self:
             ops.grad_slot_provider = None
+        ops.defer_blocked = False
         self._hooks_live = True
 
     def end_capture(self):

@@ -74,6 +74,10 @@ class ConvTransformerBackbone(nn.Module):
         self.branch = nn.ModuleList([block((scale_factor, scale_factor), self.use_cross_modal)
                                      for _ in range(arch[2])])
 
+        if not self.use_xl and len(self.stem) > 0:
+            # stem[0] runs twice in this configuration (forward_tm below, backbones.py:276-278): the gradients through its
+            # mask-ignoring channel attention span ~1e10 between the first padded row and the rest (blocks.ChannelAttention)
+            self.stem[0].channel_attn.attn.wide_range = True
         if self.use_xl:
             if xlnet_config is None:
                 path = _find_xlnet_config(n_embd)

@@ -14,6 +14,8 @@ the isinstance checks of make_optimizer, train_utils.py:76-77); their forward is
 import math
 
 import numpy as np
+import os
+
 import torch
 from torch import nn
 
@@ -277,17 +279,28 @@ class MaskedMHCA(nn.Module):
 class ChannelAttention(nn.Module):
     """Attention over channels: softmax((k*scale)^T v) applied to q (blocks.py:412-436). [B,T,C] in/out."""
 
+    # Which of this block's backward products leave the ambient operand format for bf16 x3 when `wide_range` is set
+    # ("qkv", "core", "proj"; env VILCO_CA_WIDE overrides, for experiments).  The module ignores the mask (blocks.py:459-466,
+    # kept), so the padded rows of a short clip carry non-zero values through it; in a backbone that applies the block
+    # twice (no XLNet layer, backbones.py:276-278) the first padded row's gradient reaches ~1e10 x the typical element, more
+    # exponent range than ONE power-of-two scale per tensor leaves to the other rows of the fp16 x2 planes (DESIGN.md 7).
+    WIDE_PARTS = tuple(x for x in os.environ.get("VILCO_CA_WIDE", "qkv,core,proj").split(",") if x)
+
     def __init__(self, dim, num_heads=8, qkv_bias=False):
         super().__init__()
         self.num_heads = num_heads
         self.scale = (dim // num_heads) ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
+        self.wide_range = False          # set by the backbone on the block it applies twice
+
+    def _bp(self, part):
+        return 2 if (self.wide_range and part in self.WIDE_PARTS and ops.get_precision() == 3) else None
 
     def forward(self, x):
-        qkv = ops.linear(x.contiguous(), self.qkv.weight, self.qkv.bias)
-        a = ops.channel_attention(qkv, self.num_heads, self.scale)
-        return ops.linear(a, self.proj.weight, self.proj.bias)
+        qkv = ops.linear(x.contiguous(), self.qkv.weight, self.qkv.bias, bwd_precision=self._bp("qkv"))
+        a = ops.channel_attention(qkv, self.num_heads, self.scale, bwd_precision=self._bp("core"))
+        return ops.linear(a, self.proj.weight, self.proj.bias, bwd_precision=self._bp("proj"))
 
 
 class DropPath(nn.Module):

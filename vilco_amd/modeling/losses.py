@@ -1,6 +1,8 @@
-"""Losses of the MQ heads (reference: MQ/libs/modeling/losses.py:5-168).  Negligible FLOPs
-([#valid, ncls] / [#pos, 2] elementwise); round 1 evaluates them with device tensor ops under
-autograd -- the fused HIP loss kernel is listed as next work in DESIGN.md."""
+"""Losses of the MQ heads as device tensor expressions (reference: MQ/libs/modeling/losses.py:5-168).
+The training step does NOT go through this file: labelling + focal / DIoU / action-localisation losses run as the fused
+kernels `vilco_mq_loss_fwd / _bwd` (csrc/loss.hip, ops.mq_loss).  These functions are the
+`VILCO_FUSED_LOSS=0` path the fused kernels are tested equal to (tests/test_loss_gpu.py) and what iCaRL / BiC
+distillation terms and the narration SSL loss are built from."""
 import torch
 from torch.nn import functional as F
 

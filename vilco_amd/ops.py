@@ -158,7 +158,73 @@ def _chk(*ts):
 
 
 def _ws(nbytes, device):
-    return torch.empty(max(int(nbytes), 4), dtype=torch.uint8, device=device)
+    t = torch.empty(max(int(nbytes), 4), dtype=torch.uint8, device=device)
+    if _defer["on"]:
+        _defer["keep"].append(t)          # partials a recorded second stage will read at the flush
+    return t
+
+
+# ---- deferred finishing of the backward pass's two-stage reductions (csrc/defer.hip, include/vilco_hip.h).
+# Column sums into PARAMETER gradients (LayerNorm affine, biases, scales, depthwise taps) and the slab sums of split-K
+# weight-gradient products end in small second launches -- ~350 dependent graph nodes per step that nothing in backward
+# waits for.  Inside `with _Deferring(param, ...)` the library records them; one autograd end-of-backward callback issues
+# them all as a few batched launches (bitwise the same sums).  Two things make that safe:
+#   * a parameter used twice in the forward gets its second gradient while the first is still unfinished and autograd adds
+#     the two in place -- so a second deferral for the same storage first flushes what is pending and then runs undeferred;
+#   * nothing may read gradients during backward: dist.GradReducer's autograd hooks do (they launch the all-reduce of a
+#     complete bucket), so it blocks deferral while they are live (`defer_blocked`).
+# Tensors a recorded item reads or writes are held until the flush (a gradient autograd drops would otherwise hand its
+# memory to the next allocation).  VILCO_DEFER_FINISH=0 switches the whole thing off (tested equal).
+defer_finish = os.environ.get("VILCO_DEFER_FINISH", "1") != "0"
+defer_blocked = False
+_defer = {"on": False, "armed": False, "task": -1, "keep": [], "pending": set()}
+
+
+def _defer_flush():
+    st = _defer
+    if _lib.load().vilco_defer_pending():
+        _lib.check(_lib.load().vilco_defer_flush(_stream()))
+    else:
+        _lib.load().vilco_defer_set(0)
+    st["on"], st["armed"] = False, False
+    st["keep"].clear()
+    st["pending"].clear()
+
+
+class _Deferring:
+    def __init__(self, *params):
+        self.ptrs = [p.data_ptr() for p in params if p is not None]
+        self.on = False
+
+    def __enter__(self):
+        if not (defer_finish and not defer_blocked and self.ptrs and torch._C._current_graph_task_id() != -1):
+            return self
+        st = _defer
+        task = torch._C._current_graph_task_id()
+        if st["armed"] and st["task"] != task:
+            _defer_flush()                 # left over from a backward that ended in an exception: its callback never ran
+        if any(p in st["pending"] for p in self.ptrs):
+            armed = st["armed"]
+            _defer_flush()                 # second use of a parameter: finish its first gradient before autograd adds to it
+            st["armed"] = armed            # (the end-of-backward callback is still queued)
+            return self
+        if not st["armed"]:
+            torch.autograd.Variable._execution_engine.queue_callback(_defer_flush)
+            st["armed"], st["task"] = True, task
+        st["pending"].update(self.ptrs)
+        _lib.load().vilco_defer_set(1)
+        st["on"] = self.on = True
+        return self
+
+    def hold(self, *tensors):
+        if self.on:
+            _defer["keep"].extend(t for t in tensors if t is not None)
+
+    def __exit__(self, *a):
+        if self.on:
+            _lib.load().vilco_defer_set(0)
+            _defer["on"] = False
+        return False
 
 
 # ---------------------------------------------------------------------------------------- dropout
@@ -253,6 +319,8 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     d.res_masked = int(res_masked)
     nbytes = lib.vilco_gemm_workspace(C.byref(d))      # bf16 operand planes + split-K partials
     ws = torch.empty(nbytes, dtype=torch.uint8, device=Cc.device)
+    if _defer["on"]:
+        _defer["keep"].extend((ws, Cc))    # split-K slabs of a recorded weight-gradient product, and its output
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     for pre, am in (("a", a_amax), ("b", b_amax)):          # (partials, count) of an operand this call packs itself
         if am is not None and am[0] is not None and d.precision in (3, 4):
@@ -405,30 +473,36 @@ def weight_planes(w, rows, cols):
     return _cached(w, ("planes", rows, cols), lambda: pack(_weight_src(w, w.detach()), rows, cols))
 
 
-def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0)):
-    """dz = dropmask(dy) * act'(aux) * rowmask, optional column sums -> (dz, dbias)."""
+def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None):
+    """dz = dropmask(dy) * act'(aux) * rowmask, optional column sums -> (dz, dbias).  bias_param: the parameter dbias is the
+    gradient of (its column sum may then finish with the other deferred reductions, see _Deferring)."""
     lib = _lib.load()
     rows, Cn = dy.numel() // dy.shape[-1], dy.shape[-1]
     dz = torch.empty_like(dy)
     db = torch.empty(Cn, dtype=torch.float32, device=dy.device) if want_bias else None
-    ws = _ws(lib.vilco_colsum_workspace(rows, Cn), dy.device) if want_bias else None
-    parts = torch.empty(AMAX_PARTS, dtype=torch.float32, device=dy.device) if (produce_amax and _precision == 3) else None
-    n = C.c_int32(0)
-    _lib.check(lib.vilco_act_bwd_amax(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
-                                      int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
-                                      _p(parts), C.byref(n), _stream()))
+    with _Deferring(bias_param if want_bias else None) as dfr:
+        ws = _ws(lib.vilco_colsum_workspace(rows, Cn), dy.device) if want_bias else None
+        parts = torch.empty(AMAX_PARTS, dtype=torch.float32, device=dy.device) if (produce_amax and _precision == 3) else None
+        n = C.c_int32(0)
+        _lib.check(lib.vilco_act_bwd_amax(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
+                                          int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
+                                          _p(parts), C.byref(n), _stream()))
+        dfr.hold(db)
     if parts is not None:
         _tag_amax(dz, parts, n.value)
     return dz, db
 
 
-def colsum(x2d):
+def colsum(x2d, param=None):
+    """column sums of x2d; param: the parameter the result is the gradient of (deferred finish, see _Deferring)"""
     lib = _lib.load()
     rows, Cn = x2d.shape
     out = torch.empty(Cn, dtype=torch.float32, device=x2d.device)
-    ws = _ws(lib.vilco_colsum_workspace(rows, Cn), x2d.device)
-    _lib.check(lib.vilco_colsum(x2d.data_ptr(), out.data_ptr(), rows, Cn, ws.data_ptr(), ws.numel(),
-                                _stream()))
+    with _Deferring(param) as dfr:
+        ws = _ws(lib.vilco_colsum_workspace(rows, Cn), x2d.device)
+        _lib.check(lib.vilco_colsum(x2d.data_ptr(), out.data_ptr(), rows, Cn, ws.data_ptr(), ws.numel(),
+                                    _stream()))
+        dfr.hold(out, x2d)
     return out
 
 
@@ -437,10 +511,11 @@ class _Linear(torch.autograd.Function):
     last_amax = (None, 0)
 
     @staticmethod
-    def forward(ctx, x, w, b, act, lens, T, drop_p=0.0, drop_site="dropout"):
+    def forward(ctx, x, w, b, act, lens, T, drop_p=0.0, drop_site="dropout", bwd_precision=None):
         _chk(x, w, b)
         K = x.shape[-1]
         N = w.shape[0]
+        ctx.bwd_precision = bwd_precision
         assert w.numel() == N * K, "weight shape %s does not match input dim %d" % (tuple(w.shape), K)
         M = x.numel() // K
         y = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
@@ -458,22 +533,34 @@ class _Linear(torch.autograd.Function):
         _Linear.last_amax = _amax_of(y)
         ctx.act, ctx.T = act, T
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x, w, pre if act == ACT_GELU else (y if act == ACT_RELU else None), lens, px, pw)
+        ctx.save_for_backward(x, w, pre if act == ACT_GELU else (y if act == ACT_RELU else None), lens, px, pw, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, aux, lens, px, pw = ctx.saved_tensors
+        x, w, aux, lens, px, pw, b = ctx.saved_tensors
         dy = dy.contiguous()
         K, N = x.shape[-1], w.shape[0]
         M = x.numel() // K
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.act != ACT_NONE or lens is not None or ctx.drop[0] > 0.0:
-            dz, db = _act_bwd(dy, aux, ctx.act, lens, ctx.T, need_db, ctx.drop)
+            dz, db = _act_bwd(dy, aux, ctx.act, lens, ctx.T, need_db, ctx.drop, bias_param=b)
         else:
-            dz, db = dy, (colsum(dy.view(M, N)) if need_db else None)
+            dz, db = dy, (colsum(dy.view(M, N), param=b) if need_db else None)
         dx = dw = pz = None
         prec = None
+        if ctx.bwd_precision is not None:
+            # a call site whose gradient tensors span more exponent range than one scale per tensor can carry (see
+            # `wide_range` in modeling/blocks.py: ChannelAttention): both backward products from the fp32 tensors, in the
+            # requested format (bf16 x3: 8 exponent bits per element)
+            bp = int(ctx.bwd_precision)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=bp)
+            if ctx.needs_input_grad[1]:
+                dw = _grad_out(w)
+                gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=bp)
+            return dx, dw, db, None, None, None, None, None, None
         if px is not None:                       # one pack of dZ feeds dX and dW; X and W planes come from forward
             prec = ctx.prec
             pz = pack(dz, M, N, prec)
@@ -481,19 +568,20 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=prec, a_planes=pz, b_planes=pw, want_amax=True)   # dX = dZ W     (NN)
         if ctx.needs_input_grad[1]:
-            with _DwFork(w):
+            with _DwFork(w), _Deferring(w):          # (a split-K slab sum of this product may finish with the deferred ones)
                 dw = _grad_out(w)
                 gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(prec, M), a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def linear(x, w, b=None, act=ACT_NONE, lens=None, T=None, drop_p=0.0, drop_site="dropout"):
+def linear(x, w, b=None, act=ACT_NONE, lens=None, T=None, drop_p=0.0, drop_site="dropout", bwd_precision=None):
     """drop_p: nn.Dropout(drop_p) applied to the layer's output (pass 0 outside training), fused into the GEMM epilogue.
-    With a ReLU (output saved as the activation witness) the dropout stays a separate op."""
+    With a ReLU (output saved as the activation witness) the dropout stays a separate op.
+    bwd_precision: operand format of this layer's two backward products when not the ambient one (2 = bf16 x3)."""
     if drop_p > 0.0 and act == ACT_RELU:
-        return dropout(_Linear.apply(x, w, b, act, lens, T, 0.0, drop_site), drop_p, True, drop_site)
+        return dropout(_Linear.apply(x, w, b, act, lens, T, 0.0, drop_site, bwd_precision), drop_p, True, drop_site)
     _Linear.last_amax = (None, 0)
-    y = _Linear.apply(x, w, b, act, lens, T, float(drop_p), drop_site)
+    y = _Linear.apply(x, w, b, act, lens, T, float(drop_p), drop_site, bwd_precision)
     if _Linear.last_amax[0] is not None:            # max|y| partials left by the GEMM epilogue
         _tag_amax(y, *_Linear.last_amax)
     _Linear.last_amax = (None, 0)
@@ -540,7 +628,7 @@ class _LinearKN(torch.autograd.Function):
             dx = torch.empty_like(x)
             gemm(dy, w, dx, M, K, N, 1, 1, N, N, K, precision=prec, a_planes=pz, b_planes=pw)   # dX = dY W^T   (NT)
         if ctx.needs_input_grad[1]:
-            with _DwFork(w):
+            with _DwFork(w), _Deferring(w):
                 dw = _grad_out(w)
                 gemm(x, dy, dw, K, N, M, 0, 0, K, N, N, precision=_dw_prec(prec, M), a_planes=px, b_planes=pz)   # dW = X^T dY   (TN)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -586,20 +674,20 @@ class _Conv3(torch.autograd.Function):
         gemm(x, wp, y, B * T, Cout, 3 * Cin, 1, 1, Cin, 3 * Cin, Cout, tap=TAP_A, tapC=Cin, tapT=T,
              bias=b, row_len=lens, rowT=T, b_planes=pwp, a_amax=_amax_of(x))
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x, w, lens)
+        ctx.save_for_backward(x, w, lens, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, lens = ctx.saved_tensors
+        x, w, lens, b = ctx.saved_tensors
         B, T, Cin = x.shape
         Cout = w.shape[0]
         dy = dy.contiguous()
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
         if lens is not None:
-            dz, db = _act_bwd(dy, None, ACT_NONE, lens, T, need_db)
+            dz, db = _act_bwd(dy, None, ACT_NONE, lens, T, need_db, bias_param=b)
         else:
-            dz, db = dy, (colsum(dy.view(B * T, Cout)) if need_db else None)
+            dz, db = dy, (colsum(dy.view(B * T, Cout), param=b) if need_db else None)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             # wt[ci][j'][co] = w[co][ci][2-j']: dX is the k=3 conv of dZ with flipped taps
@@ -653,11 +741,13 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty(Cn, dtype=torch.float32, device=x.device)
         db = torch.empty(Cn, dtype=torch.float32, device=x.device)
-        ws = _ws(lib.vilco_layernorm_bwd_workspace(rows, Cn), x.device)
-        _lib.check(lib.vilco_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _p(y), _p(gamma),
-                                           mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                                           dg.data_ptr(), db.data_ptr(), rows, Cn, int(ctx.relu),
-                                           ws.data_ptr(), ws.numel(), _stream()))
+        with _Deferring(gamma) as dfr:           # the d-gamma / d-beta column sums may finish with the other deferred ones
+            ws = _ws(lib.vilco_layernorm_bwd_workspace(rows, Cn), x.device)
+            _lib.check(lib.vilco_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _p(y), _p(gamma),
+                                               mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                               dg.data_ptr(), db.data_ptr(), rows, Cn, int(ctx.relu),
+                                               ws.data_ptr(), ws.numel(), _stream()))
+            dfr.hold(dg, db)
         return dx, dg.view_as(gamma), db.view_as(gamma), None, None
 
 
@@ -691,10 +781,12 @@ class _DwConv3(torch.autograd.Function):
         B, T, Cn = x.shape
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        ws = _ws(lib.vilco_dwconv3_bwd_workspace(B, T, Cn, ctx.stride), x.device)
-        _lib.check(lib.vilco_dwconv3_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), lens.data_ptr(),
-                                         _p(dx), _p(dw), B, T, Cn, ctx.stride, ws.data_ptr(),
-                                         ws.numel(), _stream()))
+        with _Deferring(w if dw is not None else None) as dfr:
+            ws = _ws(lib.vilco_dwconv3_bwd_workspace(B, T, Cn, ctx.stride), x.device)
+            _lib.check(lib.vilco_dwconv3_bwd(dy.data_ptr(), x.data_ptr(), w.data_ptr(), lens.data_ptr(),
+                                             _p(dx), _p(dw), B, T, Cn, ctx.stride, ws.data_ptr(),
+                                             ws.numel(), _stream()))
+            dfr.hold(dw)
         return dx, dw, None, None
 
 
@@ -763,11 +855,13 @@ class _ScaleAdd(torch.autograd.Function):
         db = dout if plain_b else (torch.empty_like(b) if need_b else None)
         dcs = torch.empty(Cn, dtype=torch.float32, device=b.device) if need_cs else None
         if (need_a and not plain_a) or (need_b and not plain_b) or need_cs:
-            ws = _ws(lib.vilco_colsum_workspace(B * T, Cn), b.device) if need_cs else None
-            _lib.check(lib.vilco_scale_add_bwd(
-                dout.data_ptr(), b.data_ptr(), _p(colscale), _p(rowscale), _p(lens), ctx.mask_a,
-                None if plain_a else _p(da), None if plain_b else _p(db), _p(dcs), B, T, Cn, _p(ws),
-                ws.numel() if ws is not None else 0, _stream()))
+            with _Deferring(colscale if need_cs else None) as dfr:
+                ws = _ws(lib.vilco_colsum_workspace(B * T, Cn), b.device) if need_cs else None
+                _lib.check(lib.vilco_scale_add_bwd(
+                    dout.data_ptr(), b.data_ptr(), _p(colscale), _p(rowscale), _p(lens), ctx.mask_a,
+                    None if plain_a else _p(da), None if plain_b else _p(db), _p(dcs), B, T, Cn, _p(ws),
+                    ws.numel() if ws is not None else 0, _stream()))
+                dfr.hold(dcs)
         return da, db, (dcs.view_as(colscale) if need_cs else None), None, None, None
 
 
@@ -1172,8 +1266,9 @@ class _ChannelAttn(torch.autograd.Function):
     A_h = softmax_rows(scale * k_h^T v_h)  [hd,hd];  out_h[t,:] = q_h[t,:] A_h^T."""
 
     @staticmethod
-    def forward(ctx, qkv, H, scale):
+    def forward(ctx, qkv, H, scale, bwd_precision=None):
         _chk(qkv)
+        ctx.bp = bwd_precision
         B, T, C3 = qkv.shape
         Cn = C3 // 3
         hd = Cn // H
@@ -1203,22 +1298,23 @@ class _ChannelAttn(torch.autograd.Function):
         sO = (T * Cn, hd)
         dqkv = torch.empty_like(qkv)
         # dq[t,e] = sum_d dout[t,d] A[d,e]                                   (NN)
-        gemm(dout, A, dqkv, T, hd, hd, 1, 0, Cn, hd, C3, batch=(B, H), sA=sO, sB=sA_, sC=sQ)
+        bp = ctx.bp                            # None: the ambient format (see _Linear.backward on bwd_precision)
+        gemm(dout, A, dqkv, T, hd, hd, 1, 0, Cn, hd, C3, batch=(B, H), sA=sO, sB=sA_, sC=sQ, precision=bp)
         # dA[d,e] = sum_t dout[t,d] q[t,e]                                   (TN)
         dA = torch.empty_like(A)
-        gemm(dout, qkv, dA, hd, hd, T, 0, 0, Cn, C3, hd, batch=(B, H), sA=sO, sB=sQ, sC=sA_)
+        gemm(dout, qkv, dA, hd, hd, T, 0, 0, Cn, C3, hd, batch=(B, H), sA=sO, sB=sQ, sC=sA_, precision=bp)
         _lib.check(lib.vilco_softmax_bwd(dA.data_ptr(), A.data_ptr(), B, H, hd, hd, _stream()))
         # S[d,e] = scale * sum_t k[t,d] v[t,e]:  dk[t,d] = scale * sum_e v[t,e] dS[d,e]   (NT)
         gemm(qkv, dA, dqkv, T, hd, hd, 1, 1, C3, hd, C3, batch=(B, H), sA=sQ, sB=sA_, sC=sQ,
-             offA=2 * Cn, offC=Cn, alpha=scale)
+             offA=2 * Cn, offC=Cn, alpha=scale, precision=bp)
         # dv[t,e] = scale * sum_d k[t,d] dS[d,e]                                          (NN)
         gemm(qkv, dA, dqkv, T, hd, hd, 1, 0, C3, hd, C3, batch=(B, H), sA=sQ, sB=sA_, sC=sQ, offA=Cn,
-             offC=2 * Cn, alpha=scale)
-        return dqkv, None, None
+             offC=2 * Cn, alpha=scale, precision=bp)
+        return dqkv, None, None, None
 
 
-def channel_attention(qkv, n_head, scale):
-    return _ChannelAttn.apply(qkv, int(n_head), float(scale))
+def channel_attention(qkv, n_head, scale, bwd_precision=None):
+    return _ChannelAttn.apply(qkv, int(n_head), float(scale), bwd_precision)
 
 
 # ---------------------------------------------------------------------------------------- labels + losses
@@ -1361,20 +1457,22 @@ class _QkvPre(torch.autograd.Function):
         dh = torch.empty_like(x)
         dpar = torch.empty(15, Cn, dtype=torch.float32, device=dev)
         nws = lib.vilco_qkv_pre_bwd_workspace(B, T, Cn, ctx.stride)
-        ws = _ws(nws, dev)
         means, rstds = [stats[2 * j] for j in range(3)], [stats[2 * j + 1] for j in range(3)]
         dh_ext = None if dh_ext is None else dh_ext.contiguous()
-        _lib.check(lib.vilco_qkv_pre_bwd(h.data_ptr(), _ptr3([wq, wk, wv]), _ptr3([gq, gk, gv]), _ptr3(dys), _ptr3(means),
-                                         _ptr3(rstds), lens.data_ptr(), _p(dh_ext), _ptr3(dcs), dh.data_ptr(), dpar.data_ptr(),
-                                         B, T, Cn, ctx.stride, ws.data_ptr(), nws, _stream()))
-        del dcs
         dx = torch.empty_like(x)
         dg1 = torch.empty(Cn, dtype=torch.float32, device=dev)
         db1 = torch.empty(Cn, dtype=torch.float32, device=dev)
-        ws1 = _ws(lib.vilco_layernorm_bwd_workspace(B * T, Cn), dev)
-        _lib.check(lib.vilco_layernorm_bwd(dh.data_ptr(), x.data_ptr(), None, _p(g1), stats1[0].data_ptr(), stats1[1].data_ptr(),
-                                           dx.data_ptr(), dg1.data_ptr(), db1.data_ptr(), B * T, Cn, 0, ws1.data_ptr(),
-                                           ws1.numel(), _stream()))
+        with _Deferring(g1, wq, wk, wv, gq, gk, gv) as dfr:      # 15 parameter-gradient rows + LN1's affine gradients
+            ws = _ws(nws, dev)
+            _lib.check(lib.vilco_qkv_pre_bwd(h.data_ptr(), _ptr3([wq, wk, wv]), _ptr3([gq, gk, gv]), _ptr3(dys), _ptr3(means),
+                                             _ptr3(rstds), lens.data_ptr(), _p(dh_ext), _ptr3(dcs), dh.data_ptr(), dpar.data_ptr(),
+                                             B, T, Cn, ctx.stride, ws.data_ptr(), nws, _stream()))
+            del dcs
+            ws1 = _ws(lib.vilco_layernorm_bwd_workspace(B * T, Cn), dev)
+            _lib.check(lib.vilco_layernorm_bwd(dh.data_ptr(), x.data_ptr(), None, _p(g1), stats1[0].data_ptr(), stats1[1].data_ptr(),
+                                               dx.data_ptr(), dg1.data_ptr(), db1.data_ptr(), B * T, Cn, 0, ws1.data_ptr(),
+                                               ws1.numel(), _stream()))
+            dfr.hold(dpar, dg1, db1)
         dws = [dpar[6 + 3 * j:9 + 3 * j].view_as(w) for j, w in enumerate((wq, wk, wv))]      # already [C][1][3] (qkvpre.hip)
         dgs = [dpar[2 * j].view_as(g) for j, g in enumerate((gq, gk, gv))]
         dbs = [dpar[2 * j + 1].view_as(g) for j, g in enumerate((gq, gk, gv))]
