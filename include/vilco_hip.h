@@ -454,7 +454,7 @@ int vilco_cl_penalty(const int64_t* ptrs, const int64_t* numel, const int32_t* c
 /* Deferred finishing (csrc/defer.hip).  The second stage of every two-stage column reduction (LayerNorm d-gamma / d-beta,  */
 /* bias and scale gradients, depthwise-tap gradients: reference autograd sums under blocks.py:152-166, 106-130, 628-641)  */
 /* and the slab sum of a split-K product with a plain epilogue are small dependent launches whose results -- parameter     */
-/* gradients -- nothing reads before backward ends.  While vilco_defer_set(1) is in force on the calling thread they are   */
+/* gradients -- nothing reads before backward ends.  While vilco_defer_set(1) is in force (process-wide) they are            */
 /* recorded instead of launched; vilco_defer_flush(stream) issues all recorded items as a few batched launches (same       */
 /* arithmetic, same order: bitwise the results of the individual launches) and switches recording off.  The partial buffers */
 /* (workspaces) of recorded calls must stay alive until the flush.                                                        */

@@ -4,11 +4,12 @@
 // depthwise-tap gradients) and every split-K weight-gradient product ends in a small second launch that folds per-block
 // partials: ~350 launches per step of config P, 4-6 us each because each is a dependent node, not because of its bytes
 // (profiles/r03_z_bench_kernel_stats.csv: splitk_reduce 148, reduce_rows 156, colsum 46).  Their results are PARAMETER
-// gradients: nothing in backward reads them.  While vilco_defer_set(1) is in force on the calling thread those second
+// gradients: nothing in backward reads them.  While vilco_defer_set(1) is in force those second
 // stages are RECORDED instead of launched; vilco_defer_flush issues them as a handful of batched launches (the item table
 // travels in the kernel arguments).  Each item is finished by the same arithmetic in the same order as its own launch
 // would have used, so results are bitwise the same.  The caller keeps the partial buffers alive until the flush
 // (vilco_amd/ops.py: _defer).
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -32,12 +33,16 @@ struct SKItem {           // out[m][n] = sum_s part[s][m][n] in split order (spl
 constexpr int SK_MAX = 64;
 struct SKBatch { SKItem it[SK_MAX]; int n; };
 
+// ONE recording per process, not per thread: autograd runs the backward functions of device tensors on its worker thread
+// and the end-of-backward callback that flushes on the thread that called backward().  (Recording is a mode of the one
+// training loop of the process; entry points used from other threads meanwhile would be recorded too.)
 struct State {
   bool on = false;
   std::vector<RRItem> rr;
   std::vector<SKItem> sk;
+  std::mutex mu;
 };
-State& st() { static thread_local State s; return s; }
+State& st() { static State s; return s; }
 
 template <class B>
 __device__ __forceinline__ int find_item(const B& b, int blk) {
@@ -113,10 +118,12 @@ __global__ __launch_bounds__(256) void splitk_sum_many_kernel(SKBatch b) {
 bool vilco_defer_active() { return st().on; }
 
 void vilco_defer_push_rr(const float* ws, float* out0, float* out1, int nrows, int ncols, int split) {
+  std::lock_guard<std::mutex> g(st().mu);
   st().rr.push_back(RRItem{ws, out0, out1, nrows, ncols, split, 0});
 }
 
 void vilco_defer_push_sk(const float* part, float* out, long split_stride, long ldc, int M, int N, int ksplit) {
+  std::lock_guard<std::mutex> g(st().mu);
   st().sk.push_back(SKItem{part, out, split_stride, ldc, M, N, ksplit, 0, 0});
 }
 
@@ -125,10 +132,14 @@ extern "C" int vilco_defer_set(int32_t on) {
   return VILCO_OK;
 }
 
-extern "C" int64_t vilco_defer_pending(void) { return (int64_t)(st().rr.size() + st().sk.size()); }
+extern "C" int64_t vilco_defer_pending(void) {
+  std::lock_guard<std::mutex> g(st().mu);
+  return (int64_t)(st().rr.size() + st().sk.size());
+}
 
 extern "C" int vilco_defer_flush(void* stream) {
   State& s = st();
+  std::lock_guard<std::mutex> g(s.mu);
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   for (size_t i0 = 0; i0 < s.rr.size(); i0 += RR_MAX) {
     RRBatch b;

@@ -169,26 +169,32 @@ def _ws(nbytes, device):
 # weight-gradient products end in small second launches -- ~350 dependent graph nodes per step that nothing in backward
 # waits for.  Inside `with _Deferring(param, ...)` the library records them; one autograd end-of-backward callback issues
 # them all as a few batched launches (bitwise the same sums).  Two things make that safe:
-#   * a parameter used twice in the forward gets its second gradient while the first is still unfinished and autograd adds
-#     the two in place -- so a second deferral for the same storage first flushes what is pending and then runs undeferred;
+#   * a parameter used twice in the forward: autograd sums its gradients the moment the second one arrives -- so only the
+#     FIRST gradient a backward produces for a storage is deferred; a later one flushes what is still recorded (when the
+#     first is among it) and is finished in place;
 #   * nothing may read gradients during backward: dist.GradReducer's autograd hooks do (they launch the all-reduce of a
 #     complete bucket), so it blocks deferral while they are live (`defer_blocked`).
 # Tensors a recorded item reads or writes are held until the flush (a gradient autograd drops would otherwise hand its
 # memory to the next allocation).  VILCO_DEFER_FINISH=0 switches the whole thing off (tested equal).
 defer_finish = os.environ.get("VILCO_DEFER_FINISH", "1") != "0"
 defer_blocked = False
-_defer = {"on": False, "armed": False, "task": -1, "keep": [], "pending": set()}
+_defer = {"on": False, "armed": False, "task": -1, "keep": [], "pending": set(), "seen": set()}
 
 
-def _defer_flush():
+def _defer_flush(final=True):
+    """issue what is recorded.  final: the end-of-backward callback (or a reset) -- also forgets which parameters this
+    backward has already produced a gradient for"""
     st = _defer
     if _lib.load().vilco_defer_pending():
         _lib.check(_lib.load().vilco_defer_flush(_stream()))
     else:
         _lib.load().vilco_defer_set(0)
-    st["on"], st["armed"] = False, False
+    st["on"] = False
     st["keep"].clear()
     st["pending"].clear()
+    if final:
+        st["armed"] = False
+        st["seen"].clear()
 
 
 class _Deferring:
@@ -203,22 +209,26 @@ class _Deferring:
         task = torch._C._current_graph_task_id()
         if st["armed"] and st["task"] != task:
             _defer_flush()                 # left over from a backward that ended in an exception: its callback never ran
-        if any(p in st["pending"] for p in self.ptrs):
-            armed = st["armed"]
-            _defer_flush()                 # second use of a parameter: finish its first gradient before autograd adds to it
-            st["armed"] = armed            # (the end-of-backward callback is still queued)
+        if any(p in st["seen"] for p in self.ptrs):
+            # a further use of a parameter: autograd sums its gradients the moment this one arrives, so the earlier one
+            # must be complete by then (flush if it is still recorded) and this one is finished in place
+            if any(p in st["pending"] for p in self.ptrs):
+                _defer_flush(final=False)
             return self
         if not st["armed"]:
             torch.autograd.Variable._execution_engine.queue_callback(_defer_flush)
             st["armed"], st["task"] = True, task
         st["pending"].update(self.ptrs)
+        st["seen"].update(self.ptrs)
         _lib.load().vilco_defer_set(1)
         st["on"] = self.on = True
         return self
 
     def hold(self, *tensors):
+        # an ALIAS of each tensor: holding the tensor object itself would raise its reference count, and AccumulateGrad
+        # only adopts a gradient it holds the sole reference to (otherwise it copies -- here: the unfinished values)
         if self.on:
-            _defer["keep"].extend(t for t in tensors if t is not None)
+            _defer["keep"].extend(t.detach() for t in tensors if t is not None)
 
     def __exit__(self, *a):
         if self.on:
@@ -320,7 +330,7 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     nbytes = lib.vilco_gemm_workspace(C.byref(d))      # bf16 operand planes + split-K partials
     ws = torch.empty(nbytes, dtype=torch.uint8, device=Cc.device)
     if _defer["on"]:
-        _defer["keep"].extend((ws, Cc))    # split-K slabs of a recorded weight-gradient product, and its output
+        _defer["keep"].extend((ws, Cc.detach()))    # split-K slabs of a recorded weight-gradient product, and (an alias of) its output
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     for pre, am in (("a", a_amax), ("b", b_amax)):          # (partials, count) of an operand this call packs itself
         if am is not None and am[0] is not None and d.precision in (3, 4):
