@@ -190,13 +190,17 @@ def test_p_config_train_step_vs_fp32_oracle_with_replayed_masks(dev):
     assert ctx.leftover() == {}, ctx.leftover()
     for k in ('cls_loss', 'reg_loss', 'final_loss'):
         assert abs(got_losses[k] - float(want[k])) <= 1e-3 * abs(float(want[k])), (k, got_losses[k], float(want[k]))
-    # Two executions of this model in different arithmetic cannot agree element by element at THIS size: the embedding and
-    # head trunks are LayerNorm -> ReLU over 2 x 9.4 M pre-activations, a handful of which lie within the forward rounding
-    # error of zero in any given step; there the two runs take different sides of the ReLU, and the whole gradient term of
-    # that (token, channel) appears in one run only -- ~1/sqrt(B T) of a weight-gradient row, 1e-3 ... 3e-3 of the tensor's
-    # maximum (the fp32 reference differs from an fp64 run of itself the same way).  So: every tensor within
-    # 1e-3 in the L2 sense (a flipped row is invisible there), within 1e-3 of its maximum in all but a vanishing fraction of
-    # elements, and no element further than 5e-3.
+    # What "within 1e-3 of the fp32 reference" can mean at THIS size was measured in round 4 (profiles/r04_oracle_*.json,
+    # tools/diag/oracle_perturbation.py, oracle_self_distance.py; profiles/r04_p_parity_stats_*.json for this very comparison):
+    #   * the fp32 reference is reproducible -- re-rounding every parameter by <= 1 ulp moves no gradient element by more than
+    #     2.7e-5 of its tensor's maximum;
+    #   * the embedding trunk is LayerNorm -> ReLU over 2 x 9.4 M pre-activations, a handful of which lie within ~1e-6 of zero;
+    #     an arithmetic whose products carry 22-bit operands (errors ~4 ulp, on activations as well as weights) puts a few of
+    #     them on the other side of the ReLU, and the whole gradient term of that (token, channel) appears in one run only:
+    #     ONE tensor (embd.0.conv.weight) shows a row at 1.9e-3 of its maximum (3e-5 of its elements beyond 1e-3), the next
+    #     (embd.1.conv.weight) stands at 8e-4, every other tensor below 4.1e-4 (strict 3-MFMA weight gradients: below 9e-5).
+    # Bounds: every tensor within 1e-3 in the L2 sense (measured 3.3e-4), at most two tensors with any element beyond 1e-3 of
+    # the maximum, none beyond 3e-3, and never more than 1e-4 of a tensor's elements.
     l2, outliers, worst = [], [], []
     for k, g in got.items():
         if p[k].grad is not None and not k.endswith(('key_norm.bias', '.key.bias')):     # analytically zero (softmax shift)
@@ -210,5 +214,5 @@ def test_p_config_train_step_vs_fp32_oracle_with_replayed_masks(dev):
     outliers.sort(reverse=True)
     assert len(worst) > 300 and max(l2) < 1e-3, (max(l2), worst[:5])
     assert outliers[0][0] < 1e-4, outliers[:5]
-    assert worst[0][0] < 5e-3, worst[:8]
-    assert sum(1 for e, _ in worst if e < 1e-3) >= len(worst) - 6, worst[:10]
+    assert worst[0][0] < 3e-3, worst[:8]
+    assert sum(1 for e, _ in worst if e < 1e-3) >= len(worst) - 2, worst[:10]
