@@ -215,7 +215,7 @@ def pmc_traffic():
     """HBM bytes per GEMM-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950
     note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); None when the summary is absent."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # newest committed summary
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # newest committed summary
         try:
             return json.load(open(os.path.join(prof, name)))["gemm_pp_kernel"]["hbm_bytes_per_launch"]
         except Exception:

@@ -47,7 +47,8 @@ def _train(dev, mode, steps=4):
     batch = golden_inputs(gold)
     opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-3))
     red = GradReducer(model, bucket_mb=0.05) if mode != "plain" else None
-    graph = GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=2, reducer=red) if mode == "graph" else None
+    graph = (GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=2, reducer=red, comm_in_graph=(mode == "graph_comm"))
+             if mode in ("graph", "graph_comm") else None)
     losses, in_slots = [], 0
     for it in range(steps):
         if graph is not None:
@@ -82,7 +83,8 @@ def test_reducer_paths_reproduce_the_single_process_run(dev, one_rank_group):
     l1, s1, in_slots = _train(dev, "hooks")
     assert in_slots >= 40, in_slots                 # the matrices' gradients were produced in place
     l2, s2, _ = _train(dev, "graph")
-    for other_l, other_s in ((l1, s1), (l2, s2)):
+    l3, s3, _ = _train(dev, "graph_comm")          # the all-reduces captured inside graph 1 (or the fallback, if the runtime refuses)
+    for other_l, other_s in ((l1, s1), (l2, s2), (l3, s3)):
         assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(other_l, l0)), (other_l, l0)
         for k in s0:
             # (key / key-norm biases: analytically zero gradients, 1e-12-level noise that Adam turns into +-lr steps)

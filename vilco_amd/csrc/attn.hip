@@ -994,6 +994,37 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
 // registers).  No transposed K planes, no transposed tile in LDS.
 // XL: XLNet's relative attention as in attn_fwd64_kernel<true> (position scores prefetched into LDS by LDS-DMA, XLNet
 // mask, probability dropout) plus the dS store the position-term gradients are derived from (a.dbias, [B,H,Tq,Tk])
+// delta_i = dO_i . O_i of query qi, head h (64 channels), as the four lanes {l, l^16, l^32, l^48} of the fast-path kernels
+// compute it: lane group g4 sums channels ks*32 + 8 g4 .. +7, the groups are combined as (g0 + g1) + (g2 + g3).
+// ONE function for attn_bwd_dq64_kernel and attn_delta64_kernel: both must produce the same bits (a captured step may take
+// delta from the latter, the eager step from the former; tests/test_graph_gpu.py compares them bit for bit).
+__device__ __forceinline__ float delta64(const AttnArgs& a, int b, int h, int qi, int g4) {
+  float delta_i = 0.f;
+  if (qi < a.Tq) {
+    const float* po = a.o_in + ((long)b * a.Tq + qi) * a.C + h * 64;
+    const float* pg = a.dout + ((long)b * a.Tq + qi) * a.C + h * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int d = ks * 32 + g4 * 8 + hh * 4;
+        const float4 x = *reinterpret_cast<const float4*>(po + d), y = *reinterpret_cast<const float4*>(pg + d);
+        delta_i += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+  }
+  return quad16_sum(delta_i);
+}
+
+// delta alone (16 queries per wave, the lane layout of the kernels above): lets attn_bwd_dkdv64 start without waiting for
+// attn_bwd_dq64 when the two run on different streams (launch_bwd: fork)
+__global__ __launch_bounds__(256) void attn_delta64_kernel(AttnArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qi = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  const float d = delta64(a, b, h, qi, lane >> 4);
+  if ((lane >> 4) == 0 && qi < a.Tq) a.delta[(long)(b * a.H + h) * a.Tq + qi] = d;
+}
+
 template <bool XL>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs a) {
   if (a.drop_thresh) a.drop_seed = vilco_step_seed(a.drop_seed, a.seed_word);
@@ -1049,20 +1080,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
     // P * 2^-22 = exp2(acc * c2 - lse2): natural-log lse to the log2 domain, the fp16 range shift of dS folded in
     lse2[g] = qi < a.Tq ? a.lse[row_bh + qi] * 1.44269504088896340736f + 22.f : 0.f;
     // delta_i = dO_i . O_i in exact fp32 (lane group g4 covers channels ks*32 + 8 g4 .. +7); also left for attn_bwd_dkdv
-    float delta_i = 0.f;
-    if (qi < a.Tq) {
-      const float* po = a.o_in + ((long)b * a.Tq + qi) * a.C + h * HDP;
-      const float* pg = a.dout + ((long)b * a.Tq + qi) * a.C + h * HDP;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int d = ks * 32 + g4 * 8 + hh * 4;
-          const float4 x = *reinterpret_cast<const float4*>(po + d), y = *reinterpret_cast<const float4*>(pg + d);
-          delta_i += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-        }
-    }
-    delta_i = quad16_sum(delta_i);
+    const float delta_i = delta64(a, b, h, qi, g4);
     if (g4 == 0 && qi < a.Tq) a.delta[row_bh + qi] = delta_i;
     dlt[g] = (delta_i * sc.sdo) * sc.sv;                   // plane units; never form sdO * sV (see attn_bwd_dq_kernel)
     if constexpr (XL) dlt[g] /= a.drop_inv_keep;           // dS = inv_keep P (M dP - (1-p) delta)
@@ -1798,6 +1816,28 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
   return vilco_launch_status();
 }
 
+struct ForkCtx { hipStream_t s2; hipEvent_t e0, e1; };
+
+// the side stream + events of the dQ || dK-dV fork, or null: VILCO_ATTN_FORK=0, or `s` is not capturing.  The stream and the
+// events are created by the first call that finds `s` NOT capturing (resource creation inside a capture is not safe in every
+// capture mode); a process's first backward is always eager (graph.py captures after eager_steps >= 1 iterations).
+inline ForkCtx* attn_fork(hipStream_t s) {
+  static const bool enabled = [] { const char* e = getenv("VILCO_ATTN_FORK"); return !(e && e[0] == '0'); }();
+  if (!enabled) return nullptr;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) return nullptr;
+  static ForkCtx ctx;
+  static int state = 0;                 // 0: not created, 1: ready, -1: creation failed
+  if (st != hipStreamCaptureStatusActive) {
+    if (state == 0)
+      state = (hipStreamCreateWithFlags(&ctx.s2, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&ctx.e0, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&ctx.e1, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
+    return nullptr;
+  }
+  return state == 1 ? &ctx : nullptr;
+}
+
 template <int HDP, int NP, bool F16 = false>
 int launch_bwd(const AttnArgs& a, hipStream_t s) {
   static const bool once = [] {
@@ -1812,13 +1852,30 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
   (void)once;
   dim3 gq((a.Tq + 63) / 64, a.H, a.B), gk((a.Tk + 63) / 64, a.H, a.B);
   const size_t lq = dq_lds<HDP, NP>(), lk = dkdv_lds<HDP, NP>();
+  (void)attn_fork(s);                   // (creates the fork resources on the first eager call)
   bool fast = false;
   if constexpr (HDP == 64 && NP == 2 && F16)
     fast = fast64(a, 3);
   if (fast) {
     if constexpr (HDP == 64 && NP == 2 && F16) {
       constexpr size_t l64 = 2 * 2 * PL64 * sizeof(__bf16);
-      hipLaunchKernelGGL(attn_bwd_dq64_kernel<false>, dim3((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B), dim3(ATT_THREADS), l64, s, a);
+      const dim3 gq64((a.Tq + F64_Q - 1) / F64_Q, a.H, a.B);
+      // dQ and dK/dV are independent once delta exists.  At the long levels neither grid fills the chip in whole rounds
+      // (T = 2304, B H = 32: 576 and 1152 workgroups on 512 resident slots -> 2 and 3 rounds for 1.125 and 2.25 rounds of
+      // work); on two streams the runtime packs them together.  Only inside a stream capture (a replayed graph has no host
+      // in the loop; an eager second queue made step times erratic) and only where there is a tail to fill.
+      ForkCtx* f = (long)gq64.x * gq64.y * gq64.z > 512 ? attn_fork(s) : nullptr;
+      if (f) {
+        hipLaunchKernelGGL(attn_delta64_kernel, dim3((a.Tq + 63) / 64, a.H, a.B), dim3(256), 0, s, a);
+        hipEventRecord(f->e0, s);
+        hipStreamWaitEvent(f->s2, f->e0, 0);
+        hipLaunchKernelGGL(attn_bwd_dq64_kernel<false>, gq64, dim3(ATT_THREADS), l64, s, a);      // (writes the same delta again)
+        hipLaunchKernelGGL(attn_bwd_dkdv64_kernel<false>, gk, dim3(ATT_THREADS), l64, f->s2, a);
+        hipEventRecord(f->e1, f->s2);
+        hipStreamWaitEvent(s, f->e1, 0);
+        return vilco_launch_status();
+      }
+      hipLaunchKernelGGL(attn_bwd_dq64_kernel<false>, gq64, dim3(ATT_THREADS), l64, s, a);
       hipLaunchKernelGGL(attn_bwd_dkdv64_kernel<false>, gk, dim3(ATT_THREADS), l64, s, a);
       return vilco_launch_status();
     }

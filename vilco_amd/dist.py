@@ -119,7 +119,26 @@ class GradReducer:
                 self._next += 1
         return hook
 
+    def _sync_producers(self):
+        """inside a stream capture the backward runs on several streams (ops.fork_enabled: text branch, regression head) and a
+        bucket's last hook fires on whichever of them finished it: the stream that is about to read the whole bucket waits
+        for the others (edges of the captured graph; eager backward runs on one stream)"""
+        if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            return
+        from . import ops
+        cur = torch.cuda.current_stream()
+        others = [st for (name, dev), st in ops._side_streams.items() if dev == cur.device_index]
+        if getattr(self, "_capture_stream", None) is not None:
+            others.append(self._capture_stream)
+        for st in others:
+            if st != cur:
+                with torch.cuda.stream(st):
+                    live = torch.cuda.is_current_stream_capturing()
+                if live:
+                    cur.wait_stream(st)
+
     def _launch(self, b):
+        self._sync_producers()
         src, dst = [], []
         for p, v in zip(b["params"], b["views"]):
             if p.grad is None:

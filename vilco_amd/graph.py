@@ -31,18 +31,25 @@ from . import _lib, ops
 
 class GraphedStep:
     def __init__(self, model, optimizer=None, clip_grad_l2norm=-1.0, eager_steps=2, between=None, enabled=True,
-                 gt_pad=8, max_graphs=16, reducer=None):
+                 gt_pad=8, max_graphs=16, reducer=None, comm_in_graph=None):
         """optimizer: a FusedOptimizer (None: forward + backward only, gradients left in p.grad);
         eager_steps: iterations of a new signature run eagerly before its capture (>= 1 with an optimizer: the capture
         must follow an eager update, whose max|w| partials scale the captured weight packs);
         between: callable run eagerly between backward and the update of every iteration;
         gt_pad: ground-truth rows are padded to this many segments per clip so that their count does not key the graph;
         reducer: a dist.GradReducer -- eager iterations exchange gradients from its autograd hooks (overlapped with
-        backward), replayed ones right after graph 1 (`reduce_now`, averaged in place)."""
+        backward), replayed ones right after graph 1 (`reduce_now`, averaged in place);
+        comm_in_graph (default: env VILCO_DP_GRAPH_COMM, off): capture the bucketed RCCL all-reduces INSIDE graph 1 -- the
+        reducer's autograd hooks stay live during the capture, every collective lands on RCCL's stream behind an event of
+        the capture stream, and a replay overlaps the exchange with the rest of backward the way the eager step does.  Needs
+        the "nccl" backend; falls back to the exchange after the replay when the capture refuses.  Exercised on one rank
+        (tests/test_dist_gpu.py); not yet on a multi-GPU node, hence opt-in."""
         self.model, self.optimizer, self.clip = model, optimizer, float(clip_grad_l2norm)
         self.eager_steps = max(int(eager_steps), 1 if optimizer is not None else 0)
         self.between, self.enabled, self.gt_pad, self.max_graphs = between, bool(enabled), gt_pad, int(max_graphs)
         self.reducer = reducer
+        import os
+        self.comm_in_graph = (os.environ.get("VILCO_DP_GRAPH_COMM", "0") == "1") if comm_in_graph is None else bool(comm_in_graph)
         self._graphs = {}
         self._pool = None
         self._lr_dev = None
@@ -136,21 +143,36 @@ class GraphedStep:
         gc.collect()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        red = self.reducer if (self.reducer is not None and self.reducer.enabled) else None
+        comm = bool(red is not None and self.comm_in_graph and red._avg and not ent.get('comm_refused'))
         if self.reducer is not None:
-            # no collectives inside the capture (replays exchange after graph 1), but the captured weight-gradient kernels
-            # write into the reducer's bucket slots: a replayed backward leaves the large gradients in place
-            self.reducer.begin(hooks=False)
+            # default: no collectives inside the capture (replays exchange after graph 1), but the captured weight-gradient
+            # kernels write into the reducer's bucket slots: a replayed backward leaves the large gradients in place.
+            # comm: the hooks stay live and the all-reduces are captured with the backward they overlap.
+            self.reducer.begin(hooks=comm)
         try:
             with torch.cuda.graph(g, pool=self._pool):
+                if red is not None:
+                    red._capture_stream = torch.cuda.current_stream()
                 _lib.check(lib.vilco_seed_word_bump(ops._stream()))
                 losses = model.forward_prepared(static, None, task_id=task_id)
                 losses['final_loss'].backward()
+                if comm:
+                    red.finish()                 # waits become edges of the graph; p.grad = views of the averaged buckets
                 ops.join_side_streams()          # forked chains (ops.fork_enabled) end here
                 keys = sorted(losses)
                 out = torch.stack([losses[k].detach().reshape(()).float() for k in keys])
+        except Exception:
+            if not comm:
+                raise
+            ent['comm_refused'] = True           # this runtime does not capture the collectives: exchange after the replay
+            torch.cuda.synchronize()
+            return self._capture(ent, inp, task_id)
         finally:
             if self.reducer is not None:
+                self.reducer._capture_stream = None
                 self.reducer.end_capture()
+        ent['comm'] = comm
         del losses
         blocks.reset_drop_pool()
         if self._pool is None:
@@ -199,7 +221,7 @@ class GraphedStep:
         for p, g in zip(self.params, ent['grads']):
             if p.grad is not g:
                 p.grad = g
-        if self.reducer is not None:
+        if self.reducer is not None and not ent.get('comm'):
             if ent['fill']:
                 torch._foreach_zero_(ent['fill'])
             self.reducer.reduce_now()
