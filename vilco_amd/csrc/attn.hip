@@ -1818,11 +1818,12 @@ int launch_fwd(const AttnArgs& a, hipStream_t s) {
 
 struct ForkCtx { hipStream_t s2; hipEvent_t e0, e1; };
 
-// the side stream + events of the dQ || dK-dV fork, or null: VILCO_ATTN_FORK=0, or `s` is not capturing.  The stream and the
+// the side stream + events of the dQ || dK-dV fork, or null: VILCO_ATTN_FORK != 1 (the default: same-box A/B of the replayed P
+// step, round 4: 25.16 / 25.23 ms without, 25.27 / 25.12 ms with -- no gain), or `s` is not capturing.  The stream and the
 // events are created by the first call that finds `s` NOT capturing (resource creation inside a capture is not safe in every
 // capture mode); a process's first backward is always eager (graph.py captures after eager_steps >= 1 iterations).
 inline ForkCtx* attn_fork(hipStream_t s) {
-  static const bool enabled = [] { const char* e = getenv("VILCO_ATTN_FORK"); return !(e && e[0] == '0'); }();
+  static const bool enabled = [] { const char* e = getenv("VILCO_ATTN_FORK"); return e && e[0] == '1'; }();      // off by default
   if (!enabled) return nullptr;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &st) != hipSuccess) return nullptr;
