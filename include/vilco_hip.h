@@ -114,6 +114,11 @@ typedef struct vilco_gemm_desc {
   /* tensor already on the device, left by the kernel that produced it; the call then skips its amax pass over it.      */
   const float* a_amax; int32_t a_namax;
   const float* b_amax; int32_t b_namax;
+  /* 1: a_planes / b_planes hold the k=3 convs' zero-padded per-sequence image (vilco_pack_item.seq_len = tapT) instead of */
+  /* the natural [rows32][cols32] layout.  Required for -- and only legal with -- the tapped operand of a conv product:     */
+  /* tap_operand = TAP_A: a_planes (tapC % 8 == 0);  TAP_B (the weight gradient, M % 8 == 0, tapC % 8 == 0): BOTH operands, */
+  /* a_planes = the image of dZ [K rows of width M], b_planes = the image of the conv input [K rows of width tapC].          */
+  int32_t a_planes_seq, b_planes_seq;
 } vilco_gemm_desc;
 
 size_t vilco_gemm_workspace(const vilco_gemm_desc* d);
@@ -160,6 +165,12 @@ typedef struct vilco_pack_item {
   /* src (vilco_layernorm_fwd_amax, vilco_act_bwd_amax, vilco_qkv_pre_fwd) -- so the pack needs no amax launch          */
   const float* amax;
   int32_t namax;
+  /* seq_len = T > 0: src is rows / T token sequences of T rows (cols % 8 == 0) and the planes are the image the k=3 convs   */
+  /* read -- every sequence with one zero row before and after it, [nseq * (T + 2) + zero rows][cols], no column padding:    */
+  /* ONE pack of a conv's input x serves the forward product (vilco_gemm, tap_operand = TAP_A, a_planes) and the weight     */
+  /* gradient (TAP_B, b_planes); one pack of dZ serves dX (TAP_A) and the weight gradient (TAP_B, a_planes).                 */
+  /* Reference: the im2col-free form of F.conv1d under MaskedConv1D, blocks.py:106-130.                                      */
+  int32_t seq_len;
 } vilco_pack_item;
 size_t vilco_pack_item_bytes(const vilco_pack_item* item, int32_t precision);   /* honours nbatch / relshift */
 int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t precision, void* stream);

@@ -167,8 +167,10 @@ def test_packed_operand_errors(dev):
     from vilco_amd import ops, _lib
     x, w, y = torch.randn(64, 32, device=dev), torch.randn(16, 32, device=dev), torch.empty(64, 16, device=dev)
     px = ops.pack(x, 64, 32)
-    with pytest.raises(RuntimeError):      # pre-packed operands are not defined for the k=3 tap products
+    with pytest.raises(RuntimeError):      # a tapped operand's planes must be the per-sequence image (ops.pack_tap), not natural ones
         ops.gemm(x, w, y, 64, 16, 96, 1, 1, 32, 96, 16, tap=ops.TAP_A, tapC=32, tapT=64, a_planes=px)
+    with pytest.raises(RuntimeError):      # ... and a plain product does not take that image
+        ops.gemm(x, w, y, 64, 16, 32, 1, 1, 32, 32, 16, a_planes=ops.pack_tap(x.view(1, 64, 32)), planes_seq=(True, False))
     lib = _lib.load()
     small = torch.empty(16, dtype=torch.uint8, device=dev)
     assert lib.vilco_pack(x.data_ptr(), 64, 32, 32, 3, small.data_ptr(), 16, None) != 0   # buffer too small

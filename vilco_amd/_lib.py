@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ("drop_p", f32), ("drop_seed", C.c_uint32),
         ("amax_out", c_fp),
         ("a_amax", c_fp), ("a_namax", i32), ("b_amax", c_fp), ("b_namax", i32),
+        ("a_planes_seq", i32), ("b_planes_seq", i32),
     ]
 
 
@@ -58,7 +59,7 @@ class AttnAmaxIn(C.Structure):
 class PackItem(C.Structure):
     """Mirror of `vilco_pack_item`."""
     _fields_ = [("src", c_fp), ("rows", i64), ("cols", i64), ("ld", i64), ("planes", c_fp), ("planes_bytes", sz),
-                ("nbatch", i32), ("batch_stride", i64), ("relshift", i32), ("amax", c_fp), ("namax", i32)]
+                ("nbatch", i32), ("batch_stride", i64), ("relshift", i32), ("amax", c_fp), ("namax", i32), ("seq_len", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/vilco_hip.h declares

@@ -791,6 +791,7 @@ struct Plan {
   int a_nbo, a_nbi, b_nbo, b_nbi;
   long a_bytes, b_bytes, part_bytes;
   long split_stride;
+  bool tapkm;                     // k=3 conv weight gradient as a k-major x k-major product over zero-padded token rows (make_plan)
   bool k2;                        // precision 4: a barrier interval of the kernel covers two K-steps (64 elements of K)
   bool fixup;                     // split-K finished inside the launch (tile counters) instead of by splitk_reduce_kernel
 };
@@ -826,12 +827,18 @@ unsigned* tile_counters(hipStream_t s) {
   return base + (long)(n++) * FIX_TILES;
 }
 
+inline bool tapkm_enabled() {
+  static const bool v = [] { const char* e = getenv("VILCO_CONV_DW_KM"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 void make_plan(const vilco_gemm_desc* d, Plan& p) {
   p.NP = d->precision == 1 ? 1 : ((d->precision == 0 || d->precision == 3 || d->precision == 4) ? 2 : 3);
   p.Kp = (int)align_up(d->K > 0 ? d->K : 1, 32);
   p.a_tr = !d->a_kcontig;
   p.b_tr = !d->b_kcontig;
   p.a_tap = p.b_tap = 0;
+  p.tapkm = false;
   p.a_out_rows = d->M;
   p.b_out_rows = d->N;
   long a_batch = (long)d->M * p.Kp, b_batch = (long)d->N * p.Kp;
@@ -852,7 +859,28 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
       p.a_tap = 2;
     }
   } else if (d->tap_operand == VILCO_TAP_B) {
-    p.b_tap = 3;
+    // dW[co][j*Cin + c] = sum_tok dZ[tok][co] X[tok + j - 1][c] (zero across sequence ends).  Round 4: no transposing pack.
+    // Both operands are packed the way the forward conv packs its input -- token rows in their natural layout, one zero row
+    // before and after every sequence (tap mode 1) -- and the product contracts over those PADDED rows r: with dZ' starting
+    // at padded row 1, row r of dZ' meets rows r, r+1, r+2 of X' for the taps j = 0, 1, 2; X' has row stride Cin, so
+    // "row r, columns j*Cin + c" of the virtual [rows][3 Cin] operand is the plain address r*Cin + j*Cin + c: the kernel's
+    // ordinary k-major tile read (the overlapped-row trick of the forward conv, turned on its side).  The padding rows of
+    // dZ' are zero, so whatever X' holds opposite them (the next sequence's first token) contributes nothing.
+    if (use_km() && tapkm_enabled() && (d->tapC % 8) == 0 && (d->M % 8) == 0 && d->tapT > 0 && (d->K % d->tapT) == 0 &&
+        d->batch_outer == 1 && d->batch_inner == 1) {
+      const long nseq = d->K / d->tapT;
+      p.tapkm = true;
+      p.Kp = (int)align_up(nseq * (d->tapT + 2) - 1, 32);
+      p.a_tap = p.b_tap = 1;
+      p.a_tr = p.b_tr = false;
+      p.a_km = p.b_km = true;
+      p.a_out_rows = p.Kp + 1 + 32;          // + the skipped first row + one K-step of over-read
+      p.b_out_rows = p.Kp + 3 + 32;
+      a_batch = (long)p.a_out_rows * d->M;
+      b_batch = (long)p.b_out_rows * d->tapC;
+    } else {
+      p.b_tap = 3;
+    }
   }
   p.a_nbo = (d->sAo && d->batch_outer > 1) ? d->batch_outer : 1;
   p.a_nbi = (d->sAi && d->batch_inner > 1) ? d->batch_inner : 1;
@@ -1042,8 +1070,15 @@ extern "C" size_t vilco_pack_bytes(int64_t rows, int64_t cols, int32_t precision
 
 static inline long item_cols(const vilco_pack_item& it) { return it.relshift ? it.rows + it.cols : it.cols; }
 
+// rows of a zero-padded per-sequence plane image (vilco_pack_item.seq_len): nseq * (T + 2) padded rows + enough zero rows for
+// both readers -- the forward / dX conv's overlapped spans (make_plan: a_out_rows) and the weight-gradient product's
+// contraction over the padded rows (Kp + 3 + one K-step)
+static inline long tap_plane_rows(long nseq, long T) { return align_up(nseq * (T + 2), 32) + 64; }
+
 extern "C" size_t vilco_pack_item_bytes(const vilco_pack_item* it, int32_t precision) {
   if (!it || it->rows <= 0 || it->cols <= 0) return 0;
+  if (it->seq_len > 0)
+    return (size_t)(PACK_HDR + align_up(tap_plane_rows(it->rows / it->seq_len, it->seq_len) * it->cols, 8) * 2 * np_of_precision(precision));
   const long nb = it->nbatch > 1 ? it->nbatch : 1;
   return (size_t)(PACK_HDR + nb * align_up(it->rows, 32) * align_up(item_cols(*it), 32) * 2 * np_of_precision(precision));
 }
@@ -1072,6 +1107,12 @@ extern "C" int vilco_pack_many(const vilco_pack_item* items, int32_t n, int32_t 
     pa.so = 0; pa.si = nbatch > 1 ? it.batch_stride : 0;
     pa.tap = it.relshift ? 4 : 0; pa.tapC = it.relshift ? (int)it.cols : 1; pa.tapT = 1; pa.out_rows = (int)rows32;
     pa.vec = vilco_aligned(it.src, 16) && (it.ld % 4) == 0 && (it.batch_stride % 4) == 0;
+    if (it.seq_len > 0) {          // the k=3 convs' image: [nseq * (T + 2) + zero rows][cols], first and last row of a sequence zero
+      if (it.relshift || nbatch != 1 || (it.cols % 8) != 0 || (it.rows % it.seq_len) != 0) return VILCO_ERR_UNSUPPORTED;
+      const long tr = tap_plane_rows(it.rows / it.seq_len, it.seq_len);
+      pa.tap = 1; pa.tapC = (int)it.cols; pa.tapT = it.seq_len; pa.out_rows = (int)tr;
+      pa.plane_stride = align_up(tr * it.cols, 8); pa.batch_stride = pa.plane_stride;
+    }
     pa.amax = nullptr; pa.namax = 0; pa.inv_scale = hdr + AMAX_MAX_BLOCKS;
     if (precision == 3) {
       PackArgs src_view = pa;                     // amax runs over the source matrix itself ([rows][cols])
@@ -1115,7 +1156,10 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (!d || !d->C || (!d->A && !d->a_planes) || (!d->B && !d->b_planes)) return VILCO_ERR_BADARG;
   if (d->a_planes || d->b_planes) {
     // pre-packed operands: untapped problems, or the plain (weight) operand B of a k=3 conv whose taps are on A
-    const bool tap_ok = d->tap_operand == VILCO_TAP_NONE || (d->tap_operand == VILCO_TAP_A && !d->a_planes && d->b_kcontig);
+    // (k=3 convs: the tapped operand's planes must be the zero-padded per-sequence image, vilco_pack_item.seq_len; checked
+    //  against the plan below)
+    const bool tap_ok = d->tap_operand == VILCO_TAP_NONE || (d->tap_operand == VILCO_TAP_A && d->b_kcontig) ||
+                        d->tap_operand == VILCO_TAP_B;
     if (!tap_ok || !use_km()) return VILCO_ERR_UNSUPPORTED;
     if (!vilco_aligned(d->a_planes, 256) || !vilco_aligned(d->b_planes, 256)) return VILCO_ERR_BADARG;
   }
@@ -1141,6 +1185,15 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   }
   Plan p;
   make_plan(d, p);
+  // operand planes must come in the layout the product reads: natural for plain operands, the per-sequence image for tapped ones
+  {
+    const bool a_seq = d->a_planes && d->a_planes_seq, b_seq = d->b_planes && d->b_planes_seq;
+    const bool a_want = d->a_planes && ((d->tap_operand == VILCO_TAP_A && p.a_tap == 1) || p.tapkm);
+    const bool b_want = d->b_planes && p.tapkm;
+    if (a_seq != a_want || b_seq != b_want) return VILCO_ERR_UNSUPPORTED;
+    if (d->tap_operand == VILCO_TAP_A && d->a_planes && p.a_tap != 1) return VILCO_ERR_UNSUPPORTED;   // tapC % 8 != 0: expanded rows
+    if (d->tap_operand == VILCO_TAP_B && (d->a_planes || d->b_planes) && !(p.tapkm && d->a_planes && d->b_planes)) return VILCO_ERR_UNSUPPORTED;
+  }
   // the kernel's staging loads address one operand matrix (one batch element of one part) with 32-bit byte offsets
   // (buffer loads: lane offset + K-step offset, gemm_pp_kernel); the last K-step may over-read one tile
   {
@@ -1169,6 +1222,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   pa.tap = p.a_tap; pa.tapC = d->tapC > 0 ? d->tapC : 1; pa.tapT = d->tapT > 0 ? d->tapT : 1;
   pa.out_rows = p.a_out_rows;
   if (p.a_km) { pa.rows = d->K; pa.K = d->M; pa.Kp = (int)align_up(d->M, 32); }   // natural [K][M] view
+  if (p.tapkm) { pa.tapC = d->M; pa.K = d->M; }                                     // dZ rows: Cout wide, zero-padded per sequence
   pa.vec = vilco_aligned(d->A, 16) && (d->lda % 4) == 0 && (d->sAo % 4) == 0 && (d->sAi % 4) == 0;
   pa.amax = f16 ? scales : nullptr; pa.namax = 0; pa.inv_scale = scales + 2 * AMAX_MAX_BLOCKS;
   const bool packA = d->a_planes == nullptr, packB = d->b_planes == nullptr;
@@ -1180,6 +1234,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   pb.tap = p.b_tap; pb.tapC = d->tapC > 0 ? d->tapC : 1; pb.tapT = d->tapT > 0 ? d->tapT : 1;
   pb.out_rows = p.b_out_rows;
   if (p.b_km) { pb.rows = d->K; pb.K = d->N; pb.Kp = (int)align_up(d->N, 32); }   // natural [K][N] view
+  if (p.tapkm) { pb.K = d->tapC; }                                                  // X rows: Cin wide
   pb.vec = vilco_aligned(d->B, 16) && (d->ldb % 4) == 0 && (d->sBo % 4) == 0 && (d->sBi % 4) == 0;
   pb.amax = f16 ? scales + AMAX_MAX_BLOCKS : nullptr; pb.namax = 0; pb.inv_scale = scales + 2 * AMAX_MAX_BLOCKS + 2;
   bool doneA = !packA, doneB = !packB;
@@ -1210,6 +1265,9 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     planesA = reinterpret_cast<__bf16*>(const_cast<unsigned char*>(u) + PACK_HDR);
     inv_a = reinterpret_cast<const float*>(u) + AMAX_MAX_BLOCKS;
     p.a_batch = p.a_km ? (long)p.Kp * align_up(d->M, 32) : align_up(d->M, 32) * (long)p.Kp;
+    if (p.a_tap == 1)                                // the convs' zero-padded image (vilco_pack_item.seq_len)
+      p.a_batch = p.tapkm ? align_up(tap_plane_rows(d->K / d->tapT, d->tapT) * d->M, 8)
+                          : align_up(tap_plane_rows(d->M / d->tapT, d->tapT) * d->tapC, 8);
     p.a_plane = p.a_batch * p.a_nbo * p.a_nbi;       // batched planes: [part][batch][rows32][cols32]
   }
   if (!packB) {
@@ -1217,6 +1275,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     planesB = reinterpret_cast<__bf16*>(const_cast<unsigned char*>(u) + PACK_HDR);
     inv_b = reinterpret_cast<const float*>(u) + AMAX_MAX_BLOCKS;
     p.b_batch = p.b_km ? (long)p.Kp * align_up(d->N, 32) : align_up(d->N, 32) * (long)p.Kp;
+    if (p.tapkm) p.b_batch = align_up(tap_plane_rows(d->K / d->tapT, d->tapT) * d->tapC, 8);
     p.b_plane = p.b_batch * p.b_nbo * p.b_nbi;
   }
 
@@ -1228,11 +1287,13 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   else { g.a.seqT = 0x7fffffff; g.a.seq_stride = 0; g.a.row_stride = p.Kp; }
   g.a.cols = 0;
   if (p.a_km) { g.a.row_stride = align_up(d->M, 32); g.a.cols = (int)align_up(d->M, 32); }
+  if (p.tapkm) { g.a.p = planesA + d->M; g.a.row_stride = d->M; g.a.cols = d->M; }      // dZ' = padded rows 1 ...
   g.b.p = planesB; g.b.plane_stride = p.b_plane; g.b.batch_stride = p.b_batch; g.b.nbi = p.b_nbi;
   g.b.has_o = p.b_nbo > 1; g.b.has_i = p.b_nbi > 1; g.b.rows = d->N;
   g.b.seqT = 0x7fffffff; g.b.seq_stride = 0; g.b.row_stride = p.Kp;
   g.b.cols = 0;
   if (p.b_km) { g.b.row_stride = align_up(d->N, 32); g.b.cols = (int)align_up(d->N, 32); }
+  if (p.tapkm) { g.b.row_stride = d->tapC; g.b.cols = d->N; }                            // X' seen as [rows][3 Cin], row stride Cin
   g.ldc = d->ldc; g.M = d->M; g.N = d->N; g.Kp = p.Kp;
   g.batch_inner = d->batch_inner; g.sCo = d->sCo; g.sCi = d->sCi;
   g.tiles_n = (d->N + BN - 1) / BN;

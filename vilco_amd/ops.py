@@ -297,7 +297,7 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
          sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
          bias=None, preact=None, act=ACT_NONE, row_len=None, rowT=0, colscale=None, residual=None,
          res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0, drop=(0.0, 0), want_amax=False,
-         a_amax=None, b_amax=None):
+         a_amax=None, b_amax=None, planes_seq=(False, False)):
     """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements.  a_planes / b_planes: operands
     already packed by `pack` (the fp32 tensor may then be None).  want_amax: the call writes ALL of Cc, which goes on
     into another product -- the kernel leaves max|C| partials and Cc is tagged with them (`_tag_amax`)."""
@@ -306,6 +306,7 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     d.A = None if A is None else A.data_ptr() + 4 * offA
     d.B = None if B is None else B.data_ptr() + 4 * offB
     d.a_planes, d.b_planes = _p(a_planes), _p(b_planes)
+    d.a_planes_seq, d.b_planes_seq = int(bool(planes_seq[0])), int(bool(planes_seq[1]))     # pack_tap images (k=3 convs)
     d.band, d.bandT = int(band), int(bandT)
     d.drop_p, d.drop_seed = float(drop[0]), int(drop[1])
     d.C = Cc.data_ptr() + 4 * offC
@@ -372,6 +373,25 @@ def _amax_of(x):
 _pack_cache = os.environ.get("VILCO_PACK_CACHE", "1") != "0"
 
 
+def _cache_mark():
+    """(stream, event) to remember with planes packed just now.  Inside a stream capture independent chains run on side streams
+    (fork_enabled): a chain that finds another chain's planes in the cache must wait for the pack that wrote them -- an
+    event recorded right behind it, so the wait covers the pack and nothing else of the other chain.  Eager steps run on one
+    stream and skip the event."""
+    if torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        ev.record()
+        return (torch.cuda.current_stream(), ev)
+    return None
+
+
+def _cache_sync(mark):
+    if mark is not None and torch.cuda.is_current_stream_capturing():
+        cur = torch.cuda.current_stream()
+        if mark[0] != cur:
+            cur.wait_event(mark[1])
+
+
 def pack(x, rows, cols, precision=None):
     """One pass over the fp32 row-major matrix x[rows][cols] -> 16-bit operand planes (a uint8 tensor) that every
     product the tensor appears in consumes, in either orientation (vilco_pack, include/vilco_hip.h).  The planes are
@@ -381,6 +401,7 @@ def pack(x, rows, cols, precision=None):
     key = (int(rows), int(cols), prec, x._version)
     hit = getattr(x, "_vilco_planes", None) if _pack_cache else None
     if hit is not None and hit[1] == key:
+        _cache_sync(hit[2])
         return hit[0]
     nbytes = lib.vilco_pack_bytes(int(rows), int(cols), prec)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -394,7 +415,34 @@ def pack(x, rows, cols, precision=None):
         it.amax, it.namax = parts.data_ptr(), n
         _lib.check(lib.vilco_pack_many(C.byref(it), 1, prec, _stream()))
     if _pack_cache:
-        x._vilco_planes = (buf, key)
+        x._vilco_planes = (buf, key, _cache_mark())
+    return buf
+
+
+def pack_tap(x, precision=None):
+    """x [B, T, C] (C % 8 == 0) -> the operand planes the k=3 convs read: every sequence with a zero row before and after it
+    (vilco_pack_item.seq_len).  One pack of a conv's input serves its forward product and its weight gradient; one pack of
+    the output gradient serves dX and the weight gradient.  Remembered on the tensor like `pack`."""
+    lib = _lib.load()
+    prec = _precision if precision is None else int(precision)
+    B, T, Cn = x.shape
+    key = ("tap", int(B), int(T), int(Cn), prec, x._version)
+    hit = getattr(x, "_vilco_tap_planes", None) if _pack_cache else None
+    if hit is not None and hit[1] == key:
+        _cache_sync(hit[2])
+        return hit[0]
+    it = _lib.PackItem()
+    it.src, it.rows, it.cols, it.ld = x.data_ptr(), int(B * T), int(Cn), int(Cn)
+    it.nbatch, it.batch_stride, it.relshift, it.seq_len = 1, 0, 0, int(T)
+    parts, n = _amax_of(x) if prec == 3 else (None, 0)
+    if parts is not None:
+        it.amax, it.namax = parts.data_ptr(), n
+    nbytes = lib.vilco_pack_item_bytes(C.byref(it), prec)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    it.planes, it.planes_bytes = buf.data_ptr(), nbytes
+    _lib.check(lib.vilco_pack_many(C.byref(it), 1, prec, _stream()))
+    if _pack_cache:
+        x._vilco_tap_planes = (buf, key, _cache_mark())
     return buf
 
 
@@ -423,6 +471,9 @@ def pack_many(items, precision=None, nbatch=1, relshift=False):
 
 # packed operands are shared between forward, dX and dW (env VILCO_PACK_REUSE=0: every GEMM packs its own operands)
 _reuse_packs = os.environ.get("VILCO_PACK_REUSE", "1") != "0"
+# k=3 convs: x and dZ packed once each in the zero-padded per-sequence image, for all three products (VILCO_CONV_TAP_PLANES=0,
+# or VILCO_CONV_DW_KM=0 which also takes the weight gradient back to its transposing packs)
+conv_tap_planes = os.environ.get("VILCO_CONV_TAP_PLANES", "1") != "0" and os.environ.get("VILCO_CONV_DW_KM", "1") != "0"
 
 # ---- weight planes are packed ONCE per parameter version, not once per step.  A weight's planes (and the re-laid
 # [Cout][tap][Cin] images of k=3 conv weights) are cached on the parameter object, keyed by torch's in-place version
@@ -681,15 +732,18 @@ class _Conv3(torch.autograd.Function):
         # [Cout][tap][Cin] image of the weight and its planes: built once per weight version
         wp, pwp = _cached(w, "conv3_fwd", lambda: _conv3_weight(w, (Cout, 3, Cin), 0, (Cin * 3, 1, 3), Cout, 3 * Cin))
         y = torch.empty(B, T, Cout, dtype=torch.float32, device=x.device)
+        # x in the convs' zero-padded image: packed once, read by this product and by the weight gradient in backward
+        px = pack_tap(x) if (_reuse_packs and conv_tap_planes and pwp is not None and Cin % 8 == 0) else None
         gemm(x, wp, y, B * T, Cout, 3 * Cin, 1, 1, Cin, 3 * Cin, Cout, tap=TAP_A, tapC=Cin, tapT=T,
-             bias=b, row_len=lens, rowT=T, b_planes=pwp, a_amax=_amax_of(x))
+             bias=b, row_len=lens, rowT=T, a_planes=px, b_planes=pwp, a_amax=_amax_of(x), planes_seq=(px is not None, False))
         ctx.has_bias = b is not None
-        ctx.save_for_backward(x, w, lens, b)
+        ctx.prec = _precision
+        ctx.save_for_backward(x, w, lens, b, px)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, lens, b = ctx.saved_tensors
+        x, w, lens, b, px = ctx.saved_tensors
         B, T, Cin = x.shape
         Cout = w.shape[0]
         dy = dy.contiguous()
@@ -699,17 +753,24 @@ class _Conv3(torch.autograd.Function):
         else:
             dz, db = dy, (colsum(dy.view(B * T, Cout), param=b) if need_db else None)
         dx = dw = None
+        # dZ in the convs' image: one pack for dX and the weight gradient (needs the format the forward planes were made in)
+        pz = pack_tap(dz, ctx.prec) if (px is not None and Cout % 8 == 0 and ctx.prec == _precision) else None
         if ctx.needs_input_grad[0]:
             # wt[ci][j'][co] = w[co][ci][2-j']: dX is the k=3 conv of dZ with flipped taps
             wt, pwt = _cached(w, "conv3_dx", lambda: _conv3_weight(w, (Cin, 3, Cout), 2, (3, -1, Cin * 3), Cin, 3 * Cout))
             dx = torch.empty_like(x)
             gemm(dz, wt, dx, B * T, Cin, 3 * Cout, 1, 1, Cout, 3 * Cout, Cin, tap=TAP_A, tapC=Cout,
-                 tapT=T, b_planes=pwt, a_amax=_amax_of(dz))
+                 tapT=T, a_planes=pz if pwt is not None else None, b_planes=pwt, a_amax=_amax_of(dz),
+                 planes_seq=(pz is not None and pwt is not None, False))
         if ctx.needs_input_grad[1]:
             with _DwFork(w):
                 dwp = torch.empty(Cout, 3 * Cin, dtype=torch.float32, device=x.device)
-                gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
-                     tapT=T, precision=_dw_prec(_precision, B * T), a_amax=_amax_of(dz), b_amax=_amax_of(x))
+                if pz is not None:          # k-major x k-major over the padded token rows: no operand pack at all (gemm.hip: make_plan)
+                    gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
+                         tapT=T, precision=_dw_prec(ctx.prec, B * T), a_planes=pz, b_planes=px, planes_seq=(True, True))
+                else:
+                    gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
+                         tapT=T, precision=_dw_prec(_precision, B * T), a_amax=_amax_of(dz), b_amax=_amax_of(x))
                 dw = permute3(dwp, (Cout, Cin, 3), 0, (3 * Cin, 1, Cin), out=_grad_out(w))
         return dx, dw, db, None
 
