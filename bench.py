@@ -257,15 +257,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # test hooks (tests / one-GPU boxes): VILCO_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and VILCO_BENCH_BACKEND=gloo carries the
+    # device tensors over gloo (RCCL refuses two ranks on one device) -- the N > 1 code path of this file on a single GPU
+    one_dev = os.environ.get("VILCO_BENCH_ONE_DEVICE", "0") == "1"
     if dry:
         dev = torch.device("cpu")
     else:
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(0 if one_dev else local_rank)
+        dev = torch.device("cuda", 0 if one_dev else local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo" if dry else "nccl")            # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend="gloo" if dry else os.environ.get("VILCO_BENCH_BACKEND", "nccl"))   # "nccl" IS RCCL on ROCm
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     if dry:

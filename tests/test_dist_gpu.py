@@ -83,7 +83,7 @@ def test_reducer_paths_reproduce_the_single_process_run(dev, one_rank_group):
     l1, s1, in_slots = _train(dev, "hooks")
     assert in_slots >= 40, in_slots                 # the matrices' gradients were produced in place
     l2, s2, _ = _train(dev, "graph")
-    l3, s3, _ = _train(dev, "graph_comm")          # the all-reduces captured inside graph 1 (or the fallback, if the runtime refuses)
+    l3, s3, _ = _train(dev, "graph" if os.environ.get("VILCO_TEST_NO_COMM") else "graph_comm")   # the all-reduces captured inside graph 1 (or the fallback, if the runtime refuses)
     for other_l, other_s in ((l1, s1), (l2, s2), (l3, s3)):
         assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(other_l, l0)), (other_l, l0)
         for k in s0:

@@ -1,6 +1,8 @@
 """Full-size (BASELINE configs[1], "P": T=2304, Cin=2304, D=1024, H=16, XLNet on) checks through
 size-independent properties -- the oracle is too slow at this size for direct comparison in a test."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -152,7 +154,7 @@ def test_single_part_weight_gradients_at_full_size(dev):
     assert sum(1 for e, _ in errs if e > 0) > 30          # the fast mode is actually in use (48 weight tensors at P)
 
 
-def test_p_config_train_step_vs_fp32_oracle_with_replayed_masks(dev):
+def p_train_step_vs_fp32_oracle(dev):
     """ONE full-size step of the benchmark workload itself -- config P, two clips, train mode with dropout 0.1 /
     stochastic depth 0.1 / XLNet dropout 0.1, the single-part weight-gradient products active -- against the fp32 oracle
     (the CPU restatement of the reference, ~15-30 s on the GPU box's host cores) replaying exactly the masks and
@@ -212,7 +214,23 @@ def test_p_config_train_step_vs_fp32_oracle_with_replayed_masks(dev):
             worst.append(((d.max() / top).item(), k))
     worst.sort(reverse=True)
     outliers.sort(reverse=True)
-    assert len(worst) > 300 and max(l2) < 1e-3, (max(l2), worst[:5])
+    assert len(worst) > 300 and max(l2) < 1e-3, (max(l2), [(round(e, 5), k) for e, k in worst[:12]])
     assert outliers[0][0] < 1e-4, outliers[:5]
     assert worst[0][0] < 3e-3, worst[:8]
     assert sum(1 for e, _ in worst if e < 1e-3) >= len(worst) - 2, worst[:10]
+
+
+
+def test_p_config_train_step_vs_fp32_oracle_with_replayed_masks(dev):
+    """`p_train_step_vs_fp32_oracle` in a process of its own.  The CPU oracle's gradients for a family of near-cancelling
+    tensors (the branches' MLP output projections, the heads' first convs: |gradient| ~ 1e-8) depend on what the host process
+    did before -- after the data-parallel and episode tests of this suite the same oracle call returns values up to 0.15 of
+    the tensor maximum away from what it returns in a fresh interpreter (round 4, tools/lab/state_dbg.py), while the HIP
+    step's gradients are bit-identical in both situations.  The reference a user would compare against is the fresh one."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_fullsize_gpu as t; "
+            "t.p_train_step_vs_fp32_oracle(torch.device('cuda:0')); print('P_PARITY_OK')" % (here, os.path.dirname(here)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and "P_PARITY_OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
