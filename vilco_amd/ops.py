@@ -1335,6 +1335,7 @@ def rel_attention(qw, qr, k, v, kr, kv_len, n_head, scale, drop_p=0.0):
 class _ChannelAttn(torch.autograd.Function):
     """ChannelAttention core (blocks.py:426-434) on a fused qkv [B,T,3C]:
     A_h = softmax_rows(scale * k_h^T v_h)  [hd,hd];  out_h[t,:] = q_h[t,:] A_h^T."""
+    last_amax = (None, 0)
 
     @staticmethod
     def forward(ctx, qkv, H, scale, bwd_precision=None):
@@ -1350,7 +1351,8 @@ class _ChannelAttn(torch.autograd.Function):
         _softmax_(A, None, B, H, hd, hd, MASK_NONE)
         out = torch.empty(B, T, Cn, dtype=torch.float32, device=qkv.device)
         gemm(qkv, A, out, T, hd, hd, 1, 1, C3, hd, Cn, batch=(B, H), sA=sQ, sB=(H * hd * hd, hd * hd),
-             sC=(T * Cn, hd))                                                    # q A^T
+             sC=(T * Cn, hd), want_amax=True)                                    # q A^T (its output goes straight into proj)
+        _ChannelAttn.last_amax = _amax_of(out)          # picked up by `channel_attention` (attributes set here do not survive apply)
         ctx.H, ctx.scale = H, scale
         ctx.save_for_backward(qkv, A)
         return out
@@ -1385,7 +1387,11 @@ class _ChannelAttn(torch.autograd.Function):
 
 
 def channel_attention(qkv, n_head, scale, bwd_precision=None):
-    return _ChannelAttn.apply(qkv, int(n_head), float(scale), bwd_precision)
+    _ChannelAttn.last_amax = (None, 0)
+    out = _ChannelAttn.apply(qkv, int(n_head), float(scale), bwd_precision)
+    parts, n = _ChannelAttn.last_amax
+    _ChannelAttn.last_amax = (None, 0)
+    return _tag_amax(out, parts, n) if parts is not None else out
 
 
 # ---------------------------------------------------------------------------------------- labels + losses
