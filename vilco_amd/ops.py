@@ -374,22 +374,29 @@ _pack_cache = os.environ.get("VILCO_PACK_CACHE", "1") != "0"
 
 
 def _cache_mark():
-    """(stream, event) to remember with planes packed just now.  Inside a stream capture independent chains run on side streams
-    (fork_enabled): a chain that finds another chain's planes in the cache must wait for the pack that wrote them -- an
-    event recorded right behind it, so the wait covers the pack and nothing else of the other chain.  Eager steps run on one
-    stream and skip the event."""
-    if torch.cuda.is_current_stream_capturing():
+    """the stream cached planes were packed on, while capturing.  Inside a stream capture independent chains run on side
+    streams (fork_enabled), and a chain that finds another chain's planes in this Python-level cache has no edge to the pack
+    that writes them: `_cache_ok` treats such a hit as a miss and the chain packs its own (an event behind every pack would
+    order it, at the price of ~290 extra event records per captured step).  Eager steps run on one stream."""
+    if not torch.cuda.is_current_stream_capturing():
+        return None
+    if _cache_events:                      # (A/B toggle: the event form)
         ev = torch.cuda.Event()
         ev.record()
         return (torch.cuda.current_stream(), ev)
-    return None
+    return (torch.cuda.current_stream(), None)
 
 
-def _cache_sync(mark):
-    if mark is not None and torch.cuda.is_current_stream_capturing():
-        cur = torch.cuda.current_stream()
-        if mark[0] != cur:
-            cur.wait_event(mark[1])
+def _cache_ok(mark):
+    if mark is None or not torch.cuda.is_current_stream_capturing() or mark[0] == torch.cuda.current_stream():
+        return True
+    if mark[1] is not None:
+        torch.cuda.current_stream().wait_event(mark[1])
+        return True
+    return False
+
+
+_cache_events = os.environ.get("VILCO_CACHE_EVENTS", "0") == "1"
 
 
 def pack(x, rows, cols, precision=None):
@@ -400,8 +407,7 @@ def pack(x, rows, cols, precision=None):
     prec = _precision if precision is None else int(precision)
     key = (int(rows), int(cols), prec, x._version)
     hit = getattr(x, "_vilco_planes", None) if _pack_cache else None
-    if hit is not None and hit[1] == key:
-        _cache_sync(hit[2])
+    if hit is not None and hit[1] == key and _cache_ok(hit[2]):
         return hit[0]
     nbytes = lib.vilco_pack_bytes(int(rows), int(cols), prec)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -428,8 +434,7 @@ def pack_tap(x, precision=None):
     B, T, Cn = x.shape
     key = ("tap", int(B), int(T), int(Cn), prec, x._version)
     hit = getattr(x, "_vilco_tap_planes", None) if _pack_cache else None
-    if hit is not None and hit[1] == key:
-        _cache_sync(hit[2])
+    if hit is not None and hit[1] == key and _cache_ok(hit[2]):
         return hit[0]
     it = _lib.PackItem()
     it.src, it.rows, it.cols, it.ld = x.data_ptr(), int(B * T), int(Cn), int(Cn)
