@@ -154,7 +154,7 @@ def test_single_part_weight_gradients_at_full_size(dev):
     assert sum(1 for e, _ in errs if e > 0) > 30          # the fast mode is actually in use (48 weight tensors at P)
 
 
-def p_train_step_vs_fp32_oracle(dev):
+def test_p_config_train_step_vs_fp32_oracle_with_replayed_masks(dev):
     """ONE full-size step of the benchmark workload itself -- config P, two clips, train mode with dropout 0.1 /
     stochastic depth 0.1 / XLNet dropout 0.1, the single-part weight-gradient products active -- against the fp32 oracle
     (the CPU restatement of the reference, ~15-30 s on the GPU box's host cores) replaying exactly the masks and
@@ -168,6 +168,15 @@ def p_train_step_vs_fp32_oracle(dev):
     model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet())).to(dev).train()
     batch = bench.synth_batch(2, dev)
     assert ops.dw_precision == 4 and ops.get_precision() == 3
+    # A FIXED mask realisation, whatever ran before in the process (the stochastic-depth factors come from the device RNG, the
+    # dropout seeds from a process-wide counter, replayed graphs leave the device step word behind): the state of a fresh
+    # interpreter after torch.manual_seed(0).  The bounds below are asserted for this realisation -- see the comment there.
+    from vilco_amd import _lib
+    from vilco_amd.modeling import blocks
+    torch.cuda.manual_seed_all(0)
+    blocks.reset_drop_pool()
+    ops._drop_counter[0] = 0
+    _lib.check(_lib.load().vilco_seed_word_set(0, None))
     ops.dropout_log = []
     try:
         losses = model(batch, is_training=True)
@@ -203,6 +212,15 @@ def p_train_step_vs_fp32_oracle(dev):
     #     (embd.1.conv.weight) stands at 8e-4, every other tensor below 4.1e-4 (strict 3-MFMA weight gradients: below 9e-5).
     # Bounds: every tensor within 1e-3 in the L2 sense (measured 3.3e-4), at most two tensors with any element beyond 1e-3 of
     # the maximum, none beyond 3e-3, and never more than 1e-4 of a tensor's elements.
+    #   * These numbers belong to THIS realisation of the masks.  A family of tensors whose gradients are ~1e-7 (the branches'
+    #     MLP / attention output projections behind the 1e-4 AffineDropPath scales, the heads' first convs) is a sum of
+    #     cancelling contributions: the fp32 oracle differs from an fp64 run of ITSELF by 0.1 ... 0.2 of the tensor maximum on
+    #     single elements there under any masks (profiles/r04_oracle_self_distance*.json), and under realisations that drop a
+    #     clip at some of the stochastic-depth sites the HIP step and the fp32 oracle differ the same way (0.15 on
+    #     branch.0.mlp.3.weight with the device RNG where the data-parallel + episode tests leave it, tools/lab/p_hist_dbg.py)
+    #     -- maximum values and L2 norms of those tensors still agree to three digits.  Element-wise agreement on that family is
+    #     a property of the realisation, not of either arithmetic; the oracle itself is bit-reproducible across process
+    #     histories (tools/lab/oracle_state_dbg.py) and so is the HIP step (tools/lab/state_dbg.py).
     l2, outliers, worst = [], [], []
     for k, g in got.items():
         if p[k].grad is not None and not k.endswith(('key_norm.bias', '.key.bias')):     # analytically zero (softmax shift)
@@ -218,19 +236,3 @@ def p_train_step_vs_fp32_oracle(dev):
     assert outliers[0][0] < 1e-4, outliers[:5]
     assert worst[0][0] < 3e-3, worst[:8]
     assert sum(1 for e, _ in worst if e < 1e-3) >= len(worst) - 2, worst[:10]
-
-
-
-def test_p_config_train_step_vs_fp32_oracle_with_replayed_masks(dev):
-    """`p_train_step_vs_fp32_oracle` in a process of its own.  The CPU oracle's gradients for a family of near-cancelling
-    tensors (the branches' MLP output projections, the heads' first convs: |gradient| ~ 1e-8) depend on what the host process
-    did before -- after the data-parallel and episode tests of this suite the same oracle call returns values up to 0.15 of
-    the tensor maximum away from what it returns in a fresh interpreter (round 4, tools/lab/state_dbg.py), while the HIP
-    step's gradients are bit-identical in both situations.  The reference a user would compare against is the fresh one."""
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_fullsize_gpu as t; "
-            "t.p_train_step_vs_fp32_oracle(torch.device('cuda:0')); print('P_PARITY_OK')" % (here, os.path.dirname(here)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(here))
-    assert r.returncode == 0 and "P_PARITY_OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
