@@ -212,15 +212,16 @@ def test_p_config_train_step_vs_fp32_oracle_with_replayed_masks(dev):
     #     (embd.1.conv.weight) stands at 8e-4, every other tensor below 4.1e-4 (strict 3-MFMA weight gradients: below 9e-5).
     # Bounds: every tensor within 1e-3 in the L2 sense (measured 3.3e-4), at most two tensors with any element beyond 1e-3 of
     # the maximum, none beyond 3e-3, and never more than 1e-4 of a tensor's elements.
-    #   * These numbers belong to THIS realisation of the masks.  A family of tensors whose gradients are ~1e-7 (the branches'
-    #     MLP / attention output projections behind the 1e-4 AffineDropPath scales, the heads' first convs) is a sum of
-    #     cancelling contributions: the fp32 oracle differs from an fp64 run of ITSELF by 0.1 ... 0.2 of the tensor maximum on
-    #     single elements there under any masks (profiles/r04_oracle_self_distance*.json), and under realisations that drop a
-    #     clip at some of the stochastic-depth sites the HIP step and the fp32 oracle differ the same way (0.15 on
-    #     branch.0.mlp.3.weight with the device RNG where the data-parallel + episode tests leave it, tools/lab/p_hist_dbg.py)
-    #     -- maximum values and L2 norms of those tensors still agree to three digits.  Element-wise agreement on that family is
-    #     a property of the realisation, not of either arithmetic; the oracle itself is bit-reproducible across process
-    #     histories (tools/lab/oracle_state_dbg.py) and so is the HIP step (tools/lab/state_dbg.py).
+    #   * These numbers belong to THIS realisation of the masks.  Besides the ReLU flips above there is a second kind of discrete
+    #     decision: the stride-2 max-pool of a branch block's skip path routes a residual-stream gradient element to one of two
+    #     near-tied neighbouring tokens, and two evaluations whose forward activations differ in the last bits pick differently at a
+    #     few windows (tools/diag/grad_family_probe.py: the fp32 oracle vs an fp64 run of ITSELF, 0.39 of max|dY| at token pairs
+    #     18 / 19 and 77 / 78).  Where such an element lands in a tensor whose gradients carry the 1e-4 AffineDropPath factor (the
+    #     branches' MLP / attention output projections, ~1e-7) it is ~10 % of that tensor's maximum: 0.1 ... 0.2 between the fp32
+    #     and fp64 oracle under any masks (profiles/r04_oracle_self_distance*.json), 0.15 between the HIP step and the fp32 oracle
+    #     under the realisation the data-parallel + episode tests leave behind (tools/lab/p_hist_dbg.py) -- maxima and L2 norms of
+    #     those tensors still agree to three digits.  Both arithmetics are bit-reproducible given the masks
+    #     (tools/lab/state_dbg.py, oracle_state_dbg.py).
     l2, outliers, worst = [], [], []
     for k, g in got.items():
         if p[k].grad is not None and not k.endswith(('key_norm.bias', '.key.bias')):     # analytically zero (softmax shift)
