@@ -334,6 +334,15 @@ int vilco_act_bwd(const float* dy, const float* aux, float* dz, float* dbias, in
 int vilco_act_bwd_amax(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
                        const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p, uint32_t drop_seed,
                        void* workspace, size_t workspace_bytes, float* amax_parts, int32_t* n_parts, void* stream);
+/* the same, and dz written by this kernel as the fp16 x2 operand planes of its consumers (`planes`: vilco_pack's layout for
+ * [rows][C] at precision 3, vilco_pack_bytes() long, 256-byte aligned; C % 32 == 0) -- no vilco_pack of dz follows.  The
+ * planes' scale comes from a BOUND instead of the exact maximum: max|dy| (dy_amax: n_dy_amax partial maxima of |dy| left by
+ * the producer of dy, e.g. vilco_gemm_desc.amax_out) x 1 / (1 - drop_p) x max|act'|; it is the same power-of-two rule, at
+ * most two binary orders below the exact-maximum scale.  dz may be NULL (planes only). */
+int vilco_act_bwd_planes(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
+                         const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p, uint32_t drop_seed,
+                         void* workspace, size_t workspace_bytes, float* amax_parts, int32_t* n_parts,
+                         const float* dy_amax, int32_t n_dy_amax, void* planes, size_t planes_bytes, void* stream);
 /* out[c] = sum_r x[r][c] */
 int vilco_colsum(const float* x, float* out, int64_t rows, int32_t C, void* workspace,
                  size_t workspace_bytes, void* stream);

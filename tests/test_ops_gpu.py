@@ -659,3 +659,79 @@ def test_single_part_products_two_k_steps_per_interval(dev, M, N, K, form):
     C2 = torch.empty(M, N, device=dev)
     ops.gemm(A, B, C2, M, N, K, a_kc, b_kc, lda, ldb, N, precision=4, a_planes=pa, b_planes=pb)
     assert rel(C2, want) < 2e-6
+
+
+@pytest.mark.parametrize("rows,C,act,p,masked", [(4608, 1024, 2, 0.1, True), (100, 96, 0, 0.0, True), (333, 64, 1, 0.3, False), (77, 1024, 2, 0.0, False)])
+def test_act_bwd_writes_operand_planes(dev, rows, C, act, p, masked):
+    """vilco_act_bwd_planes: dz written by the activation-backward kernel as fp16 x2 operand planes (scale from a bound on
+    max|dz| instead of the exact maximum) -- the planes decode to the fp32 dz of the plain kernel to 22 bits, their zero rows
+    are zero, the bias gradient is unchanged, and both backward products read them like the planes `pack` makes."""
+    from vilco_amd import ops, _lib
+    torch.manual_seed(rows + C)
+    T = rows
+    dy = torch.randn(rows, C, device=dev) * 3e-4
+    dy[5, :] *= 40.0
+    aux = torch.randn(rows, C, device=dev)
+    lens = torch.tensor([rows - 9], dtype=torch.int32, device=dev) if masked else None
+    drop = (p, 1234)
+    dz_ref, db_ref = ops._act_bwd(dy, aux if act else None, act, lens, T if masked else None, True, drop)
+    parts = torch.stack([dy[: rows // 2].abs().max(), dy[rows // 2:].abs().max()])          # what the producer of dy would leave
+    ops._tag_amax(dy, parts, 2)
+    dz, db, planes = ops._act_bwd(dy, aux if act else None, act, lens, T if masked else None, True, drop, planes=True)
+    assert dz is None and planes is not None and planes.numel() == _lib.load().vilco_pack_bytes(rows, C, 3)
+    assert torch.equal(db, db_ref)
+    hdr = planes[:4096 + 512].view(torch.float32)
+    inv_s, s = float(hdr[1024]), float(hdr[1025])
+    assert inv_s * s == 1.0
+    bound = float(dy.abs().max()) / (1.0 - p) * (1.13 if act == 2 else 1.0)
+    assert 2.0 ** 14 <= bound * s < 2.0 ** 15
+    rows32 = (rows + 31) // 32 * 32
+    body = planes[4096 + 512:].view(torch.float16).view(2, rows32, C).double()
+    dec = (body[0] + body[1]) / s
+    assert float(dec[rows:].abs().max()) == 0.0 if rows32 > rows else True
+    err = (dec[:rows] - dz_ref.double()).abs()
+    assert bool((err <= dz_ref.double().abs() * 2.0 ** -21 + bound * 2.0 ** -39).all())
+    # the two products of a Linear backward on these planes vs on pack(dz)
+    N2 = 72
+    w = torch.randn(C, N2, device=dev) / 8          # dX = dZ W (NN), dW = dZ^T X (TN)
+    x = torch.randn(rows, N2, device=dev)
+    pw, px, pz = ops.pack(w, C, N2), ops.pack(x, rows, N2), ops.pack(dz_ref, rows, C)
+    for pl in (planes, pz):
+        dx, dw = torch.empty(rows, N2, device=dev), torch.empty(C, N2, device=dev)
+        ops.gemm(None, w, dx, rows, N2, C, 1, 0, C, N2, N2, a_planes=pl, b_planes=pw)
+        ops.gemm(None, x, dw, C, N2, rows, 0, 0, C, N2, N2, a_planes=pl, b_planes=px)
+        assert rel(dx, dz_ref.double() @ w.double()) < 4e-6 and rel(dw, dz_ref.double().t() @ x.double()) < 4e-6
+
+
+def test_linear_backward_takes_producer_planes(dev, monkeypatch):
+    """a Linear whose upstream gradient carries amax partials (here: the dX of the layer above) runs its backward without a pack
+    of dz and without an fp32 dz; gradients equal the VILCO_PRODUCER_PLANES=0 path to operand precision"""
+    from vilco_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(2, 300, 64, device=dev, requires_grad=True)
+    w1 = (torch.randn(256, 64, device=dev) / 8).requires_grad_(True)
+    b1 = torch.randn(256, device=dev, requires_grad=True)
+    w2 = (torch.randn(64, 256, device=dev) / 16).requires_grad_(True)
+    lens = torch.tensor([300, 250], dtype=torch.int32, device=dev)
+    g = torch.randn(2, 300, 64, device=dev)
+    calls = []
+    real = ops._act_bwd
+
+    def spy(*a, **k):              # (flags only: a held reference to db would make AccumulateGrad copy it before its deferred finish)
+        out = real(*a, **k)
+        calls.append(tuple(t is not None for t in out))
+        return out
+    monkeypatch.setattr(ops, "_act_bwd", spy)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, "producer_planes", on)
+        for t in (x, w1, b1, w2):
+            t.grad = None
+        calls.clear()
+        y = ops.linear(ops.linear(x, w1, b1, ops.ACT_GELU, lens, 300), w2, None, ops.ACT_NONE, lens, 300)
+        y.backward(g)
+        res.append([t.grad.clone() for t in (x, w1, b1, w2)])
+        fc1 = [c for c in calls if len(c) == 3 and c[1]]          # the GELU layer's call (it has the bias): (dz?, db?, planes?)
+        assert fc1 == [(False, True, True) if on else (True, True, False)]
+    for a, c in zip(*res):
+        assert rel(a, c) < 2e-6

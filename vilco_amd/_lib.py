@@ -119,6 +119,8 @@ SIGNATURES = {
     "vilco_act_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp]),
     "vilco_act_bwd_amax": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp,
                                      C.POINTER(i32), c_fp]),
+    "vilco_act_bwd_planes": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp,
+                                       C.POINTER(i32), c_fp, i32, c_fp, sz, c_fp]),
     "vilco_colsum": (C.c_int, [c_fp, c_fp, i64, i32, c_fp, sz, c_fp]),
     "vilco_mask_rows": (C.c_int, [c_fp, c_fp, i32, i32, i32, c_fp]),
     "vilco_add_pe": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),

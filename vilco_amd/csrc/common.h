@@ -195,5 +195,11 @@ __device__ __forceinline__ void vilco_finish_colsum(const float* __restrict__ ws
 
 // deferred second stages of two-stage reductions (defer.hip)
 bool vilco_defer_active();
+
+// vilco_pack buffers (pack.h, gemm.hip): [VILCO_AMAX_MAX_BLOCKS floats of amax partials | {1/s, s} | pad] = VILCO_PACK_HDR bytes,
+// then the 16-bit planes [part][rows32][cols32].  Producers that write the planes of their own output (eltwise.hip, norm.hip)
+// use the same layout.
+constexpr int VILCO_AMAX_MAX_BLOCKS = 1024;
+constexpr long VILCO_PACK_HDR = VILCO_AMAX_MAX_BLOCKS * 4 + 512;
 void vilco_defer_push_rr(const float* ws, float* out0, float* out1, int nrows, int ncols, int split);
 void vilco_defer_push_sk(const float* part, float* out, long split_stride, long ldc, int M, int N, int ksplit);

@@ -175,12 +175,51 @@ __global__ __launch_bounds__(EW_THREADS) void axpby_kernel(float* __restrict__ o
     out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
 
+// Producer-written operand planes (round 4).  dz goes nowhere but into the two backward products of its layer, as fp16 x2
+// planes (pack.h): a plane element can be written the moment its value exists IF the tensor's scale is known -- and a scale
+// needs no exact maximum, only a bound: |dz| <= max|dy| * (1 / keep) * max|act'|, with max|dy| folded from the partials the
+// producer of dy left (what the pack kernel does with them), max|gelu'| < 1.13.  The scale is the same power-of-two rule
+// (bound * s in [2^14, 2^15)); a bound k bits above the true maximum only raises the format's absolute floor from 2^-40 to
+// 2^(k-40) of the tensor maximum (k <= 2 here), the 22 significant bits of every element are untouched.
+struct PlaneOut {
+  _Float16* p0;              // part 0 of element (r, c) at p0[r * C + c] (C % 32 == 0: no column padding); null = no planes
+  long plane_stride;         // elements between the two parts
+  const float* in_amax;      // partial maxima of |dy|
+  int n_in_amax;
+  float bound_factor;
+  float* inv_scale;          // {1/s, s} for the consumer kernel
+  long rows32;               // rows of a plane; rows .. rows32 - 1 are zeroed here
+};
+
+__device__ __forceinline__ float plane_scale_from_bound(const PlaneOut& po, bool writer) {
+  __shared__ float red_[EW_THREADS / 64];
+  float m = 0.f;
+  const int last = po.n_in_amax - 1;
+  for (int i = threadIdx.x; i < po.n_in_amax; i += 4 * EW_THREADS) {      // four partials in flight (a clamped repeat changes no maximum)
+    const float p0 = po.in_amax[i], p1 = po.in_amax[i + EW_THREADS < last ? i + EW_THREADS : last],
+                p2 = po.in_amax[i + 2 * EW_THREADS < last ? i + 2 * EW_THREADS : last],
+                p3 = po.in_amax[i + 3 * EW_THREADS < last ? i + 3 * EW_THREADS : last];
+    m = fmaxf(fmaxf(m, fmaxf(p0, p1)), fmaxf(p2, p3));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red_[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red_[0], red_[1]), fmaxf(red_[2], red_[3])) * po.bound_factor;
+  int e = (int)((__float_as_uint(m) >> 23) & 0xff);
+  if (e < 15) e = 15;                                     // tiny / zero tensors: any scale works
+  if (e > 250) e = 250;                                   // inf input: the result is garbage either way
+  if (writer) { po.inv_scale[0] = __uint_as_float((unsigned)(e - 14) << 23); po.inv_scale[1] = __uint_as_float((unsigned)(268 - e) << 23); }
+  return __uint_as_float((unsigned)(268 - e) << 23);
+}
+
 // dz = dy * act'(aux) * rowmask ; partial dbias -> ws[row chunk][C]   (same 2-D decomposition)
+// PLANES: dz is (also, or only: dz may be null) written as the fp16 x2 operand planes of its consumers
+template <bool PLANES>
 __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ dz,
     float* __restrict__ ws, int act, const int* __restrict__ len, int T, long rows, int C,
     int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, float drop_inv_keep, float* __restrict__ dbias,
-    unsigned* sync, float* __restrict__ amax_parts, const uint32_t* __restrict__ seed_word) {
+    unsigned* sync, float* __restrict__ amax_parts, const uint32_t* __restrict__ seed_word, PlaneOut po) {
   if (drop_thresh) drop_seed = vilco_step_seed(drop_seed, seed_word);
   __shared__ float amax_red[EW_THREADS / 64];
   float amax = 0.f;          // max |dz| of this block: dz goes straight into an operand pack
@@ -188,6 +227,8 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
   const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  float fs = 0.f;
+  if (PLANES) fs = plane_scale_from_bound(po, (blockIdx.x | blockIdx.y) == 0 && threadIdx.x == 0);
   if (c < C) {
     float acc = 0.f;
     auto one = [&](long r, float g, float ax) {
@@ -195,7 +236,13 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
       if (len && (int)(r % T) >= len[r / T]) g = 0.f;
       if (act == VILCO_ACT_RELU) g = (ax > 0.f) ? g : 0.f;
       else if (act == VILCO_ACT_GELU) g *= gelu_grad_f(ax);
-      dz[r * C + c] = g;
+      if (!PLANES || dz) dz[r * C + c] = g;
+      if (PLANES) {
+        const float xs = g * fs;                        // exact (power of two)
+        const _Float16 h0 = (_Float16)xs;
+        po.p0[r * C + c] = h0;
+        po.p0[po.plane_stride + r * C + c] = (_Float16)(xs - (float)h0);
+      }
       acc += g;
       amax = fmaxf(amax, fabsf(g));
     };
@@ -214,6 +261,8 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     }
     for (; r < r1; ++r) one(r, dy[r * C + c], has_aux ? aux[r * C + c] : 0.f);
     if (ws) vilco_st_agent(ws + (long)blockIdx.x * C + c, acc);
+    if (PLANES && blockIdx.x == gridDim.x - 1)          // the planes' zero rows (a k-major reader contracts over them)
+      for (long rz = rows; rz < po.rows32; ++rz) { po.p0[rz * C + c] = (_Float16)0.f; po.p0[po.plane_stride + rz * C + c] = (_Float16)0.f; }
   }
   if (amax_parts) {
     amax = wave_max(amax);
@@ -450,9 +499,32 @@ extern "C" int vilco_act_bwd_amax(const float* dy, const float* aux, float* dz, 
                                   const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p,
                                   uint32_t drop_seed, void* workspace, size_t workspace_bytes, float* amax_parts,
                                   int32_t* n_parts, void* stream) {
+  return vilco_act_bwd_planes(dy, aux, dz, dbias, act, len, T, rows, C, drop_p, drop_seed, workspace, workspace_bytes, amax_parts,
+                              n_parts, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int vilco_act_bwd_planes(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
+                                    const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p,
+                                    uint32_t drop_seed, void* workspace, size_t workspace_bytes, float* amax_parts,
+                                    int32_t* n_parts, const float* dy_amax, int32_t n_dy_amax, void* planes, size_t planes_bytes,
+                                    void* stream) {
   if (n_parts) *n_parts = 0;
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
-  if (!dy || !dz || rows < 0 || C <= 0 || act < 0 || act > 2) return VILCO_ERR_BADARG;
+  if (!dy || (!dz && !planes) || rows < 0 || C <= 0 || act < 0 || act > 2) return VILCO_ERR_BADARG;
+  PlaneOut po = {nullptr, 0, nullptr, 0, 1.f, nullptr, 0};
+  if (planes) {
+    // the planes of dz in vilco_pack's layout (precision 3, [rows][C]); needs the partial maxima of |dy| for the scale bound
+    if (!dy_amax || n_dy_amax <= 0 || (C % 32) != 0 || !vilco_aligned(planes, 256)) return VILCO_ERR_BADARG;
+    const long rows32 = (rows + 31) / 32 * 32;
+    if (planes_bytes < (size_t)(VILCO_PACK_HDR + (rows32 > 0 ? rows32 : 32) * (long)C * 4)) return VILCO_ERR_WORKSPACE;
+    unsigned char* u = reinterpret_cast<unsigned char*>(planes);
+    po.p0 = reinterpret_cast<_Float16*>(u + VILCO_PACK_HDR);
+    po.plane_stride = (rows32 > 0 ? rows32 : 32) * (long)C;
+    po.in_amax = dy_amax; po.n_in_amax = n_dy_amax;
+    po.bound_factor = (1.f / (1.f - drop_p)) * (act == VILCO_ACT_GELU ? 1.13f : 1.f);
+    po.inv_scale = reinterpret_cast<float*>(u) + VILCO_AMAX_MAX_BLOCKS;
+    po.rows32 = rows32;
+  }
   if (act != VILCO_ACT_NONE && !aux) return VILCO_ERR_BADARG;
   if (len && T <= 0) return VILCO_ERR_BADARG;
   if (rows == 0) return VILCO_OK;
@@ -464,9 +536,14 @@ extern "C" int vilco_act_bwd_amax(const float* dy, const float* aux, float* dz, 
   unsigned* sync = (dbias && C <= 256 * VILCO_SYNC_MAX_BLOCKS) ? vilco_sync_counter(s, VILCO_SITE_COLSUM) : nullptr;
   const bool emit = amax_parts && n_parts;
   if (emit) *n_parts = nb * ((C + EW_THREADS - 1) / EW_THREADS);
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
-                     (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,
-                     emit ? amax_parts : nullptr, vilco_seed_word_dev());
+  if (planes)
+    hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
+                       (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,
+                       emit ? amax_parts : nullptr, vilco_seed_word_dev(), po);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
+                       (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,
+                       emit ? amax_parts : nullptr, vilco_seed_word_dev(), po);
   if (dbias && !sync) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }

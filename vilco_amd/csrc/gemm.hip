@@ -213,7 +213,11 @@ __device__ __forceinline__ void wait_sc1(f32x4& a, f32x4& b, f32x4& c, f32x4& d)
 // part and 32 elements per interval the loop was bound by its MEM phase (16 MFMAs per wave against ~1000 cycles of
 // reads, stores and loads: ~2000 cycles per 32 k, MFMA pipe 25 % busy); the interval's fixed cost now buys twice the K.
 template <int BM, int NP, bool F16, bool AKM, bool BKM, bool K2 = false>
+#ifdef VILCO_GEMM_WPE            // (lab: 4 holds every instantiation at <= 128 VGPRs, tools/lab/occ_ab.py)
+__global__ __launch_bounds__(512, VILCO_GEMM_WPE) void gemm_pp_kernel(GArgs g) {
+#else
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
+#endif
   static_assert(!K2 || (NP == 2 && F16), "K2: two slots, fp16 parts");
   constexpr int NT = 512;
   constexpr int MI = BM / 64;                    // 16-row A fragments per wave (wave tile = 16*MI x 64)
@@ -765,7 +769,7 @@ inline bool use_km() {
   return v != 0;
 }
 constexpr long SCALE_BYTES = 2 * AMAX_MAX_BLOCKS * 4 + 256;   // fp16 x2 format: amax partials of A and B, then {1/sA, sA, 1/sB, sB}
-constexpr long PACK_HDR = AMAX_MAX_BLOCKS * 4 + 512;          // vilco_pack buffers: amax partials, {1/s, s}, then the planes
+constexpr long PACK_HDR = VILCO_PACK_HDR;                      // vilco_pack buffers: amax partials, {1/s, s}, then the planes
 
 inline bool k2_enabled() {
   static const bool on = [] { const char* e = getenv("VILCO_GEMM_K2"); return !(e && e[0] == '0'); }();

@@ -282,7 +282,7 @@ __device__ __forceinline__ void pack_tr_body(const PackArgs& a, int bz) {
 // ------------------------------------------------------------------------------------------ amax (fmt 1)
 // Every pack source is a strided matrix [R][W] (W contiguous) per batch; up to four operands per launch
 // (blockIdx.y); block b leaves max|x| over its rows in parts[b].
-constexpr int AMAX_MAX_BLOCKS = 1024;
+constexpr int AMAX_MAX_BLOCKS = VILCO_AMAX_MAX_BLOCKS;
 
 struct AmaxOp {
   const float* src;

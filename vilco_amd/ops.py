@@ -539,24 +539,41 @@ def weight_planes(w, rows, cols):
     return _cached(w, ("planes", rows, cols), lambda: pack(_weight_src(w, w.detach()), rows, cols))
 
 
-def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None):
+# dz of a layer goes nowhere but into its two backward products: `_act_bwd(planes=True)` has the kernel write dz as operand planes
+# (vilco_act_bwd_planes: scale from a bound on max|dz|, no pack launch, no fp32 dz) when dy carries its producer's amax partials.
+# VILCO_PRODUCER_PLANES=0: fp32 dz + pack, as before.
+producer_planes = os.environ.get("VILCO_PRODUCER_PLANES", "1") != "0"
+
+
+def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None, planes=False):
     """dz = dropmask(dy) * act'(aux) * rowmask, optional column sums -> (dz, dbias).  bias_param: the parameter dbias is the
-    gradient of (its column sum may then finish with the other deferred reductions, see _Deferring)."""
+    gradient of (its column sum may then finish with the other deferred reductions, see _Deferring).
+    planes=True -> (dz or None, dbias, operand planes of dz or None): when the planes come back, dz was never written."""
     lib = _lib.load()
     rows, Cn = dy.numel() // dy.shape[-1], dy.shape[-1]
-    dz = torch.empty_like(dy)
+    dy_parts, dy_n = _amax_of(dy) if (planes and producer_planes and _precision == 3 and Cn % 32 == 0 and rows > 0) else (None, 0)
+    pz = None
+    if dy_parts is not None:
+        nbytes = lib.vilco_pack_bytes(rows, Cn, 3)
+        pz = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    dz = torch.empty_like(dy) if pz is None else None
     db = torch.empty(Cn, dtype=torch.float32, device=dy.device) if want_bias else None
     with _Deferring(bias_param if want_bias else None) as dfr:
         ws = _ws(lib.vilco_colsum_workspace(rows, Cn), dy.device) if want_bias else None
-        parts = torch.empty(AMAX_PARTS, dtype=torch.float32, device=dy.device) if (produce_amax and _precision == 3) else None
+        parts = torch.empty(AMAX_PARTS, dtype=torch.float32, device=dy.device) if (produce_amax and _precision == 3 and pz is None) else None
         n = C.c_int32(0)
-        _lib.check(lib.vilco_act_bwd_amax(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
-                                          int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
-                                          _p(parts), C.byref(n), _stream()))
+        if pz is None:
+            _lib.check(lib.vilco_act_bwd_amax(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
+                                              int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
+                                              _p(parts), C.byref(n), _stream()))
+        else:
+            _lib.check(lib.vilco_act_bwd_planes(dy.data_ptr(), _p(aux), None, _p(db), act, _p(lens),
+                                                int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
+                                                None, None, dy_parts.data_ptr(), int(dy_n), pz.data_ptr(), pz.numel(), _stream()))
         dfr.hold(db)
     if parts is not None:
         _tag_amax(dz, parts, n.value)
-    return dz, db
+    return (dz, db, pz) if planes else (dz, db)
 
 
 def colsum(x2d, param=None):
@@ -609,11 +626,15 @@ class _Linear(torch.autograd.Function):
         K, N = x.shape[-1], w.shape[0]
         M = x.numel() // K
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        pz = None
         if ctx.act != ACT_NONE or lens is not None or ctx.drop[0] > 0.0:
-            dz, db = _act_bwd(dy, aux, ctx.act, lens, ctx.T, need_db, ctx.drop, bias_param=b)
+            # (the planes of dz straight from the kernel when both products below take planes in the ambient format)
+            want_planes = ctx.bwd_precision is None and px is not None and ctx.prec == 3 and _precision == 3
+            r = _act_bwd(dy, aux, ctx.act, lens, ctx.T, need_db, ctx.drop, bias_param=b, planes=want_planes)
+            dz, db, pz = r if want_planes else (r[0], r[1], None)
         else:
             dz, db = dy, (colsum(dy.view(M, N), param=b) if need_db else None)
-        dx = dw = pz = None
+        dx = dw = None
         prec = None
         if ctx.bwd_precision is not None:
             # a call site whose gradient tensors span more exponent range than one scale per tensor can carry (see
@@ -629,7 +650,8 @@ class _Linear(torch.autograd.Function):
             return dx, dw, db, None, None, None, None, None, None
         if px is not None:                       # one pack of dZ feeds dX and dW; X and W planes come from forward
             prec = ctx.prec
-            pz = pack(dz, M, N, prec)
+            if pz is None:
+                pz = pack(dz, M, N, prec)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=prec, a_planes=pz, b_planes=pw, want_amax=True)   # dX = dZ W     (NN)
