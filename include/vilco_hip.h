@@ -188,6 +188,19 @@ int vilco_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 int vilco_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y,
                              float* mean, float* rstd, int64_t rows, int32_t C, float eps,
                              int32_t relu, float* amax_parts, int32_t* n_parts, void* stream);
+/* the same, and y also written by the kernel as the fp16 x2 operand planes (precision 3) of the product that consumes it: */
+/* seq_len = 0: vilco_pack's layout for [rows][C] (C % 32 == 0); seq_len = T > 0: the k=3 convs' zero-padded per-sequence    */
+/* image (vilco_pack_item.seq_len; C % 8 == 0, rows % T == 0).  `planes`: device, 256-byte aligned,                           */
+/* vilco_layernorm_planes_bytes() long (= vilco_pack_bytes / vilco_pack_item_bytes of the same tensor).  The planes' scale    */
+/* comes from the bound max|gamma| sqrt(C) + max|beta| >= max|y| instead of the exact maximum: no pass over y, no pack launch. */
+/* row_mask (optional, with or without planes): y[row][:] *= row_mask[row % mask_rows] -- the zero separator rows of the heads' */
+/* concatenated pyramid levels (meta_archs.py:216-235 runs the shared head per level); with relu = 1 and a 0 / 1 mask          */
+/* vilco_layernorm_bwd needs no mask of its own: it already drops the gradient wherever the saved y is 0.                        */
+size_t vilco_layernorm_planes_bytes(int64_t rows, int32_t C, int32_t seq_len);
+int vilco_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, float* y,
+                               float* mean, float* rstd, int64_t rows, int32_t C, float eps,
+                               int32_t relu, float* amax_parts, int32_t* n_parts, void* planes, size_t planes_bytes,
+                               int32_t seq_len, const float* row_mask, int64_t mask_rows, void* stream);
 size_t vilco_layernorm_bwd_workspace(int64_t rows, int32_t C);
 /* y (forward output) is only read when relu=1.  dgamma/dbeta are overwritten. */
 int vilco_layernorm_bwd(const float* dy, const float* x, const float* y, const float* gamma,
@@ -307,6 +320,13 @@ int vilco_scale_add_bwd(const float* dout, const float* bval, const float* colsc
                         const float* rowscale, const int32_t* len, int32_t mask_a, float* da,
                         float* db, float* dcolscale, int32_t B, int32_t T, int32_t C,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* the same + partial maxima of |db| (db_amax_parts: device, >= 2048 floats; *n_parts = how many were written): db is the upstream
+ * gradient of the residual branch's last layer, whose activation-backward kernel turns it into operand planes
+ * (vilco_act_bwd_planes) */
+int vilco_scale_add_bwd_amax(const float* dout, const float* bval, const float* colscale, const float* rowscale,
+                             const int32_t* len, int32_t mask_a, float* da, float* db, float* dcolscale, int32_t B,
+                             int32_t T, int32_t C, void* workspace, size_t workspace_bytes, float* db_amax_parts,
+                             int32_t* n_parts, void* stream);
 /* Inverted dropout y = keep ? x/(1-p) : 0 with a counter-based mask (element i of the stream `seed` at `offset + i`):   */
 /* the backward pass is the same call on dy.  x = NULL writes the mask factors (0 or 1/(1-p)) -- what the parity tests  */
 /* hand to the oracle.  nn.Dropout in modeling_xlnet_x.py:308,327,486,488,1201,1228,1280 and blocks.py:226,268,349.      */

@@ -735,3 +735,101 @@ def test_linear_backward_takes_producer_planes(dev, monkeypatch):
         assert fc1 == [(False, True, True) if on else (True, True, False)]
     for a, c in zip(*res):
         assert rel(a, c) < 2e-6
+
+
+def test_scale_add_backward_tags_branch_gradient(dev):
+    """the branch gradient scale_add's backward writes carries its exact max|db| partials (vilco_scale_add_bwd_amax)"""
+    from vilco_amd import ops
+    torch.manual_seed(8)
+    B, T, C = 2, 50, 96
+    a = torch.randn(B, T, C, device=dev, requires_grad=True)
+    b = torch.randn(B, T, C, device=dev, requires_grad=True) * 1.0
+    cs = torch.randn(1, C, 1, device=dev, requires_grad=True)
+    lens = torch.tensor([50, 31], dtype=torch.int32, device=dev)
+    got = {}
+    b.register_hook(lambda g: got.__setitem__("db", g))
+    ops.scale_add(a, b, cs, None, lens, True).backward(torch.randn(B, T, C, device=dev))
+    parts, n = ops._amax_of(got["db"])
+    assert parts is not None and n > 0 and float(parts[:n].max()) == float(got["db"].abs().max())
+
+
+@pytest.mark.parametrize("B,T,C,relu,layout", [(2, 2304, 1024, False, "nat"), (3, 37, 96, False, "nat"), (2, 50, 64, True, "seq"),
+                                               (2, 4541, 1024, True, "seq"), (1, 77, 1000, False, "nat"), (2, 40, 72, True, "seq")])
+def test_layernorm_writes_operand_planes(dev, B, T, C, relu, layout):
+    """vilco_layernorm_fwd_planes: the LayerNorm kernel also writes its output as fp16 x2 operand planes, scaled by the bound
+    max|gamma| sqrt(C) + max|beta| -- natural rows (a Linear's input) or the k=3 convs' zero-padded per-sequence image.  The
+    planes decode to y to 22 bits, every padding row is zero, the consumer's pack finds them, and the products on them equal
+    the products on packed planes."""
+    from vilco_amd import ops
+    torch.manual_seed(B * T + C)
+    x = torch.randn(B, T, C, device=dev) * 3 + 1
+    g = (torch.randn(C, device=dev) * 0.5 + 1).requires_grad_(True)
+    bt = (torch.randn(C, device=dev) * 0.2).requires_grad_(True)
+    y_ref = ops.layernorm(x, g, bt, 1e-5, relu).detach()
+    y = ops.layernorm(x, g, bt, 1e-5, relu, planes=layout)
+    assert torch.equal(y.detach(), y_ref)
+    hit = getattr(y, "_vilco_planes" if layout == "nat" else "_vilco_tap_planes", None)
+    if (C % 32 if layout == "nat" else C % 8):
+        assert hit is None          # unsupported width: the hint is ignored, the consumer packs
+        return
+    planes = hit[0]
+    assert (ops.pack(y, B * T, C) if layout == "nat" else ops.pack_tap(y)) is planes          # what the consumer will find
+    hdr = planes[:4096 + 512].view(torch.float32)
+    inv_s, s = float(hdr[1024]), float(hdr[1025])
+    bound = float(g.detach().abs().max()) * math.sqrt(C) + float(bt.detach().abs().max())
+    assert inv_s * s == 1.0 and 2.0 ** 14 <= bound * s < 2.0 ** 15 and float(y_ref.abs().max()) <= bound
+    if layout == "nat":
+        rows32 = (B * T + 31) // 32 * 32
+        body = planes[4096 + 512:].view(torch.float16).view(2, rows32, C).double()
+        dec = (body[0] + body[1]) / s
+        want = torch.zeros(rows32, C, dtype=torch.float64, device=dev)
+        want[:B * T] = y_ref.view(B * T, C).double()
+    else:
+        tr = (B * (T + 2) + 31) // 32 * 32 + 64
+        ps = (tr * C + 7) // 8 * 8
+        raw = planes[4096 + 512:].view(torch.float16)
+        dec = ((raw[:tr * C].double() + raw[ps:ps + tr * C].double()) / s).view(tr, C)
+        want = torch.zeros(tr, C, dtype=torch.float64, device=dev)
+        for b in range(B):
+            want[b * (T + 2) + 1: b * (T + 2) + 1 + T] = y_ref[b].double()
+    assert bool(((dec - want).abs() <= want.abs() * 2.0 ** -21 + bound * 2.0 ** -39).all())
+    pad = dec[want.abs().sum(1) == 0]
+    assert pad.numel() == 0 or float(pad.abs().max()) == 0.0          # zero rows are exactly zero
+    # the consumer: a Linear / a k=3 conv forward + backward on the producer's planes vs on its own pack
+    N = 40
+    w = (torch.randn(N, C, device=dev) / 8) if layout == "nat" else (torch.randn(N, C, 3, device=dev) / 8)
+    res = []
+    for hint in (layout, None):
+        xx = x.clone().requires_grad_(True)
+        ww = w.clone().requires_grad_(True)
+        yy = ops.layernorm(xx, g, bt, 1e-5, relu, planes=hint)
+        out = ops.linear(yy, ww) if layout == "nat" else ops.conv3(yy, ww)
+        out.backward(torch.ones_like(out) / 7)
+        res.append((out.detach(), xx.grad, ww.grad))
+    for a, c in zip(*res):
+        assert rel(a, c) < 2e-6
+
+
+def test_layernorm_row_mask_equals_masking_afterwards(dev):
+    """LayerNorm + ReLU with the LevelCat separator rows zeroed inside the kernel (row_mask) == the op followed by the mask
+    multiply, forward and backward, and the operand image written alongside holds the masked rows"""
+    from vilco_amd import ops
+    torch.manual_seed(12)
+    B, T, C = 2, 45, 64
+    mask = (torch.rand(T, device=dev) > 0.2).float()[None, :, None].contiguous()
+    g0, b0 = torch.randn(C, device=dev) * 0.5 + 1, torch.randn(C, device=dev) * 0.3
+    x0, dy = torch.randn(B, T, C, device=dev), torch.randn(B, T, C, device=dev)
+    res = []
+    for fused in (True, False):
+        x, g, b = x0.clone().requires_grad_(True), g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = ops.layernorm(x, g, b, 1e-5, True, "seq", mask) if fused else ops.layernorm(x, g, b, 1e-5, True) * mask
+        if fused:
+            planes = ops.pack_tap(y)
+            assert planes is y._vilco_tap_planes[0]
+            parts, n = ops._amax_of(y)
+            assert float(parts[:n].max()) == float(y.abs().max())
+        y.backward(dy)
+        res.append((y.detach(), x.grad, g.grad, b.grad))
+    for a, c in zip(*res):
+        assert torch.equal(a, c) or rel(a, c) < 1e-6
+    assert float((res[0][0] * (1 - mask)).abs().max()) == 0.0

@@ -84,6 +84,9 @@ SIGNATURES = {
     "vilco_pack_many": (C.c_int, [C.POINTER(PackItem), i32, i32, c_fp]),
     "vilco_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp]),
     "vilco_layernorm_fwd_amax": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp, C.POINTER(i32), c_fp]),
+    "vilco_layernorm_planes_bytes": (sz, [i64, i32, i32]),
+    "vilco_layernorm_fwd_planes": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32, f32, i32, c_fp, C.POINTER(i32), c_fp, sz,
+                                             i32, c_fp, i64, c_fp]),
     "vilco_layernorm_bwd_workspace": (sz, [i64, i32]),
     "vilco_layernorm_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32,
                                       i32, c_fp, sz, c_fp]),
@@ -111,6 +114,8 @@ SIGNATURES = {
     "vilco_colsum_workspace": (sz, [i64, i32]),
     "vilco_scale_add_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, i32,
                                       c_fp, sz, c_fp]),
+    "vilco_scale_add_bwd_amax": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, i32,
+                                           c_fp, sz, c_fp, C.POINTER(i32), c_fp]),
     "vilco_dropout": (C.c_int, [c_fp, c_fp, i64, f32, C.c_uint32, C.c_uint64, c_fp]),
     "vilco_seed_word_set": (C.c_int, [C.c_uint32, c_fp]),
     "vilco_seed_word_bump": (C.c_int, [c_fp]),

@@ -201,5 +201,8 @@ bool vilco_defer_active();
 // use the same layout.
 constexpr int VILCO_AMAX_MAX_BLOCKS = 1024;
 constexpr long VILCO_PACK_HDR = VILCO_AMAX_MAX_BLOCKS * 4 + 512;
+// rows of a zero-padded per-sequence plane image (vilco_pack_item.seq_len): nseq * (T + 2) padded rows + enough zero rows for
+// both readers -- the forward / dX conv's overlapped spans and the weight-gradient product's contraction over the padded rows
+static inline long vilco_tap_plane_rows(long nseq, long T) { return (nseq * (T + 2) + 31) / 32 * 32 + 64; }
 void vilco_defer_push_rr(const float* ws, float* out0, float* out1, int nrows, int ncols, int split);
 void vilco_defer_push_sk(const float* part, float* out, long split_stride, long ldc, int M, int N, int ksplit);

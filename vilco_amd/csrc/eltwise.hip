@@ -129,7 +129,9 @@ __global__ __launch_bounds__(EW_THREADS) void scale_add_bwd_kernel(
     const float* __restrict__ dout, const float* __restrict__ bval, const float* __restrict__ colscale,
     const float* __restrict__ rowscale, const int* __restrict__ len, int mask_a, float* __restrict__ da,
     float* __restrict__ db, float* __restrict__ ws, int B, int T, int C, int rows_per_block,
-    float* __restrict__ dcolscale, unsigned* sync) {
+    float* __restrict__ dcolscale, unsigned* sync, float* __restrict__ db_amax) {
+  __shared__ float amax_red[EW_THREADS / 64];
+  float amax = 0.f;          // max |db| of this block: db is the upstream gradient of the branch's last layer (see act_bwd_kernel<true>)
   const long R = (long)B * T;
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(EW_THREADS) void scale_add_bwd_kernel(
       const float am = (mask_a && len && t >= len[b]) ? 0.f : 1.f;
       const float rs = rowscale ? rowscale[b] : 1.f;
       if (da) da[r * C + c] = g * am;
-      if (db) db[r * C + c] = g * cs * rs;
+      if (db) { const float v = g * cs * rs; db[r * C + c] = v; amax = fmaxf(amax, fabsf(v)); }
       if (ws) acc += g * bv * rs;
     };
     long r = r0;
@@ -162,6 +164,13 @@ __global__ __launch_bounds__(EW_THREADS) void scale_add_bwd_kernel(
     }
     for (; r < r1; ++r) one(r, dout[r * C + c], ws ? bval[r * C + c] : 0.f);
     if (ws) vilco_st_agent(ws + (long)blockIdx.x * C + c, acc);
+  }
+  if (db_amax) {
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      db_amax[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
   }
   if (sync) vilco_finish_colsum(ws, dcolscale, nullptr, (int)gridDim.x, C, C, sync, blockIdx.y * gridDim.x + blockIdx.x,
                                 gridDim.x * gridDim.y);
@@ -444,6 +453,16 @@ extern "C" int vilco_scale_add_bwd(const float* dout, const float* bval, const f
                                    const float* rowscale, const int32_t* len, int32_t mask_a,
                                    float* da, float* db, float* dcolscale, int32_t B, int32_t T,
                                    int32_t C, void* workspace, size_t workspace_bytes, void* stream) {
+  return vilco_scale_add_bwd_amax(dout, bval, colscale, rowscale, len, mask_a, da, db, dcolscale, B, T, C, workspace, workspace_bytes,
+                                  nullptr, nullptr, stream);
+}
+
+extern "C" int vilco_scale_add_bwd_amax(const float* dout, const float* bval, const float* colscale,
+                                        const float* rowscale, const int32_t* len, int32_t mask_a,
+                                        float* da, float* db, float* dcolscale, int32_t B, int32_t T,
+                                        int32_t C, void* workspace, size_t workspace_bytes, float* db_amax_parts,
+                                        int32_t* n_parts, void* stream) {
+  if (n_parts) *n_parts = 0;
   if (!dout || B < 0 || T < 0 || C <= 0) return VILCO_ERR_BADARG;
   if (dcolscale && !bval) return VILCO_ERR_BADARG;
   const long rows = (long)B * T;
@@ -454,8 +473,10 @@ extern "C" int vilco_scale_add_bwd(const float* dout, const float* bval, const f
   const int rpb = (int)((rows + nb - 1) / nb);
   float* ws = dcolscale ? reinterpret_cast<float*>(workspace) : nullptr;
   unsigned* sync = (dcolscale && C <= 256 * VILCO_SYNC_MAX_BLOCKS) ? vilco_sync_counter(s, VILCO_SITE_COLSUM) : nullptr;
+  const bool emit = db && db_amax_parts && n_parts;
+  if (emit) *n_parts = nb * ((C + EW_THREADS - 1) / EW_THREADS);
   hipLaunchKernelGGL(scale_add_bwd_kernel, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dout, bval, colscale, rowscale,
-                     len, mask_a, da, db, ws, B, T, C, rpb, dcolscale, sync);
+                     len, mask_a, da, db, ws, B, T, C, rpb, dcolscale, sync, emit ? db_amax_parts : nullptr);
   if (dcolscale && !sync) vilco_reduce_rows(ws, dcolscale, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }

@@ -1077,7 +1077,7 @@ static inline long item_cols(const vilco_pack_item& it) { return it.relshift ? i
 // rows of a zero-padded per-sequence plane image (vilco_pack_item.seq_len): nseq * (T + 2) padded rows + enough zero rows for
 // both readers -- the forward / dX conv's overlapped spans (make_plan: a_out_rows) and the weight-gradient product's
 // contraction over the padded rows (Kp + 3 + one K-step)
-static inline long tap_plane_rows(long nseq, long T) { return align_up(nseq * (T + 2), 32) + 64; }
+static inline long tap_plane_rows(long nseq, long T) { return vilco_tap_plane_rows(nseq, T); }
 
 extern "C" size_t vilco_pack_item_bytes(const vilco_pack_item* it, int32_t precision) {
   if (!it || it->rows <= 0 || it->cols <= 0) return 0;

@@ -11,11 +11,26 @@ constexpr int LN_WAVES = LN_THREADS / 64;
 
 // FULL: C == 256 * NV, every lane owns NV float4 of the row -- no `c < C` guards.  A guarded load is a branch with its own
 // s_waitcnt: the NV loads of a row become NV dependent round trips (seen in the ISA; same finding as qkvpre.hip).
-template <int NV, bool FULL>
+// PLANES (round 4): the kernel also writes y as fp16 x2 operand planes (pack.h's format) for the matrix product that consumes
+// it -- natural rows, or the k=3 convs' zero-padded per-sequence image.  The scale comes from a bound instead of the tensor's
+// maximum (which only exists once every row is done): |xhat| < sqrt(C), so |y| < max|gamma| sqrt(C) + max|beta|, taken from the
+// parameter chunks every wave already holds.  A bound k binary orders above the true maximum (k ~ 3 for C = 1024) keeps all 22
+// significant bits of every element and raises the format's absolute floor from 2^-40 to 2^(k-40) of the tensor maximum.
+struct LnPlanes {
+  _Float16* p0;          // part 0; null = none
+  long plane_stride;     // elements between the parts
+  float* inv_scale;      // {1/s, s}
+  long rows_out;         // rows of one plane (natural: rows32; image: vilco_tap_plane_rows)
+  int seqT;              // 0: natural rows; T > 0: image rows b * (T + 2) + 1 + t
+  const float* row_mask; // optional (with or without planes): y[row] *= row_mask[row % mask_rows] (the LevelCat heads' separator rows)
+  long mask_rows;
+};
+
+template <int NV, bool FULL, bool PLANES>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long rows, int C,
-    float eps, int relu, float* __restrict__ amax_parts) {
+    float eps, int relu, float* __restrict__ amax_parts, LnPlanes po) {
   __shared__ float amax_red[LN_WAVES];
   float amax = 0.f;          // max |y| over this lane's outputs: the consumer's operand pack needs the tensor's amax
   const int lane = threadIdx.x & 63;
@@ -31,6 +46,25 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
       g[i] = gamma ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
       b[i] = beta ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  }
+
+  float fs = 0.f;
+  if (PLANES) {
+    float gmax = 0.f, bmax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (FULL || c < C) {
+        gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(g[i].x), fabsf(g[i].y))), fmaxf(fabsf(g[i].z), fabsf(g[i].w)));
+        bmax = fmaxf(fmaxf(bmax, fmaxf(fabsf(b[i].x), fabsf(b[i].y))), fmaxf(fabsf(b[i].z), fabsf(b[i].w)));
+      }
+    }
+    const float bound = wave_max(gmax) * sqrtf((float)C) + wave_max(bmax);        // the same value in every wave of the grid
+    int e = (int)((__float_as_uint(bound) >> 23) & 0xff);
+    if (e < 15) e = 15;
+    if (e > 250) e = 250;
+    fs = __uint_as_float((unsigned)(268 - e) << 23);                               // bound * fs in [2^14, 2^15)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { po.inv_scale[0] = __uint_as_float((unsigned)(e - 14) << 23); po.inv_scale[1] = fs; }
   }
 
   for (long row = wid; row < rows; row += wstride) {
@@ -62,6 +96,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
       if (rstd) rstd[row] = rs;
     }
     float* yr = y + row * C;
+    const long orow = (PLANES && po.seqT) ? (row / po.seqT) * (po.seqT + 2) + 1 + row % po.seqT : row;
+    const float rm = po.row_mask ? po.row_mask[row % po.mask_rows] : 1.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
@@ -74,8 +110,37 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
         if (relu) {
           o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
+        if (po.row_mask) { o.x *= rm; o.y *= rm; o.z *= rm; o.w *= rm; }
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         *reinterpret_cast<float4*>(yr + c) = o;
+        if (PLANES) {
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          const float xs[4] = {o.x * fs, o.y * fs, o.z * fs, o.w * fs};      // exact (power of two)
+          h4 h0, h1;
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) { h0[e4] = (_Float16)xs[e4]; h1[e4] = (_Float16)(xs[e4] - (float)h0[e4]); }
+          *reinterpret_cast<h4*>(po.p0 + orow * C + c) = h0;
+          *reinterpret_cast<h4*>(po.p0 + po.plane_stride + orow * C + c) = h1;
+        }
+      }
+    }
+  }
+  if (PLANES) {        // the planes' zero rows: below the last row (natural), around every sequence and below the last one (image)
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    const long first = po.seqT ? 0 : rows, nseq = po.seqT ? rows / po.seqT : 0;
+    for (long pr = first + wid; pr < po.rows_out; pr += wstride) {
+      if (po.seqT) {
+        const long q = pr % (po.seqT + 2);
+        if (pr < nseq * (po.seqT + 2) && q != 0 && q != po.seqT + 1) continue;
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (FULL || c < C) {
+          *reinterpret_cast<h4*>(po.p0 + pr * C + c) = z;
+          *reinterpret_cast<h4*>(po.p0 + po.plane_stride + pr * C + c) = z;
+        }
       }
     }
   }
@@ -236,8 +301,8 @@ void vilco_reduce_rows(const float* ws, float* out0, float* out1, int nrows, int
 }
 
 #define LN_CASE(N_, KERNEL, ...)                                                                              \
-  if (C == (N_) * 256) hipLaunchKernelGGL((KERNEL<N_, true>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__);      \
-  else hipLaunchKernelGGL((KERNEL<N_, false>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__);                      \
+  if (C == (N_) * 256) hipLaunchKernelGGL((KERNEL<N_, true, LN_PLANES_>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__);      \
+  else hipLaunchKernelGGL((KERNEL<N_, false, LN_PLANES_>), grid, dim3(LN_THREADS), 0, s, __VA_ARGS__);                      \
   break;
 #define LN_DISPATCH(NVV, KERNEL, ...)                                                   \
   switch (NVV) {                                                                        \
@@ -280,17 +345,54 @@ extern "C" int vilco_layernorm_fwd(const float* x, const float* gamma, const flo
 extern "C" int vilco_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y,
                                         float* mean, float* rstd, int64_t rows, int32_t C, float eps,
                                         int32_t relu, float* amax_parts, int32_t* n_parts, void* stream) {
+  return vilco_layernorm_fwd_planes(x, gamma, beta, y, mean, rstd, rows, C, eps, relu, amax_parts, n_parts, nullptr, 0, 0, nullptr, 0,
+                                    stream);
+}
+
+extern "C" size_t vilco_layernorm_planes_bytes(int64_t rows, int32_t C, int32_t seq_len) {
+  if (rows <= 0 || C <= 0) return 0;
+  if (seq_len > 0) return (size_t)(VILCO_PACK_HDR + (vilco_tap_plane_rows(rows / seq_len, seq_len) * C + 7) / 8 * 8 * 4);
+  return (size_t)(VILCO_PACK_HDR + (rows + 31) / 32 * 32 * (long)C * 4);
+}
+
+extern "C" int vilco_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, float* y,
+                                          float* mean, float* rstd, int64_t rows, int32_t C, float eps,
+                                          int32_t relu, float* amax_parts, int32_t* n_parts, void* planes, size_t planes_bytes,
+                                          int32_t seq_len, const float* row_mask, int64_t mask_rows, void* stream) {
   if (!x || !y || rows < 0 || C <= 0) return VILCO_ERR_BADARG;
   if (n_parts) *n_parts = 0;
   if (rows == 0) return VILCO_OK;
   if ((C % 4) != 0 || C > 4096) return VILCO_ERR_UNSUPPORTED;
   if (!vilco_aligned(x, 16) || !vilco_aligned(y, 16)) return VILCO_ERR_BADARG;
+  if (row_mask && mask_rows <= 0) return VILCO_ERR_BADARG;
+  LnPlanes po = {nullptr, 0, nullptr, 0, 0, row_mask, (long)mask_rows};
+  if (planes) {
+    // natural rows need C % 32 == 0 (no column padding); the convs' image C % 8 == 0 and whole sequences
+    if (seq_len < 0 || !vilco_aligned(planes, 256)) return VILCO_ERR_BADARG;
+    if (seq_len > 0 ? ((C % 8) != 0 || (rows % seq_len) != 0) : (C % 32) != 0) return VILCO_ERR_UNSUPPORTED;
+    if (planes_bytes < vilco_layernorm_planes_bytes(rows, C, seq_len)) return VILCO_ERR_WORKSPACE;
+    unsigned char* u = reinterpret_cast<unsigned char*>(planes);
+    po.p0 = reinterpret_cast<_Float16*>(u + VILCO_PACK_HDR);
+    po.rows_out = seq_len > 0 ? vilco_tap_plane_rows(rows / seq_len, seq_len) : (rows + 31) / 32 * 32;
+    po.plane_stride = seq_len > 0 ? (po.rows_out * C + 7) / 8 * 8 : po.rows_out * (long)C;
+    po.inv_scale = reinterpret_cast<float*>(u) + VILCO_AMAX_MAX_BLOCKS;
+    po.seqT = seq_len;
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int nv = (C + 255) / 256;
   dim3 grid(ln_blocks(rows, 2048));
   if (amax_parts && n_parts) *n_parts = (int32_t)grid.x;
-  LN_DISPATCH(nv, ln_fwd_kernel, x, gamma, beta, y, mean, rstd, (long)rows, (int)C, eps, (int)relu,
-              (amax_parts && n_parts) ? amax_parts : nullptr)
+  if (planes) {
+#define LN_PLANES_ true
+    LN_DISPATCH(nv, ln_fwd_kernel, x, gamma, beta, y, mean, rstd, (long)rows, (int)C, eps, (int)relu,
+                (amax_parts && n_parts) ? amax_parts : nullptr, po)
+#undef LN_PLANES_
+  } else {
+#define LN_PLANES_ false
+    LN_DISPATCH(nv, ln_fwd_kernel, x, gamma, beta, y, mean, rstd, (long)rows, (int)C, eps, (int)relu,
+                (amax_parts && n_parts) ? amax_parts : nullptr, po)
+#undef LN_PLANES_
+  }
   return vilco_launch_status();
 }
 

@@ -107,17 +107,28 @@ class ConvTransformerBackbone(nn.Module):
             torch.nn.init.constant_(module.bias, 0.)
 
     @staticmethod
-    def _conv_ln_relu(conv, norm, x, lens):
+    def _next_planes(convs, i):
+        """the operand-plane layout the conv after convs[i] reads its input in (hint for ops.layernorm), or None"""
+        if i + 1 >= len(convs):
+            return None
+        c = convs[i + 1]
+        if c.conv.groups != 1 or c.stride != 1:
+            return None
+        return {1: "nat", 3: "seq"}.get(c.conv.kernel_size[0])
+
+    @staticmethod
+    def _conv_ln_relu(conv, norm, x, lens, planes=None):
+        """planes: the layout of the output's operand planes when it goes straight into another conv (ops.layernorm)"""
         x, lens = conv.forward_tm(x, lens)
         if isinstance(norm, LayerNorm):
-            return norm.forward_tm(x, relu=True), lens
+            return norm.forward_tm(x, relu=True, planes=planes), lens
         return torch.relu(x), lens
 
     def forward_tm(self, x, lens, text=None, text_lens=None):
         """x [B,T,Cin] token-major, lens int32 [B]; text [B,L,Ctxt] -> lists of feats_tm / lens per level."""
         B, T, _ = x.shape
-        for conv, norm in zip(self.embd, self.embd_norm):
-            x, lens = self._conv_ln_relu(conv, norm, x, lens)
+        for i, (conv, norm) in enumerate(zip(self.embd, self.embd_norm)):
+            x, lens = self._conv_ln_relu(conv, norm, x, lens, self._next_planes(self.embd, i))
 
         if self.use_abs_pe:
             if self.training or T < self.max_len:
@@ -143,8 +154,8 @@ class ConvTransformerBackbone(nn.Module):
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):
                 q, q_lens = text, text_lens
-                for conv, norm in zip(self.txt_embd, self.txt_embd_norm):
-                    q, q_lens = self._conv_ln_relu(conv, norm, q, q_lens)
+                for i, (conv, norm) in enumerate(zip(self.txt_embd, self.txt_embd_norm)):
+                    q, q_lens = self._conv_ln_relu(conv, norm, q, q_lens, self._next_planes(self.txt_embd, i))
                 for blk in self.txt_stem:
                     q, q_lens = blk.forward_tm(q, q_lens)
 

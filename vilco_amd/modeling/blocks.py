@@ -146,9 +146,10 @@ class LayerNorm(nn.Module):
             self.register_parameter('weight', None)
             self.register_parameter('bias', None)
 
-    def forward_tm(self, x, relu=False):
+    def forward_tm(self, x, relu=False, planes=None, row_mask=None):
+        """planes: "nat" / "seq" when the output goes straight into a Linear / a k=3 conv; row_mask: see ops.layernorm"""
         assert x.shape[-1] == self.num_channels
-        return ops.layernorm(x, self.weight, self.bias, self.eps, relu)
+        return ops.layernorm(x, self.weight, self.bias, self.eps, relu, planes, row_mask)
 
     def forward(self, x):
         assert x.dim() == 3 and x.shape[1] == self.num_channels
@@ -253,11 +254,11 @@ class MaskedMHCA(nn.Module):
 
     def forward_tm(self, x, lens):
         q, q_lens = self.query_conv.forward_tm(x, lens)
-        q = self.query_norm.forward_tm(q)
+        q = self.query_norm.forward_tm(q, planes="nat")          # (each goes straight into its projection)
         k, kv_lens = self.key_conv.forward_tm(x, lens)
-        k = self.key_norm.forward_tm(k)
+        k = self.key_norm.forward_tm(k, planes="nat")
         v, _ = self.value_conv.forward_tm(x, lens)
-        v = self.value_norm.forward_tm(v)
+        v = self.value_norm.forward_tm(v, planes="nat")
         return self._attend(q, k, v, q_lens, kv_lens)
 
     def _attend(self, q, k, v, q_lens, kv_lens):
@@ -333,7 +334,7 @@ class ChannelBlock(nn.Module):
         cur = self.attn(x)
         x = ops.scale_add(x, cur, None, self._dp(x))
         if self.ffn:
-            h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            h = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, planes="nat")
             h = ops.linear(h, self.mlp[0].weight, self.mlp[0].bias, ACT_GELU)
             h = ops.linear(h, self.mlp[2].weight, self.mlp[2].bias)
             x = ops.scale_add(x, h, None, self._dp(x))
@@ -437,13 +438,13 @@ class TransformerBlock(nn.Module):
         cs, rs = self._dp(self.drop_path_attn, a)
         out = ops.scale_add(skip, a, cs, rs, out_lens, mask_a=True)
         if self.use_cross_modal and cross_y is not None:
-            c, _ = self.cross_attn.forward_tm(self.ln3.forward_tm(out), out_lens,
-                                              self.ln3.forward_tm(cross_y), cross_lens)
+            c, _ = self.cross_attn.forward_tm(self.ln3.forward_tm(out, planes="nat"), out_lens,
+                                              self.ln3.forward_tm(cross_y, planes="nat"), cross_lens)
             cs, rs = self._dp(self.drop_path_attn, c)
             out = ops.scale_add(out, c, cs, rs, out_lens, mask_a=True)
         T2 = out.shape[1]
         tr = self.training                                                              # mlp dropouts: blocks.py:533-540
-        m = ops.linear(self.ln2.forward_tm(out), self.mlp[0].weight, self.mlp[0].bias, ACT_GELU,
+        m = ops.linear(self.ln2.forward_tm(out, planes="nat"), self.mlp[0].weight, self.mlp[0].bias, ACT_GELU,
                        drop_p=self.mlp[2].p if tr else 0.0, drop_site="mlp_drop")
         m = ops.linear(m, self.mlp[3].weight, self.mlp[3].bias, ACT_NONE, out_lens, T2,
                        drop_p=self.mlp[4].p if tr else 0.0, drop_site="mlp_drop")

@@ -149,11 +149,8 @@ class _ConvHead(nn.Module):
         for conv, norm in zip(self.head, self.norm):
             x = self._conv_cat(conv, x, cat)
             if isinstance(norm, LayerNorm):
-                y = norm.forward_tm(x, relu=True)
-                x = y * cat.notgap
-                parts, n = ops._amax_of(y)          # zeroing the separator rows can only lower max|x|: the LayerNorm kernel's
-                if parts is not None:               # partials stay a valid (and in practice exact) scale for the next conv's pack
-                    ops._tag_amax(x, parts, n)
+                # the separator rows are zeroed by the LayerNorm kernel itself, which also writes the next conv's operand image
+                x = norm.forward_tm(x, relu=True, planes="seq", row_mask=cat.notgap)
             else:
                 x = torch.relu(x)
         return x

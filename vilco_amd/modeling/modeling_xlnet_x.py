@@ -70,7 +70,7 @@ class XLNetRelativeAttention(nn.Module):
         C = self.n_head * self.d_head
         out = ops.linear(vec, self.o.view(self.d_model, C), drop_p=p, drop_site="xl_attn_out")   # einsum("ibnd,hnd->ibh") + dropout (:327)
         out = ops.axpby(out, h, 1.0, 1.0)
-        return ops.layernorm(out, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return ops.layernorm(out, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, planes="nat")   # -> layer_1
 
 
 class XLNetFeedForward(nn.Module):
@@ -89,7 +89,7 @@ class XLNetFeedForward(nn.Module):
         y = ops.linear(x, self.layer_1.weight, self.layer_1.bias, ACT_GELU, drop_p=p, drop_site="xl_ff_inner")   # (:486)
         y = ops.linear(y, self.layer_2.weight, self.layer_2.bias, drop_p=p, drop_site="xl_ff_out")              # (:488)
         y = ops.axpby(y, x, 1.0, 1.0)
-        return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return ops.layernorm(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps, planes="nat")   # -> the next layer's q / k / v
 
 
 class XLNetLayer(nn.Module):

@@ -543,6 +543,7 @@ def weight_planes(w, rows, cols):
 # (vilco_act_bwd_planes: scale from a bound on max|dz|, no pack launch, no fp32 dz) when dy carries its producer's amax partials.
 # VILCO_PRODUCER_PLANES=0: fp32 dz + pack, as before.
 producer_planes = os.environ.get("VILCO_PRODUCER_PLANES", "1") != "0"
+ln_planes = os.environ.get("VILCO_LN_PLANES", "1") != "0"          # the LayerNorm half of it (ops.layernorm(planes=...))
 
 
 def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None, planes=False):
@@ -809,10 +810,12 @@ def conv3(x, w, b=None, lens=None):
 # ---------------------------------------------------------------------------------------- LayerNorm
 class _LayerNorm(torch.autograd.Function):
     last_amax = (None, 0)
+    last_planes = None
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
-        _chk(x, gamma, beta)
+    def forward(ctx, x, gamma, beta, eps, relu, planes=None, row_mask=None):
+        _chk(x, gamma, beta, row_mask)
+        assert row_mask is None or relu, "row_mask: the backward kernel drops masked rows through the ReLU test on the saved output"
         lib = _lib.load()
         Cn = x.shape[-1]
         rows = x.numel() // Cn
@@ -821,12 +824,22 @@ class _LayerNorm(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         parts = torch.empty(AMAX_PARTS, dtype=torch.float32, device=x.device) if (produce_amax and _precision == 3) else None
         n = C.c_int32(0)
-        _lib.check(lib.vilco_layernorm_fwd_amax(x.data_ptr(), _p(gamma), _p(beta), y.data_ptr(),
-                                                mean.data_ptr(), rstd.data_ptr(), rows, Cn, eps,
-                                                int(relu), _p(parts), C.byref(n), _stream()))
+        # planes: "nat" / "seq" -- the caller knows y goes into a Linear / a k=3 conv: the kernel writes its operand planes too
+        seq = int(x.shape[-2]) if planes == "seq" else 0
+        ok = (planes in ("nat", "seq") and producer_planes and ln_planes and _pack_cache and _reuse_packs and _precision == 3 and rows > 0 and
+              (Cn % 8 == 0 and x.dim() == 3 and conv_tap_planes if seq else Cn % 32 == 0))
+        buf = None
+        if ok:
+            nbytes = lib.vilco_layernorm_planes_bytes(rows, Cn, seq)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.vilco_layernorm_fwd_planes(x.data_ptr(), _p(gamma), _p(beta), y.data_ptr(),
+                                                  mean.data_ptr(), rstd.data_ptr(), rows, Cn, eps,
+                                                  int(relu), _p(parts), C.byref(n), _p(buf), buf.numel() if buf is not None else 0,
+                                                  seq, _p(row_mask), row_mask.numel() if row_mask is not None else 0, _stream()))
         ctx.relu = bool(relu)
         ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
         _LayerNorm.last_amax = (parts, n.value)          # picked up by `layernorm` (attributes set here do not survive apply)
+        _LayerNorm.last_planes = (buf, seq, _cache_mark()) if buf is not None else None
         return y
 
     @staticmethod
@@ -846,14 +859,26 @@ class _LayerNorm(torch.autograd.Function):
                                                dg.data_ptr(), db.data_ptr(), rows, Cn, int(ctx.relu),
                                                ws.data_ptr(), ws.numel(), _stream()))
             dfr.hold(dg, db)
-        return dx, dg.view_as(gamma), db.view_as(gamma), None, None
+        return dx, dg.view_as(gamma), db.view_as(gamma), None, None, None, None
 
 
-def layernorm(x, gamma, beta, eps=1e-5, relu=False):
-    """gamma/beta may have the reference's [1,C,1] shape (blocks.py:152-155) or [C]."""
-    y = _LayerNorm.apply(x, gamma, beta, float(eps), bool(relu))
+def layernorm(x, gamma, beta, eps=1e-5, relu=False, planes=None, row_mask=None):
+    """gamma/beta may have the reference's [1,C,1] shape (blocks.py:152-155) or [C].
+    planes: "nat" when y feeds a Linear, "seq" when it feeds a k=3 conv -- the kernel then writes y's operand planes as well
+    (vilco_layernorm_fwd_planes) and the consumer's `pack` / `pack_tap` finds them on the tensor.
+    row_mask (relu only): a contiguous 0 / 1 float mask over the token rows, repeated over the batch -- y[b, t] *= row_mask[t]."""
+    _LayerNorm.last_planes = None
+    y = _LayerNorm.apply(x, gamma, beta, float(eps), bool(relu), planes, row_mask)
     parts, n = _LayerNorm.last_amax
     _LayerNorm.last_amax = (None, 0)
+    made, _LayerNorm.last_planes = _LayerNorm.last_planes, None
+    if made is not None:
+        buf, seq, mark = made
+        Cn = y.shape[-1]
+        if seq:
+            y._vilco_tap_planes = (buf, ("tap", int(y.shape[0]), int(y.shape[1]), int(Cn), 3, y._version), mark)
+        else:
+            y._vilco_planes = (buf, (int(y.numel() // Cn), int(Cn), 3, y._version), mark)
     return _tag_amax(y, parts, n) if parts is not None else y
 
 
@@ -953,13 +978,19 @@ class _ScaleAdd(torch.autograd.Function):
         db = dout if plain_b else (torch.empty_like(b) if need_b else None)
         dcs = torch.empty(Cn, dtype=torch.float32, device=b.device) if need_cs else None
         if (need_a and not plain_a) or (need_b and not plain_b) or need_cs:
+            # (db goes up the residual branch into its last layer's backward: its max|db| partials ride along, see _act_bwd)
+            parts = (torch.empty(AMAX_PARTS, dtype=torch.float32, device=b.device)
+                     if (need_b and not plain_b and produce_amax and producer_planes and _precision == 3) else None)
+            n = C.c_int32(0)
             with _Deferring(colscale if need_cs else None) as dfr:
                 ws = _ws(lib.vilco_colsum_workspace(B * T, Cn), b.device) if need_cs else None
-                _lib.check(lib.vilco_scale_add_bwd(
+                _lib.check(lib.vilco_scale_add_bwd_amax(
                     dout.data_ptr(), b.data_ptr(), _p(colscale), _p(rowscale), _p(lens), ctx.mask_a,
                     None if plain_a else _p(da), None if plain_b else _p(db), _p(dcs), B, T, Cn, _p(ws),
-                    ws.numel() if ws is not None else 0, _stream()))
+                    ws.numel() if ws is not None else 0, _p(parts), C.byref(n), _stream()))
                 dfr.hold(dcs)
+            if parts is not None:
+                _tag_amax(db, parts, n.value)
         return da, db, (dcs.view_as(colscale) if need_cs else None), None, None, None
 
 
