@@ -833,3 +833,4 @@ def test_layernorm_row_mask_equals_masking_afterwards(dev):
     for a, c in zip(*res):
         assert torch.equal(a, c) or rel(a, c) < 1e-6
     assert float((res[0][0] * (1 - mask)).abs().max()) == 0.0
+
