@@ -119,6 +119,10 @@ typedef struct vilco_gemm_desc {
   /* tap_operand = TAP_A: a_planes (tapC % 8 == 0);  TAP_B (the weight gradient, M % 8 == 0, tapC % 8 == 0): BOTH operands, */
   /* a_planes = the image of dZ [K rows of width M], b_planes = the image of the conv input [K rows of width tapC].          */
   int32_t a_planes_seq, b_planes_seq;
+  /* optional: one float per output row m (M floats, one batch element only): rows with row_mask[m] == 0 are zeroed exactly as */
+  /* rows beyond row_len are -- a validity pattern that is not "the first len rows of every sequence" (the heads over the        */
+  /* concatenated pyramid levels: per level, per clip; meta_archs.py:216-235 applies mask[level] after every conv)               */
+  const float* row_mask;
 } vilco_gemm_desc;
 
 size_t vilco_gemm_workspace(const vilco_gemm_desc* d);
@@ -362,7 +366,8 @@ int vilco_act_bwd_amax(const float* dy, const float* aux, float* dz, float* dbia
 int vilco_act_bwd_planes(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
                          const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p, uint32_t drop_seed,
                          void* workspace, size_t workspace_bytes, float* amax_parts, int32_t* n_parts,
-                         const float* dy_amax, int32_t n_dy_amax, void* planes, size_t planes_bytes, void* stream);
+                         const float* dy_amax, int32_t n_dy_amax, void* planes, size_t planes_bytes,
+                         const float* row_mask, void* stream);      /* row_mask: as vilco_gemm_desc.row_mask (rows floats) or NULL */
 /* out[c] = sum_r x[r][c] */
 int vilco_colsum(const float* x, float* out, int64_t rows, int32_t C, void* workspace,
                  size_t workspace_bytes, void* stream);

@@ -834,3 +834,23 @@ def test_layernorm_row_mask_equals_masking_afterwards(dev):
         assert torch.equal(a, c) or rel(a, c) < 1e-6
     assert float((res[0][0] * (1 - mask)).abs().max()) == 0.0
 
+
+
+def test_conv3_row_mask_equals_masking_afterwards(dev):
+    """vilco_gemm_desc.row_mask / vilco_act_bwd_planes(row_mask): a k=3 conv whose output rows are zeroed by a per-row 0 / 1 mask in
+    the GEMM epilogue == the conv followed by the multiply, forward and all three gradients"""
+    from vilco_amd import ops
+    torch.manual_seed(21)
+    B, T, Cin, Cout = 2, 70, 64, 48
+    mask = (torch.rand(B, T, 1, device=dev) > 0.3).float().contiguous()
+    x0, w0, b0 = torch.randn(B, T, Cin, device=dev), torch.randn(Cout, Cin, 3, device=dev) / 8, torch.randn(Cout, device=dev)
+    dy = torch.randn(B, T, Cout, device=dev)
+    res = []
+    for fused in (True, False):
+        x, w, b = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = ops.conv3(x, w, b, None, row_mask=mask) if fused else ops.conv3(x, w, b, None) * mask
+        y.backward(dy)
+        res.append((y.detach(), x.grad, w.grad, b.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, c in zip(*res):
+        assert rel(a, c) < 2e-6

@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("amax_out", c_fp),
         ("a_amax", c_fp), ("a_namax", i32), ("b_amax", c_fp), ("b_namax", i32),
         ("a_planes_seq", i32), ("b_planes_seq", i32),
+        ("row_mask", c_fp),
     ]
 
 
@@ -125,7 +126,7 @@ SIGNATURES = {
     "vilco_act_bwd_amax": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp,
                                      C.POINTER(i32), c_fp]),
     "vilco_act_bwd_planes": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp,
-                                       C.POINTER(i32), c_fp, i32, c_fp, sz, c_fp]),
+                                       C.POINTER(i32), c_fp, i32, c_fp, sz, c_fp, c_fp]),
     "vilco_colsum": (C.c_int, [c_fp, c_fp, i64, i32, c_fp, sz, c_fp]),
     "vilco_mask_rows": (C.c_int, [c_fp, c_fp, i32, i32, i32, c_fp]),
     "vilco_add_pe": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),

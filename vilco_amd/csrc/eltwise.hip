@@ -228,7 +228,8 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ dz,
     float* __restrict__ ws, int act, const int* __restrict__ len, int T, long rows, int C,
     int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, float drop_inv_keep, float* __restrict__ dbias,
-    unsigned* sync, float* __restrict__ amax_parts, const uint32_t* __restrict__ seed_word, PlaneOut po) {
+    unsigned* sync, float* __restrict__ amax_parts, const uint32_t* __restrict__ seed_word, PlaneOut po,
+    const float* __restrict__ row_mask) {
   if (drop_thresh) drop_seed = vilco_step_seed(drop_seed, seed_word);
   __shared__ float amax_red[EW_THREADS / 64];
   float amax = 0.f;          // max |dz| of this block: dz goes straight into an operand pack
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     auto one = [&](long r, float g, float ax) {
       if (drop_thresh) g = vilco_drop_hash(drop_seed, (uint64_t)(r * C + c)) >= drop_thresh ? g * drop_inv_keep : 0.f;
       if (len && (int)(r % T) >= len[r / T]) g = 0.f;
+      if (row_mask && row_mask[r] == 0.f) g = 0.f;
       if (act == VILCO_ACT_RELU) g = (ax > 0.f) ? g : 0.f;
       else if (act == VILCO_ACT_GELU) g *= gelu_grad_f(ax);
       if (!PLANES || dz) dz[r * C + c] = g;
@@ -521,14 +523,14 @@ extern "C" int vilco_act_bwd_amax(const float* dy, const float* aux, float* dz, 
                                   uint32_t drop_seed, void* workspace, size_t workspace_bytes, float* amax_parts,
                                   int32_t* n_parts, void* stream) {
   return vilco_act_bwd_planes(dy, aux, dz, dbias, act, len, T, rows, C, drop_p, drop_seed, workspace, workspace_bytes, amax_parts,
-                              n_parts, nullptr, 0, nullptr, 0, stream);
+                              n_parts, nullptr, 0, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int vilco_act_bwd_planes(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
                                     const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p,
                                     uint32_t drop_seed, void* workspace, size_t workspace_bytes, float* amax_parts,
                                     int32_t* n_parts, const float* dy_amax, int32_t n_dy_amax, void* planes, size_t planes_bytes,
-                                    void* stream) {
+                                    const float* row_mask, void* stream) {
   if (n_parts) *n_parts = 0;
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (!dy || (!dz && !planes) || rows < 0 || C <= 0 || act < 0 || act > 2) return VILCO_ERR_BADARG;
@@ -560,11 +562,11 @@ extern "C" int vilco_act_bwd_planes(const float* dy, const float* aux, float* dz
   if (planes)
     hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
                        (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,
-                       emit ? amax_parts : nullptr, vilco_seed_word_dev(), po);
+                       emit ? amax_parts : nullptr, vilco_seed_word_dev(), po, row_mask);
   else
     hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
                        (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,
-                       emit ? amax_parts : nullptr, vilco_seed_word_dev(), po);
+                       emit ? amax_parts : nullptr, vilco_seed_word_dev(), po, row_mask);
   if (dbias && !sync) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }

@@ -45,6 +45,7 @@ struct Epi {
   const float* colscale;
   const float* residual;
   int res_masked;
+  const float* row_mask;
 };
 
 struct PlaneOp {
@@ -685,7 +686,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[idx + e] = v[e];
       } else {
-        const bool valid = g.e.row_len ? (m % g.e.rowT) < g.e.row_len[m / g.e.rowT] : true;
+        bool valid = g.e.row_len ? (m % g.e.rowT) < g.e.row_len[m / g.e.rowT] : true;
+        if (g.e.row_mask) valid = valid && g.e.row_mask[m] != 0.f;
         if (g.vec_out) am = fmaxf(am, store_out4(g, idx, n, v, valid));
         else
 #pragma unroll
@@ -728,6 +730,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
     const long idx = zo * g.sCo + zi * g.sCi + (long)m * g.ldc + n;
     bool valid = true;
     if (g.e.row_len) valid = (m % g.e.rowT) < g.e.row_len[m / g.e.rowT];
+    if (g.e.row_mask) valid = valid && g.e.row_mask[m] != 0.f;
     if (VEC) {
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
       int k = 0;
@@ -1175,6 +1178,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (!(d->drop_p >= 0.f) || d->drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (d->drop_p > 0.f && (d->ldc != d->N || d->batch_outer != 1 || d->batch_inner != 1)) return VILCO_ERR_UNSUPPORTED;
   if (d->row_len && d->rowT <= 0) return VILCO_ERR_BADARG;
+  if (d->row_mask && (d->batch_outer != 1 || d->batch_inner != 1)) return VILCO_ERR_UNSUPPORTED;
   if (d->a_kcontig == 0 && d->b_kcontig == 1) return VILCO_ERR_UNSUPPORTED;  // "TT" is never needed
   if (d->tap_operand != VILCO_TAP_NONE) {
     if (d->tapC <= 0 || d->tapT <= 0) return VILCO_ERR_BADARG;
@@ -1318,7 +1322,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   }
   g.amax_out = d->band == 1 ? nullptr : d->amax_out;
   g.e = Epi{d->alpha, d->beta, d->bias, d->preact, d->act, d->row_len, d->rowT, d->colscale, d->residual,
-            d->res_masked};
+            d->res_masked, d->row_mask};
   const int nz = d->batch_outer * d->batch_inner;
   dim3 grid(g.ntiles, p.ksplit, nz);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1354,7 +1358,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     prof().rec.push_back(ProfRec{{d->M, d->N, d->K, nz, p.BM, p.ksplit, d->precision, p.a_km, p.b_km, p.a_tap | (p.b_tap << 4)}});
   }
   if (p.ksplit > 1 && !p.fixup && vilco_defer_active() && nz == 1 && d->alpha == 1.f && d->beta == 0.f && !d->bias &&
-      !d->preact && d->act == VILCO_ACT_NONE && !d->row_len && !d->colscale && !d->residual && d->drop_p == 0.f &&
+      !d->preact && d->act == VILCO_ACT_NONE && !d->row_len && !d->row_mask && !d->colscale && !d->residual && d->drop_p == 0.f &&
       !d->amax_out) {
     // a plain sum of the split slabs whose result nothing reads before the end of backward (a weight gradient): recorded
     vilco_defer_push_sk(g.c, g.cfinal, g.split_stride, g.ldc, d->M, d->N, p.ksplit);

@@ -143,7 +143,9 @@ class _ConvHead(nn.Module):
     def _conv_cat(self, conv, x, cat):
         c = conv.conv
         assert c.kernel_size[0] == 3 and conv.stride == 1 and c.groups == 1
-        return ops.conv3(x, c.weight, c.bias, None) * cat.valid
+        if not _HEAD_ROWMASK:                        # (A/B: the mask as a separate multiply, as up to round 3)
+            return ops.conv3(x, c.weight, c.bias, None) * cat.valid
+        return ops.conv3(x, c.weight, c.bias, None, row_mask=cat.valid)          # output rows masked in the GEMM epilogue
 
     def _trunk_cat(self, x, cat):
         for conv, norm in zip(self.head, self.norm):
@@ -158,6 +160,9 @@ class _ConvHead(nn.Module):
     @staticmethod
     def can_cat(heads):
         return all(m.conv.kernel_size[0] == 3 and m.stride == 1 and m.conv.groups == 1 for m in heads)
+
+
+_HEAD_ROWMASK = os.environ.get("VILCO_HEAD_ROWMASK", "1") != "0"
 
 
 class LevelCat:

@@ -297,7 +297,7 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
          sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
          bias=None, preact=None, act=ACT_NONE, row_len=None, rowT=0, colscale=None, residual=None,
          res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0, drop=(0.0, 0), want_amax=False,
-         a_amax=None, b_amax=None, planes_seq=(False, False)):
+         a_amax=None, b_amax=None, planes_seq=(False, False), row_mask=None):
     """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements.  a_planes / b_planes: operands
     already packed by `pack` (the fp32 tensor may then be None).  want_amax: the call writes ALL of Cc, which goes on
     into another product -- the kernel leaves max|C| partials and Cc is tagged with them (`_tag_amax`)."""
@@ -324,6 +324,7 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
     d.preact = None if preact is None else preact.data_ptr() + 4 * offC
     d.act = int(act)
     d.row_len = _p(row_len)
+    d.row_mask = _p(row_mask)            # one float per output row: rows with 0 are zeroed like rows beyond row_len
     d.rowT = int(rowT)
     d.colscale = _p(colscale)
     d.residual = None if residual is None else residual.data_ptr() + 4 * offC
@@ -546,7 +547,7 @@ producer_planes = os.environ.get("VILCO_PRODUCER_PLANES", "1") != "0"
 ln_planes = os.environ.get("VILCO_LN_PLANES", "1") != "0"          # the LayerNorm half of it (ops.layernorm(planes=...))
 
 
-def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None, planes=False):
+def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None, planes=False, row_mask=None):
     """dz = dropmask(dy) * act'(aux) * rowmask, optional column sums -> (dz, dbias).  bias_param: the parameter dbias is the
     gradient of (its column sum may then finish with the other deferred reductions, see _Deferring).
     planes=True -> (dz or None, dbias, operand planes of dz or None): when the planes come back, dz was never written."""
@@ -564,13 +565,13 @@ def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None, p
         parts = torch.empty(AMAX_PARTS, dtype=torch.float32, device=dy.device) if (produce_amax and _precision == 3 and pz is None) else None
         n = C.c_int32(0)
         if pz is None:
-            _lib.check(lib.vilco_act_bwd_amax(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
-                                              int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
-                                              _p(parts), C.byref(n), _stream()))
+            _lib.check(lib.vilco_act_bwd_planes(dy.data_ptr(), _p(aux), dz.data_ptr(), _p(db), act, _p(lens),
+                                                int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
+                                                _p(parts), C.byref(n), None, 0, None, 0, _p(row_mask), _stream()))
         else:
             _lib.check(lib.vilco_act_bwd_planes(dy.data_ptr(), _p(aux), None, _p(db), act, _p(lens),
                                                 int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
-                                                None, None, dy_parts.data_ptr(), int(dy_n), pz.data_ptr(), pz.numel(), _stream()))
+                                                None, None, dy_parts.data_ptr(), int(dy_n), pz.data_ptr(), pz.numel(), _p(row_mask), _stream()))
         dfr.hold(db)
     if parts is not None:
         _tag_amax(dz, parts, n.value)
@@ -752,8 +753,9 @@ class _Conv3(torch.autograd.Function):
     token rows (K = 3*Cin), no im2col buffer."""
 
     @staticmethod
-    def forward(ctx, x, w, b, lens):
-        _chk(x, w, b)
+    def forward(ctx, x, w, b, lens, row_mask=None):
+        _chk(x, w, b, row_mask)
+        assert row_mask is None or row_mask.numel() == x.shape[0] * x.shape[1]
         B, T, Cin = x.shape
         Cout = w.shape[0]
         assert w.shape[1] == Cin and w.shape[2] == 3
@@ -763,21 +765,22 @@ class _Conv3(torch.autograd.Function):
         # x in the convs' zero-padded image: packed once, read by this product and by the weight gradient in backward
         px = pack_tap(x) if (_reuse_packs and conv_tap_planes and pwp is not None and Cin % 8 == 0) else None
         gemm(x, wp, y, B * T, Cout, 3 * Cin, 1, 1, Cin, 3 * Cin, Cout, tap=TAP_A, tapC=Cin, tapT=T,
-             bias=b, row_len=lens, rowT=T, a_planes=px, b_planes=pwp, a_amax=_amax_of(x), planes_seq=(px is not None, False))
+             bias=b, row_len=lens, rowT=T, a_planes=px, b_planes=pwp, a_amax=_amax_of(x), planes_seq=(px is not None, False),
+             row_mask=row_mask)
         ctx.has_bias = b is not None
         ctx.prec = _precision
-        ctx.save_for_backward(x, w, lens, b, px)
+        ctx.save_for_backward(x, w, lens, b, px, row_mask)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, lens, b, px = ctx.saved_tensors
+        x, w, lens, b, px, row_mask = ctx.saved_tensors
         B, T, Cin = x.shape
         Cout = w.shape[0]
         dy = dy.contiguous()
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if lens is not None:
-            dz, db = _act_bwd(dy, None, ACT_NONE, lens, T, need_db, bias_param=b)
+        if lens is not None or row_mask is not None:
+            dz, db = _act_bwd(dy, None, ACT_NONE, lens, T, need_db, bias_param=b, row_mask=row_mask)
         else:
             dz, db = dy, (colsum(dy.view(B * T, Cout), param=b) if need_db else None)
         dx = dw = None
@@ -800,11 +803,13 @@ class _Conv3(torch.autograd.Function):
                     gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
                          tapT=T, precision=_dw_prec(_precision, B * T), a_amax=_amax_of(dz), b_amax=_amax_of(x))
                 dw = permute3(dwp, (Cout, Cin, 3), 0, (3 * Cin, 1, Cin), out=_grad_out(w))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def conv3(x, w, b=None, lens=None):
-    return _Conv3.apply(x, w, b, lens)
+def conv3(x, w, b=None, lens=None, row_mask=None):
+    """row_mask: one float per token row ([B, T] or [B, T, 1], contiguous); output rows whose entry is 0 are zeroed (and take no
+    gradient) -- the validity pattern of the heads over the concatenated pyramid levels, which `lens` cannot express"""
+    return _Conv3.apply(x, w, b, lens, row_mask)
 
 
 # ---------------------------------------------------------------------------------------- LayerNorm
