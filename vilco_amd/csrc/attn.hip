@@ -24,6 +24,7 @@
 // P^T / dS^T are packed stores: dV^T = dO^T P, dK^T = Q^T dS).  No atomics: results are bitwise reproducible.
 #include <type_traits>
 #include "common.h"
+#define VILCO_TU "attn"
 #include "pack.h"
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

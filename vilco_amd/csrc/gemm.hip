@@ -22,6 +22,7 @@
 #include <vector>
 #include <type_traits>
 #include "common.h"
+#define VILCO_TU "gemm"
 #include "pack.h"
 
 namespace {

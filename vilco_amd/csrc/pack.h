@@ -362,6 +362,10 @@ inline AmaxOp amax_view(const PackArgs& a, bool tr, int nbo, float* parts) {
 }
 
 inline void launch_amax(AmaxArgs& am, int nops, hipStream_t s) {
+  static const bool trace = getenv("VILCO_AMAX_TRACE") != nullptr;          // (diagnosis: which tensors still need a pass of their own)
+  if (trace)
+    for (int i = 0; i < nops; ++i)
+      fprintf(stderr, "amax_launch %s R=%d W=%d nb=%d\n", VILCO_TU, am.op[i].R, am.op[i].W, am.op[i].nbo * am.op[i].nbi);
   int gx = 1;
   for (int i = 0; i < nops; ++i) gx = am.op[i].nblocks > gx ? am.op[i].nblocks : gx;
   hipLaunchKernelGGL(amax_kernel, dim3(gx, nops), dim3(256), 0, s, am);

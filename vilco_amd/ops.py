@@ -1395,6 +1395,19 @@ def rel_attention(qw, qr, k, v, kr, kv_len, n_head, scale, drop_p=0.0):
     return _RelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale))
 
 
+_unit = {}
+
+
+def _unit_bound(device):
+    """(partials, count) saying max|x| <= 1: the scale bound of a softmax output"""
+    t = _unit.get(device)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():      # (never allocate a cached constant from a graph's private pool)
+            return (None, 0)
+        t = _unit[device] = torch.ones(1, dtype=torch.float32, device=device)
+    return (t, 1)
+
+
 class _ChannelAttn(torch.autograd.Function):
     """ChannelAttention core (blocks.py:426-434) on a fused qkv [B,T,3C]:
     A_h = softmax_rows(scale * k_h^T v_h)  [hd,hd];  out_h[t,:] = q_h[t,:] A_h^T."""
@@ -1409,12 +1422,15 @@ class _ChannelAttn(torch.autograd.Function):
         hd = Cn // H
         sQ = (T * C3, hd)
         A = torch.empty(B, H, hd, hd, dtype=torch.float32, device=qkv.device)
+        # operand scales without a pass over the operands: max|qkv| (left by the qkv projection's epilogue) bounds each of its
+        # three slices, a softmax output is bounded by 1
+        qa, one = _amax_of(qkv), _unit_bound(qkv.device)
         gemm(qkv, qkv, A, hd, hd, T, 0, 0, C3, C3, hd, batch=(B, H), sA=sQ, sB=sQ, sC=(H * hd * hd, hd * hd),
-             offA=Cn, offB=2 * Cn, alpha=scale)                                  # (k*scale)^T v
+             offA=Cn, offB=2 * Cn, alpha=scale, a_amax=qa, b_amax=qa)            # (k*scale)^T v
         _softmax_(A, None, B, H, hd, hd, MASK_NONE)
         out = torch.empty(B, T, Cn, dtype=torch.float32, device=qkv.device)
         gemm(qkv, A, out, T, hd, hd, 1, 1, C3, hd, Cn, batch=(B, H), sA=sQ, sB=(H * hd * hd, hd * hd),
-             sC=(T * Cn, hd), want_amax=True)                                    # q A^T (its output goes straight into proj)
+             sC=(T * Cn, hd), want_amax=True, a_amax=qa, b_amax=one)             # q A^T (its output goes straight into proj)
         _ChannelAttn.last_amax = _amax_of(out)          # picked up by `channel_attention` (attributes set here do not survive apply)
         ctx.H, ctx.scale = H, scale
         ctx.save_for_backward(qkv, A)
@@ -1435,17 +1451,18 @@ class _ChannelAttn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         # dq[t,e] = sum_d dout[t,d] A[d,e]                                   (NN)
         bp = ctx.bp                            # None: the ambient format (see _Linear.backward on bwd_precision)
-        gemm(dout, A, dqkv, T, hd, hd, 1, 0, Cn, hd, C3, batch=(B, H), sA=sO, sB=sA_, sC=sQ, precision=bp)
+        qa, da, one = _amax_of(qkv), _amax_of(dout), _unit_bound(qkv.device)      # (scales from bounds, as in forward)
+        gemm(dout, A, dqkv, T, hd, hd, 1, 0, Cn, hd, C3, batch=(B, H), sA=sO, sB=sA_, sC=sQ, precision=bp, a_amax=da, b_amax=one)
         # dA[d,e] = sum_t dout[t,d] q[t,e]                                   (TN)
         dA = torch.empty_like(A)
-        gemm(dout, qkv, dA, hd, hd, T, 0, 0, Cn, C3, hd, batch=(B, H), sA=sO, sB=sQ, sC=sA_, precision=bp)
+        gemm(dout, qkv, dA, hd, hd, T, 0, 0, Cn, C3, hd, batch=(B, H), sA=sO, sB=sQ, sC=sA_, precision=bp, a_amax=da, b_amax=qa)
         _lib.check(lib.vilco_softmax_bwd(dA.data_ptr(), A.data_ptr(), B, H, hd, hd, _stream()))
         # S[d,e] = scale * sum_t k[t,d] v[t,e]:  dk[t,d] = scale * sum_e v[t,e] dS[d,e]   (NT)
         gemm(qkv, dA, dqkv, T, hd, hd, 1, 1, C3, hd, C3, batch=(B, H), sA=sQ, sB=sA_, sC=sQ,
-             offA=2 * Cn, offC=Cn, alpha=scale, precision=bp)
+             offA=2 * Cn, offC=Cn, alpha=scale, precision=bp, a_amax=qa)
         # dv[t,e] = scale * sum_d k[t,d] dS[d,e]                                          (NN)
         gemm(qkv, dA, dqkv, T, hd, hd, 1, 0, C3, hd, C3, batch=(B, H), sA=sQ, sB=sA_, sC=sQ, offA=Cn,
-             offC=2 * Cn, alpha=scale, precision=bp)
+             offC=2 * Cn, alpha=scale, precision=bp, a_amax=qa)
         return dqkv, None, None, None
 
 
