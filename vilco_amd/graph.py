@@ -23,10 +23,14 @@ against host-side logits, narration SSL, BiC) fall back to the eager path.
 """
 import ctypes as C
 import gc
+import os
 
 import torch
 
 from . import _lib, ops
+
+
+_DP_REPLAY_SYNC = os.environ.get("VILCO_DP_REPLAY_SYNC", "1") != "0"
 
 
 class GraphedStep:
@@ -224,6 +228,11 @@ class GraphedStep:
         if self.reducer is not None and not ent.get('comm'):
             if ent['fill']:
                 torch._foreach_zero_(ent['fill'])
+            # The exchange reads what the replay writes, so it cannot start earlier anyway -- and a collective queued behind a
+            # graph that is still running has been seen to crawl: two replicas on one GPU over gloo, 6-10 s per step without
+            # this wait, 0.24 s with it (tools/lab/dp_replay_probe.py).  VILCO_DP_REPLAY_SYNC=0: enqueue behind the graph.
+            if _DP_REPLAY_SYNC:
+                torch.cuda.current_stream().synchronize()
             self.reducer.reduce_now()
         if self.between is not None:
             self.between()
