@@ -237,6 +237,9 @@ def dryrun_parts(dev, rank):
 
 
 def main():
+    if os.environ.get("VILCO_BENCH_WATCHDOG"):          # (diagnosis: dump every thread's stack after this many seconds, keep running)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VILCO_BENCH_WATCHDOG"]), repeat=False, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
