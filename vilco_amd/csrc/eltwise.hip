@@ -286,6 +286,104 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
                                 gridDim.x * gridDim.y);
 }
 
+// The same op, four columns per lane (C % 4 == 0, 16-byte aligned rows): a wave covers 256 columns of one row with one
+// 16-byte load per lane, the block's four waves take every fourth row of the block's row chunk, four rows of a wave in flight
+// (8 x 16 bytes per lane against the scalar kernel's 8 x 4).  Column sums: per-wave partials, combined through LDS in wave
+// order.  Planes go out as 8-byte stores (512 contiguous bytes per wave and row).
+template <bool PLANES>
+__global__ __launch_bounds__(EW_THREADS) void act_bwd_vec_kernel(
+    const float* __restrict__ dy, const float* __restrict__ aux, float* __restrict__ dz,
+    float* __restrict__ ws, int act, const int* __restrict__ len, int T, long rows, int C,
+    int rows_per_block, uint32_t drop_thresh, uint32_t drop_seed, float drop_inv_keep, float* __restrict__ dbias,
+    unsigned* sync, float* __restrict__ amax_parts, const uint32_t* __restrict__ seed_word, PlaneOut po,
+    const float* __restrict__ row_mask) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  if (drop_thresh) drop_seed = vilco_step_seed(drop_seed, seed_word);
+  __shared__ float amax_red[EW_THREADS / 64];
+  __shared__ float4 acc_red[EW_THREADS / 64][64];
+  float amax = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  const int c = blockIdx.y * 256 + lane * 4;
+  const bool col_ok = c < C;
+  float fs = 0.f;
+  if (PLANES) fs = plane_scale_from_bound(po, (blockIdx.x | blockIdx.y) == 0 && threadIdx.x == 0);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool has_aux = act == VILCO_ACT_RELU || act == VILCO_ACT_GELU;
+  auto one = [&](long r, float4 g4, float4 a4) {
+    float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float ax[4] = {a4.x, a4.y, a4.z, a4.w};
+    const bool row_off = (len && (int)(r % T) >= len[r / T]) || (row_mask && row_mask[r] == 0.f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (drop_thresh) g[e] = vilco_drop_hash(drop_seed, (uint64_t)(r * C + c + e)) >= drop_thresh ? g[e] * drop_inv_keep : 0.f;
+      if (row_off) g[e] = 0.f;
+      if (act == VILCO_ACT_RELU) g[e] = (ax[e] > 0.f) ? g[e] : 0.f;
+      else if (act == VILCO_ACT_GELU) g[e] *= gelu_grad_f(ax[e]);
+      amax = fmaxf(amax, fabsf(g[e]));
+    }
+    if (!PLANES || dz) *reinterpret_cast<float4*>(dz + r * C + c) = make_float4(g[0], g[1], g[2], g[3]);
+    if (PLANES) {
+      h4 h0, h1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xs = g[e] * fs;                      // exact (power of two)
+        h0[e] = (_Float16)xs;
+        h1[e] = (_Float16)(xs - (float)h0[e]);
+      }
+      *reinterpret_cast<h4*>(po.p0 + r * C + c) = h0;
+      *reinterpret_cast<h4*>(po.p0 + po.plane_stride + r * C + c) = h1;
+    }
+    acc.x += g[0]; acc.y += g[1]; acc.z += g[2]; acc.w += g[3];
+  };
+  if (col_ok) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    long r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {          // four rows of this wave in flight
+      float4 g[4], ax[4] = {z4, z4, z4, z4};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const float4*>(dy + (r + 4 * u) * C + c);
+      if (has_aux) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ax[u] = *reinterpret_cast<const float4*>(aux + (r + 4 * u) * C + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(r + 4 * u, g[u], ax[u]);
+    }
+    for (; r < r1; r += 4)
+      one(r, *reinterpret_cast<const float4*>(dy + r * C + c), has_aux ? *reinterpret_cast<const float4*>(aux + r * C + c) : z4);
+    if (PLANES && blockIdx.x == gridDim.x - 1) {          // the planes' zero rows (a k-major reader contracts over them)
+      const h4 hz = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      for (long rz = rows + wave; rz < po.rows32; rz += 4) {
+        *reinterpret_cast<h4*>(po.p0 + rz * C + c) = hz;
+        *reinterpret_cast<h4*>(po.p0 + po.plane_stride + rz * C + c) = hz;
+      }
+    }
+  }
+  if (ws) {                                  // column sums of the block: the four waves' partials in wave order
+    acc_red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col_ok) {
+      float4 t = acc_red[0][lane];
+#pragma unroll
+      for (int w = 1; w < EW_THREADS / 64; ++w) { const float4 u = acc_red[w][lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      float* o = ws + (long)blockIdx.x * C + c;
+      vilco_st_agent(o, t.x); vilco_st_agent(o + 1, t.y); vilco_st_agent(o + 2, t.z); vilco_st_agent(o + 3, t.w);
+    }
+  }
+  if (amax_parts) {
+    amax = wave_max(amax);
+    if (lane == 0) amax_red[wave] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      amax_parts[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
+  }
+  if (sync) vilco_finish_colsum(ws, dbias, nullptr, (int)gridDim.x, C, C, sync, blockIdx.y * gridDim.x + blockIdx.x,
+                                gridDim.x * gridDim.y);
+}
+
 __global__ __launch_bounds__(EW_THREADS) void colsum_partial_kernel(const float* __restrict__ x,
                                                                     float* __restrict__ ws, long rows,
                                                                     int C, int rows_per_block, float* __restrict__ out,
@@ -559,14 +657,16 @@ extern "C" int vilco_act_bwd_planes(const float* dy, const float* aux, float* dz
   unsigned* sync = (dbias && C <= 256 * VILCO_SYNC_MAX_BLOCKS) ? vilco_sync_counter(s, VILCO_SITE_COLSUM) : nullptr;
   const bool emit = amax_parts && n_parts;
   if (emit) *n_parts = nb * ((C + EW_THREADS - 1) / EW_THREADS);
-  if (planes)
-    hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
-                       (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,
-                       emit ? amax_parts : nullptr, vilco_seed_word_dev(), po, row_mask);
-  else
-    hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(nb, (C + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T,
-                       (long)rows, C, rpb, vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,
-                       emit ? amax_parts : nullptr, vilco_seed_word_dev(), po, row_mask);
+  static const bool vec_on = [] { const char* e = getenv("VILCO_ACT_BWD_VEC"); return !(e && e[0] == '0'); }();
+  const bool vec = vec_on && (C % 4) == 0 && vilco_aligned(dy, 16) && vilco_aligned(aux, 16) && vilco_aligned(dz, 16);
+  const dim3 grid(nb, (C + EW_THREADS - 1) / EW_THREADS);
+#define ACT_BWD_LAUNCH(K)                                                                                                        \
+  hipLaunchKernelGGL(K, grid, dim3(EW_THREADS), 0, s, dy, aux, dz, ws, act, len, T, (long)rows, C, rpb,                          \
+                     vilco_drop_threshold_host(drop_p), drop_seed, 1.f / (1.f - drop_p), dbias, sync,                            \
+                     emit ? amax_parts : nullptr, vilco_seed_word_dev(), po, row_mask)
+  if (planes) { if (vec) ACT_BWD_LAUNCH(act_bwd_vec_kernel<true>); else ACT_BWD_LAUNCH(act_bwd_kernel<true>); }
+  else { if (vec) ACT_BWD_LAUNCH(act_bwd_vec_kernel<false>); else ACT_BWD_LAUNCH(act_bwd_kernel<false>); }
+#undef ACT_BWD_LAUNCH
   if (dbias && !sync) vilco_reduce_rows(ws, dbias, nullptr, nb, C, C, s);
   return vilco_launch_status();
 }
