@@ -92,3 +92,33 @@ def test_state_dict_is_drop_in():
         assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == \
                {k: tuple(v.shape) for k, v in gold['state_dict'].items()}
         model.load_state_dict(gold['state_dict'], strict=True)
+
+
+def test_producer_plane_entry_points_validate_on_the_host():
+    """the producer-written-planes entry points (round 4): buffer sizes equal the pack's for the same tensor, and bad layouts are
+    refused before anything is launched"""
+    from vilco_amd import _lib
+    lib = _lib.load()
+    for rows, C in ((4608, 1024), (100, 96), (77, 32)):
+        assert lib.vilco_layernorm_planes_bytes(rows, C, 0) == lib.vilco_pack_bytes(rows, C, 3)
+    it = _lib.PackItem()
+    it.rows, it.cols, it.ld, it.nbatch, it.seq_len = 2 * 4541, 1024, 1024, 1, 4541
+    assert lib.vilco_layernorm_planes_bytes(2 * 4541, 1024, 4541) == lib.vilco_pack_item_bytes(ctypes.byref(it), 3)
+    x = 4096                                            # dummy, suitably aligned addresses: every check below precedes the launch
+    # natural planes need C % 32 == 0, the convs' image whole sequences; a short buffer is a workspace error
+    assert lib.vilco_layernorm_fwd_planes(x, None, None, x, x, x, 64, 40, 1e-5, 0, None, None, x, 1 << 30, 0, None, 0, None) == -2
+    assert lib.vilco_layernorm_fwd_planes(x, None, None, x, x, x, 65, 64, 1e-5, 0, None, None, x, 1 << 30, 16, None, 0, None) == -2
+    assert lib.vilco_layernorm_fwd_planes(x, None, None, x, x, x, 64, 64, 1e-5, 0, None, None, x, 128, 0, None, 0, None) == -4
+    # activation backward: planes need the partial maxima of dy, C % 32 == 0 and a buffer of vilco_pack_bytes
+    assert lib.vilco_act_bwd_planes(x, None, None, None, 0, None, 0, 64, 64, 0.0, 0, None, 0, None, None, None, 0, x, 1 << 30, None, None) == -1
+    assert lib.vilco_act_bwd_planes(x, None, None, None, 0, None, 0, 64, 40, 0.0, 0, None, 0, None, None, x, 4, x, 1 << 30, None, None) == -1
+    assert lib.vilco_act_bwd_planes(x, None, None, None, 0, None, 0, 64, 64, 0.0, 0, None, 0, None, None, x, 4, x, 128, None, None) == -4
+    # a row mask on a batched product is not supported
+    d = _lib.GemmDesc()
+    d.A = d.B = d.C = d.row_mask = 4096
+    d.M, d.N, d.K = 128, 128, 64
+    d.a_kcontig = d.b_kcontig = 1
+    d.lda = d.ldb = 64
+    d.ldc = 128
+    d.batch_outer, d.batch_inner, d.precision = 2, 1, 3
+    assert lib.vilco_gemm(ctypes.byref(d), None) == -2
