@@ -285,6 +285,16 @@ int vilco_attn_fwd(const float* q, const float* k, const float* v, const float* 
                    int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                    uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* o_amax, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* the same, and o also written as the fp16 x2 operand planes (vilco_pack's layout for [B * Tq][H * hd], precision 3,      */
+/* vilco_pack_bytes long, 256-byte aligned) of the output projection -- the hd = 64 kernels only (when                       */
+/* vilco_attn_amax_parts(...) > 0, or XLNet's relative attention at hd = 64).  Scale from the bound max|o| <= max|v| / keep. */
+int32_t vilco_attn_planes_supported(int32_t Tq, int32_t Tk, int32_t hd, int32_t mode, int32_t precision, int32_t has_bias,
+                                    float drop_p);
+int vilco_attn_fwd_planes(const float* q, const float* k, const float* v, const float* bias,
+                   const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
+                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
+                   uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* o_amax, void* workspace,
+                   size_t workspace_bytes, void* o_planes, size_t o_planes_bytes, void* stream);
 size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision);
 /* dq/dk/dv are overwritten; dbias (optional, [B,H,Tq,Tk]) receives dS.  Deterministic (no atomics). */
 int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* bias,

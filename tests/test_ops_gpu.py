@@ -854,3 +854,45 @@ def test_conv3_row_mask_equals_masking_afterwards(dev):
     assert torch.equal(res[0][0], res[1][0])
     for a, c in zip(*res):
         assert rel(a, c) < 2e-6
+
+
+@pytest.mark.parametrize("B,Tq,Tk,H,lens", [(2, 300, 300, 2, [300, 211]), (1, 129, 77, 4, [77]), (2, 2304, 2304, 2, [2304, 1500])])
+def test_attention_writes_output_planes(dev, B, Tq, Tk, H, lens):
+    """vilco_attn_fwd_planes (hd = 64 forward kernels): the attention output also leaves the kernel as the fp16 x2 operand planes
+    of the output projection, scaled by max|v| (a convex combination of rows of v cannot exceed it): decode == o to 22 bits,
+    zero rows zero, the projection finds the planes, and its forward + backward equal the VILCO_ATTN_PLANES=0 path"""
+    from vilco_amd import ops
+    torch.manual_seed(B * Tq + H)
+    C = H * 64
+    q, k = torch.randn(B, Tq, C, device=dev), torch.randn(B, Tk, C, device=dev)
+    v = torch.randn(B, Tk, C, device=dev) * 3
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev)
+    o = ops.attention(q, k, v, lt, H, 0.125)
+    hit = getattr(o, "_vilco_planes", None)
+    assert hit is not None and ops.pack(o, B * Tq, C) is hit[0]
+    planes = hit[0]
+    hdr = planes[:4096 + 512].view(torch.float32)
+    inv_s, s = float(hdr[1024]), float(hdr[1025])
+    vmax = float(v.abs().max())
+    assert inv_s * s == 1.0 and 2.0 ** 14 <= vmax * s < 2.0 ** 15 and float(o.abs().max()) <= vmax * (1 + 1e-5)
+    rows32 = (B * Tq + 31) // 32 * 32
+    body = planes[4096 + 512:].view(torch.float16).view(2, rows32, C).double()
+    dec = (body[0] + body[1]) / s
+    want = torch.zeros(rows32, C, dtype=torch.float64, device=dev)
+    want[:B * Tq] = o.view(B * Tq, C).double()
+    assert bool(((dec - want).abs() <= want.abs() * 2.0 ** -21 + vmax * 2.0 ** -39).all())
+    w = torch.randn(C, C, device=dev) / 8
+    res = []
+    for on in (True, False):
+        ops.attn_planes = on
+        try:
+            qq, kk, vv, ww = [t.clone().requires_grad_(True) for t in (q, k, v, w)]
+            oo = ops.attention(qq, kk, vv, lt, H, 0.125)
+            assert (getattr(oo, "_vilco_planes", None) is not None) == on
+            y = ops.linear(oo, ww)
+            y.backward(torch.ones_like(y) / 5)
+            res.append((y.detach(), qq.grad, vv.grad, ww.grad))
+        finally:
+            ops.attn_planes = True
+    for a, c in zip(*res):
+        assert rel(a, c) < 2e-6

@@ -105,6 +105,9 @@ SIGNATURES = {
     "vilco_attn_amax_parts": (i32, [i32, i32, i32, i32, i32, i32, i32, f32, i32]),
     "vilco_attn_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, i32, i32, i32, f32,
                                  C.c_uint32, C.POINTER(AttnAmaxIn), c_fp, c_fp, sz, c_fp]),
+    "vilco_attn_fwd_planes": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, f32, i32, i32, i32, f32,
+                                        C.c_uint32, C.POINTER(AttnAmaxIn), c_fp, c_fp, sz, c_fp, sz, c_fp]),
+    "vilco_attn_planes_supported": (i32, [i32, i32, i32, i32, i32, i32, f32]),
     "vilco_attn_bwd_workspace": (sz, [i32, i32, i32, i32, i32, i32]),
     "vilco_attn_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32,
                                  i32, i32, i32, f32, i32, i32, i32, f32, C.c_uint32, C.POINTER(AttnAmaxIn), c_fp, c_fp, c_fp, c_fp, c_fp, sz,

@@ -216,6 +216,11 @@ struct AttnArgs {
   // optional max|x| partials of the outputs (one per workgroup), left for the operand pack of the next product
   // (vilco_pack_item.amax); written by the hd = 64 fast kernels only (vilco_attn_amax_parts)
   float* am_o; float* am_dq; float* am_dk; float* am_dv; float* am_ds;
+  // optional (hd = 64 fast forward kernels): o is also written as the fp16 x2 operand planes of the output projection
+  // (pack.h's layout for [B * Tq][C]).  Every output row is a convex combination of rows of v (times 1 / keep under probability
+  // dropout), so max|v| -- whose scale this call has just folded for its own V planes -- bounds max|o|: the planes' scale is
+  // sv * o_scale_mul, o_scale_mul = 2^-ceil(log2(1 / keep)).
+  _Float16* op0; long o_plane_stride; float* o_inv_scale; long o_rows32; float o_scale_mul;
 };
 
 // registers holding the B-operand fragments of this wave's 16 query rows (all k-steps, all parts)
@@ -775,6 +780,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
   for (int t = nfull; t < ntiles; ++t) tile(t, t + 1 < ntiles, std::true_type{});
 
   // finish: lane holds query q0 + 16 g + (lane & 15), channels di*16 + 4*g4 + r
+  typedef _Float16 h4o __attribute__((ext_vector_type(4)));
+  const float so = a.op0 ? sc.sv * a.o_scale_mul : 0.f;      // scale of the output planes (see AttnArgs.op0)
   float am = 0.f;
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
@@ -789,8 +796,29 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
         const float4 v = make_float4(oacc[g][di][0] * inv, oacc[g][di][1] * inv, oacc[g][di][2] * inv, oacc[g][di][3] * inv);
         *reinterpret_cast<float4*>(og + di * 16 + g4 * 4) = v;
         am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if (a.op0) {
+          const float xs[4] = {v.x * so, v.y * so, v.z * so, v.w * so};      // exact (power of two)
+          h4o h0, h1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { h0[e] = (_Float16)xs[e]; h1[e] = (_Float16)(xs[e] - (float)h0[e]); }
+          const long po = ((long)b * a.Tq + qi) * a.C + h * HDP + di * 16 + g4 * 4;
+          *reinterpret_cast<h4o*>(a.op0 + po) = h0;
+          *reinterpret_cast<h4o*>(a.op0 + a.o_plane_stride + po) = h1;
+        }
       }
       if (a.lse && g4 == 0) a.lse[(long)bh * a.Tq + qi] = 0.69314718055994530942f * (m_run[g] + __builtin_amdgcn_logf(l) - 15.f);
+    }
+  }
+  if (a.op0) {
+    if ((blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) { a.o_inv_scale[0] = sc.iv / a.o_scale_mul; a.o_inv_scale[1] = so; }
+    if (blockIdx.x == gridDim.x - 1 && b == a.B - 1) {          // the planes' zero rows, this head's 64 columns
+      const long rows = (long)a.B * a.Tq;
+      const h4o hz = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      for (long i = tid; i < (a.o_rows32 - rows) * 16; i += ATT_THREADS) {
+        const long po = (rows + i / 16) * a.C + h * HDP + (i % 16) * 4;
+        *reinterpret_cast<h4o*>(a.op0 + po) = hz;
+        *reinterpret_cast<h4o*>(a.op0 + a.o_plane_stride + po) = hz;
+      }
     }
   }
   if (a.am_o) block_amax_out(am, a.am_o, reinterpret_cast<float*>(smem_raw));
@@ -2066,6 +2094,15 @@ extern "C" int32_t vilco_attn_amax_parts(int32_t B, int32_t H, int32_t T, int32_
   return n <= 8192 ? (int32_t)n : 0;
 }
 
+// 1 when vilco_attn_fwd_planes can write o's operand planes for this configuration (the hd = 64 forward kernels)
+extern "C" int32_t vilco_attn_planes_supported(int32_t Tq, int32_t Tk, int32_t hd, int32_t mode, int32_t precision, int32_t has_bias,
+                                               float drop_p) {
+  AttnArgs a = {};
+  a.hd = hd; a.mode = mode; a.Tq = Tq; a.Tk = Tk; a.drop_thresh = vilco_drop_threshold_host(drop_p);
+  if (has_bias) a.bias = reinterpret_cast<const float*>(&a);      // only its nullness is looked at
+  return (fast64(a, precision) || fast64_xl_fwd(a, precision)) ? 1 : 0;
+}
+
 extern "C" size_t vilco_attn_fwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {
   const int HDP = hdp_of(hd), NP = np_of(precision);
   return (size_t)(planes_bytes(spec_nat(B, H, Tq, HDP), NP) + planes_bytes(spec_nat(B, H, Tk, HDP), NP) +
@@ -2077,6 +2114,15 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
                               int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                               uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* o_amax, void* workspace,
                               size_t workspace_bytes, void* stream) {
+  return vilco_attn_fwd_planes(q, k, v, bias, kv_len, o, lse, B, H, Tq, Tk, hd, scale, mode, window, precision, drop_p, drop_seed,
+                               amax_in, o_amax, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int vilco_attn_fwd_planes(const float* q, const float* k, const float* v, const float* bias,
+                              const int32_t* kv_len, float* o, float* lse, int32_t B, int32_t H, int32_t Tq,
+                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
+                              uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* o_amax, void* workspace,
+                              size_t workspace_bytes, void* o_planes, size_t o_planes_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision, window);
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
@@ -2093,6 +2139,18 @@ extern "C" int vilco_attn_fwd(const float* q, const float* k, const float* v, co
   a.drop_thresh = vilco_drop_threshold_host(drop_p); a.drop_seed = drop_seed; a.drop_inv_keep = 1.f / (1.f - drop_p); a.seed_word = vilco_seed_word_dev();
   if (o_amax && !fast64(a, precision)) return VILCO_ERR_UNSUPPORTED;      // see vilco_attn_amax_parts
   a.am_o = o_amax;
+  if (o_planes) {                  // the hd = 64 forward kernels only (fast64 / fast64_xl_fwd)
+    if (!(fast64(a, precision) || fast64_xl_fwd(a, precision)) || !vilco_aligned(o_planes, 256)) return VILCO_ERR_UNSUPPORTED;
+    const long rows32 = ((long)B * Tq + 31) / 32 * 32;
+    if (o_planes_bytes < (size_t)(VILCO_PACK_HDR + rows32 * (long)(H * hd) * 4)) return VILCO_ERR_WORKSPACE;
+    unsigned char* u = reinterpret_cast<unsigned char*>(o_planes);
+    a.op0 = reinterpret_cast<_Float16*>(u + VILCO_PACK_HDR);
+    a.o_plane_stride = rows32 * (long)(H * hd);
+    a.o_inv_scale = reinterpret_cast<float*>(u) + VILCO_AMAX_MAX_BLOCKS;
+    a.o_rows32 = rows32;
+    a.o_scale_mul = 1.f;
+    for (float ik = a.drop_thresh ? a.drop_inv_keep : 1.f; ik > 1.f; ik *= 0.5f) a.o_scale_mul *= 0.5f;      // 2^-ceil(log2(1 / keep))
+  }
   unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
   ScaleWs sw;
   if (precision == 3) {

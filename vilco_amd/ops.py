@@ -545,6 +545,7 @@ def weight_planes(w, rows, cols):
 # VILCO_PRODUCER_PLANES=0: fp32 dz + pack, as before.
 producer_planes = os.environ.get("VILCO_PRODUCER_PLANES", "1") != "0"
 ln_planes = os.environ.get("VILCO_LN_PLANES", "1") != "0"          # the LayerNorm half of it (ops.layernorm(planes=...))
+attn_planes = os.environ.get("VILCO_ATTN_PLANES", "1") != "0"      # the attention-output part (hd = 64 forward kernels)
 
 
 def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None, planes=False, row_mask=None):
@@ -1186,12 +1187,28 @@ def _flash_fwd(q, k, v, bias, kv_len, H, scale, mode, drop=(0.0, 0), window=0):
     na = _attn_amax_parts(B, H, Tq, Cn // H, mode, bias, drop, 0)
     am = torch.empty(na, dtype=torch.float32, device=q.device) if na else None
     ain = _attn_amax_in(q, k, v)
-    _lib.check(lib.vilco_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
-                                  lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
-                                  int(drop[1]), C.byref(ain[0]) if ain else None, _p(am), ws.data_ptr(), nws, _stream()))
+    # the output goes into the output projection: the hd = 64 kernels write its operand planes themselves (|o| <= max|v| / keep)
+    planes = None
+    if (producer_planes and attn_planes and _pack_cache and _reuse_packs and _precision == 3 and B * Tq > 0 and
+            lib.vilco_attn_planes_supported(Tq, Tk, Cn // H, int(mode), _precision, int(bias is not None), float(drop[0]))):
+        planes = torch.empty(lib.vilco_pack_bytes(B * Tq, Cn, 3), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.vilco_attn_fwd_planes(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
+                                         lse.data_ptr(), B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
+                                         int(drop[1]), C.byref(ain[0]) if ain else None, _p(am), ws.data_ptr(), nws,
+                                         _p(planes), planes.numel() if planes is not None else 0, _stream()))
     if na:
         _FlashAttention.last_amax = (am, na)
+    _FlashAttention.last_planes = (planes, _cache_mark()) if planes is not None else None
     return o, lse
+
+
+def _attach_attn_planes(o):
+    """hang the planes the forward kernel wrote on its output (attributes set inside apply do not survive it)"""
+    made, _FlashAttention.last_planes = _FlashAttention.last_planes, None
+    if made is not None:
+        Cn = o.shape[-1]
+        o._vilco_planes = (made[0], (int(o.numel() // Cn), int(Cn), 3, o._version), made[1])
+    return o
 
 
 def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, drop=(0.0, 0), window=0):
@@ -1229,6 +1246,7 @@ class _FlashAttention(torch.autograd.Function):
     """fused attention (vilco_attn_fwd / vilco_attn_bwd): scores never reach HBM; backward recomputes P
     from (q, k, lse)."""
     last_amax = None        # (partials, count) the forward kernel left for the pack of its output, or None
+    last_planes = None      # (operand planes of the output written by the forward kernel, cache mark), or None
 
     @staticmethod
     def forward(ctx, q, k, v, kv_len, H, scale, mode, drop_p=0.0, window=0):
@@ -1254,11 +1272,12 @@ def attention(q, k, v, kv_len, n_head, scale=None, mode=MASK_KEYS, drop_p=0.0, w
         scale = 1.0 / math.sqrt(q.shape[-1] // n_head)
     if use_flash and flash_supported(q.shape[-1] // n_head):
         _FlashAttention.last_amax = None
+        _FlashAttention.last_planes = None
         o = _FlashAttention.apply(q, k, v, kv_len, int(n_head), float(scale), int(mode), float(drop_p), int(window))
         if _FlashAttention.last_amax is not None:        # left by the fused kernel for the pack of the output projection
             _tag_amax(o, *_FlashAttention.last_amax)
             _FlashAttention.last_amax = None
-        return o
+        return _attach_attn_planes(o)
     if mode == MASK_LOCAL:
         raise NotImplementedError("local-window attention needs the fused kernels (head dim <= 160, multiple of 4)")
     if drop_p > 0.0:
@@ -1389,7 +1408,8 @@ class _FlashRelAttention(torch.autograd.Function):
 def rel_attention(qw, qr, k, v, kr, kv_len, n_head, scale, drop_p=0.0):
     """kr [2T, C] or [B, 2T, C]; drop_p: dropout on the attention probabilities (training only)."""
     if use_flash and flash_supported(qw.shape[-1] // n_head):
-        return _FlashRelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale), float(drop_p))
+        _FlashAttention.last_planes = None
+        return _attach_attn_planes(_FlashRelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale), float(drop_p)))
     if drop_p > 0.0 or kr.dim() == 3:
         raise NotImplementedError("XLNet dropout needs the fused attention kernels (head dim <= 160, multiple of 4)")
     return _RelAttention.apply(qw, qr, k, v, kr, kv_len, int(n_head), float(scale))
