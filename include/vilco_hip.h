@@ -137,6 +137,10 @@ int vilco_gemm_force(int32_t bm, int32_t ks);
  * the partial accumulators in split order and runs the epilogue), 0 = fp32 slabs + a reduce launch (default: measured
  * faster, gemm.hip).  Same summation order either way.  Initial value: environment VILCO_GEMM_FIXUP=1 enables. */
 int vilco_gemm_set_fixup(int32_t on);
+/* Main kernel of the fp16 x2 products (precision 3 / 4) of every following vilco_gemm: 1 = gemm_gl_kernel (round 5: 64-element
+ * K chunks staged by LDS-DMA in whole 128-byte lines; default), 0 = gemm_pp_kernel (rounds 1-4: 32-element K-steps staged through
+ * registers).  Initial value: environment VILCO_GEMM_GL=0 selects the old kernel. */
+int vilco_gemm_set_gl(int32_t on);
 /* floats written to desc->amax_out by vilco_gemm(desc) (depends on the tile / split-K plan); 0: not available */
 int32_t vilco_gemm_amax_parts(const vilco_gemm_desc* desc);
 int vilco_gemm_profile_begin(void);

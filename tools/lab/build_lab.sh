@@ -2,7 +2,7 @@
 set -e
 cd "$(dirname "$0")/../../vilco_amd/csrc"
 mkdir -p ../../tools/lab/obj
-for f in gemm attn norm conv eltwise nms decode optim loss qkvpre sync status; do
+for f in gemm attn norm conv eltwise nms decode optim loss qkvpre sync status defer; do
   extra=""; [ $f = nms ] && extra="-ffp-contract=off"
   [ $f = gemm ] && extra="-DVILCO_LAB $LABFLAGS"
   [ $f = attn ] && extra="-DVILCO_LAB_ATTN $LABFLAGS"

@@ -60,6 +60,7 @@ struct PlaneOp {
   long seq_stride;      // elements between sequences
   long row_stride;      // elements between rows
   int cols;             // k-major planes: padded row length (multiple of 32); tile columns are clamped to cols - 8
+  long bytes;           // valid bytes behind p (one part, one batch): the buffer range of gemm_gl_kernel's loads
 };
 
 struct GArgs {
@@ -207,6 +208,118 @@ __device__ __forceinline__ void ld_sc1(f32x4& v, const f32x4* p) {
 // the loads above are invisible to the compiler's vmcnt bookkeeping: wait here, and tie the four registers to the wait
 __device__ __forceinline__ void wait_sc1(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
+
+// ---- epilogue shared by the MFMA kernels: accumulators of the 4 x 2 wave layout (wave tile 16 MI x 64) -> C through LDS.
+// Each wave transposes its 16 x 64 accumulator blocks so that a lane owns 4 consecutive columns of one row and the
+// stores / residual loads are 16 bytes per lane, 256 contiguous bytes per row, instead of 4-byte scatters (measured
+// before: 24k of a 112k-cycle block at K = 1024).  The pipeline buffers must be dead when this is called.
+template <int MI, bool F16, bool FIXUP>
+__device__ __forceinline__ void gemm_epilogue(const GArgs& g, f32x4 (&acc)[MI][4], unsigned char* smem_raw, int tid, int lane,
+                                              int wave, int wm, int wn, int m0, int n0, int bid, int ks, int zo, int zi) {
+  if (F16) {
+    const float inv = g.inv_a[0] * g.inv_b[0];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] *= inv;
+  }
+
+  // ---- epilogue through LDS (the pipeline buffers are dead: every fragment read retired before the last barrier):
+  // each wave transposes its 16 x 64 accumulator blocks so that a lane owns 4 consecutive columns of one row and
+  // the stores / residual loads are 16 bytes per lane, 256 contiguous bytes per row, instead of 4-byte scatters
+  // (measured before: 24k of a 112k-cycle block at K = 1024).
+  const long coff = zo * g.sCo + zi * g.sCi;
+  if constexpr (FIXUP) if (g.ksplit > 1 && g.tile_ctr) {
+    __shared__ unsigned arrived;
+    constexpr long PIECES = MI * 4 * 64;                        // f32x4 pieces per wave
+    const long tile = (long)blockIdx.z * g.ntiles + bid;
+    f32x4* mine = reinterpret_cast<f32x4*>(g.c) + ((tile * g.ksplit + ks) * 8 + wave) * PIECES + lane;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st_sc1(mine + (i * 4 + j) * 64, acc[i][j]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave, before the barrier the signal is behind
+    __syncthreads();
+    if (tid == 0) arrived = __hip_atomic_fetch_add(g.tile_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (arrived != (unsigned)(g.ksplit - 1)) return;
+    if (tid == 0) __hip_atomic_store(g.tile_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+    const f32x4* all = reinterpret_cast<const f32x4*>(g.c) + (tile * g.ksplit * 8 + wave) * PIECES + lane;
+    const long sstride = 8 * PIECES;
+    // every piece of one other split is requested before the first is used (one memory round trip per split, not per
+    // piece); two splits are in flight at a time.  The running sums start from split 0 and take the splits in order.
+    constexpr int NPC = MI * 4;
+    f32x4 sum[NPC];
+#pragma unroll
+    for (int q = 0; q < NPC; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < g.ksplit; s0 += 2) {
+      f32x4 va[NPC], vb[NPC];
+      const bool ha = s0 != ks, hb = s0 + 1 < g.ksplit && s0 + 1 != ks;
+#pragma unroll
+      for (int q = 0; q < NPC; ++q) {
+        va[q] = sum[q]; vb[q] = sum[q];
+        if (ha) ld_sc1(va[q], all + (long)s0 * sstride + q * 64);
+        if (hb) ld_sc1(vb[q], all + (long)(s0 + 1) * sstride + q * 64);
+      }
+#pragma unroll
+      for (int q = 0; q < NPC; q += 2) wait_sc1(va[q], va[q + 1], vb[q], vb[q + 1]);
+#pragma unroll
+      for (int q = 0; q < NPC; ++q) {
+        sum[q] += ha ? va[q] : acc[q / 4][q % 4];
+        if (s0 + 1 < g.ksplit) sum[q] += hb ? vb[q] : acc[q / 4][q % 4];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NPC; ++q) acc[q / 4][q % 4] = sum[q];
+  }
+  const bool partial = g.ksplit > 1 && !g.tile_ctr;
+  float* cp = g.c + (partial ? (long)ks * g.split_stride : 0);
+  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (16 * EPI_LD);
+  const int n = n0 + wn * 64 + (lane & 15) * 4;
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) stg[((lane >> 4) * 4 + rr) * EPI_LD + j * 16 + (lane & 15)] = acc[i][j][rr];
+#pragma unroll
+    for (int p4 = 0; p4 < 4; ++p4) {
+      const int row = p4 * 4 + (lane >> 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 15) * 4);
+      const int m = m0 + wm * (16 * MI) + i * 16 + row;
+      if (m >= g.M || n >= g.N) continue;
+      const long idx = coff + (long)m * g.ldc + n;
+      if (partial) {
+        if (g.vec_out) *reinterpret_cast<f32x4*>(cp + idx) = v;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[idx + e] = v[e];
+      } else {
+        bool valid = g.e.row_len ? (m % g.e.rowT) < g.e.row_len[m / g.e.rowT] : true;
+        if (g.e.row_mask) valid = valid && g.e.row_mask[m] != 0.f;
+        if (g.vec_out) am = fmaxf(am, store_out4(g, idx, n, v, valid));
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) am = fmaxf(am, store_out(g, idx + e, n + e, v[e], valid));
+      }
+    }
+  }
+  if (g.amax_out && !partial) {     // max|C| of this tile for the operand pack of the next product (one float per workgroup)
+    am = wave_max(am);
+    __syncthreads();                // every wave is done with its staging rows
+    float* red = reinterpret_cast<float*>(smem_raw);
+    if (lane == 0) red[wave] = am;
+    __syncthreads();
+    if (tid == 0) {
+      float m = red[0];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+      g.amax_out[(long)blockIdx.z * gridDim.x + blockIdx.x] = m;     // (split-K fix-up: one last arriver per tile)
+    }
+  }
 }
 
 // K2 (r03): the single-part products (precision 4: weight gradients with long contractions) keep the TWO-slot layout of
@@ -607,108 +720,302 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   }
   STAMPX(2);
 
-  if (F16) {
-    const float inv = g.inv_a[0] * g.inv_b[0];
+  gemm_epilogue<MI, F16, true>(g, acc, smem_raw, tid, lane, wave, wm, wn, m0, n0, bid, ks, zo, zi);
+  STAMPX(3);
+}
+
+
+// ------------------------------------------------------------------------------------------ LDS-DMA kernel (round 5)
+// gemm_gl_kernel: the fp16 x2 products (precision 3: two parts, three MFMAs per fragment pair; SINGLE = precision 4: the
+// leading parts only) with the staging rebuilt around what round 5's load-path probe measured (tools/lab/ldpath.hip, one
+// workgroup per CU streaming an L2-resident operand): 1-KiB load instructions made of 64-byte row segments -- the BK = 32
+// K-steps of gemm_pp_kernel -- move 29 B / clk / CU, whole 128-byte lines 50 (to registers) to 58 (LDS-DMA).  A 192 x 128
+// tile needs 40 KB per 32 k: 1400 cycles of the ~2400 a K-step took were the address path alone.  Here:
+//   * a K CHUNK is 64 elements: every load instruction covers 8 rows x 128 B = whole lines (k-contiguous operands: 8 tile
+//     rows x 64 k; k-major operands: 8 k-rows x 64 columns);
+//   * the loads are LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write -- the VGPR -> LDS store path
+//     (13 cycles per ds_write_b128, two SIMD halves) was the other half of the old MEM phase.  The LDS image of a DMA is
+//     lane-linear, so the bank swizzle sits on the SOURCE address (lane i fetches the chunk that belongs at position i) and
+//     on the fragment reads;
+//   * every operand tile is a set of [R][128 B] panels (k-contiguous: R = tile rows; k-major: one panel per 64 columns,
+//     R = 64 k), 16-byte chunk c of row r at c ^ ((r >> 1) & 7) (k-contiguous, ds_read_b128) or with the 32-byte pair index
+//     XORed by ((k >> 1) & 1) | (((k >> 3) & 1) << 1) (k-major, ds_read_b64_tr_b16): both conflict-free by the lane groups
+//     of MI355X_MICROARCH.md (checked exhaustively, tools/lab/swizzle_check.py);
+//   * two LDS stages of one chunk (2 slots x (A + B) x 64 k: 160 KB at 192 rows), ping-pong as before: waves 0-3 ("early",
+//     the upper half of the tile's rows) and 4-7 ("late") run one PHASE apart, two raw barriers per chunk:
+//         early:  [ reads(t), DMA(t+1) | X | MFMA(t), vmcnt(0) | Y ]      late:  [ MFMA(t-1), vmcnt(0) | X | reads(t), DMA(t+1) | Y ]
+//     A DMA needs a phase to land before its first reader, and the late group issues at the END of an interval -- so the work
+//     is split by WHO READS FIRST: the early waves fetch what they read themselves at the start of the next interval (the A
+//     rows of the upper half and all of B), the late waves the A rows only they read, one phase later.  Each group waits for
+//     its own DMAs (vmcnt(0)) just before the barrier that precedes their first reader ("read a staged buffer one phase after
+//     the wait that retires it", cdna_hip_programming.md 5).
+// SINGLE keeps the two slots and fills them with part 0 of two consecutive 64-element chunks (128 k per interval).
+template <int BM, bool AKM, bool BKM, bool SINGLE>
+__global__ __launch_bounds__(512) void gemm_gl_kernel(GArgs g) {
+  constexpr int MI = BM / 64;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;       // one slot of one operand
+  constexpr int SLOT = A_BYTES + B_BYTES, STAGE = 2 * SLOT;
+  constexpr int KSLOT = 64;                                   // k per slot
+  constexpr int KINT = SINGLE ? 128 : 64;                     // k per barrier interval
+  // pieces (1 KiB = 8 panel rows): A has BM / 8, B has 16.  The early group takes the A pieces its own waves read.
+  constexpr int NA0 = AKM ? 8 * ((BM / 2 + 63) / 64) : BM / 16;
+  constexpr int NA1 = BM / 8 - NA0;
+  constexpr int NP0 = (NA0 + 16) / 4, NP0A = NA0 / 4;         // pieces per early wave (per slot); the first NP0A are A's
+  constexpr int NP1 = NA1 / 4;                                // pieces per late wave (per slot)
+  static_assert(NA0 % 4 == 0 && NA1 % 4 == 0 && NP1 >= 1, "piece split");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool late = wave >= 4;
+  const int w4 = wave & 3;
+#ifdef VILCO_LAB
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave & 3) == 0;
+#endif
+  STAMPX(0);
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = g.ntiles, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
+  const int ks = blockIdx.y;
+
+  const __bf16* pa = g.a.p + ((long)(g.a.has_o ? zo : 0) * g.a.nbi + (g.a.has_i ? zi : 0)) * g.a.batch_stride;
+  const __bf16* pb = g.b.p + ((long)(g.b.has_o ? zo : 0) * g.b.nbi + (g.b.has_i ? zi : 0)) * g.b.batch_stride;
+  __amdgpu_buffer_rsrc_t rsA[2], rsB[2];
+  {
+    const unsigned na = g.a.bytes > 0xffffffffL ? 0xffffffffu : (unsigned)g.a.bytes;
+    const unsigned nb = g.b.bytes > 0xffffffffL ? 0xffffffffu : (unsigned)g.b.bytes;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int q = 0; q < 2; ++q) {
+      rsA[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pa + (SINGLE ? 0 : q * g.a.plane_stride)), 0, na, 0x00020000);
+      rsB[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pb + (SINGLE ? 0 : q * g.b.plane_stride)), 0, nb, 0x00020000);
+    }
+  }
+  // ---- this wave's DMA pieces: source byte offset of this lane, LDS offset of the piece inside a slot
+  unsigned voff[NP0];
+  int ldso[NP0];
+  {
+    const int sr = lane >> 3, cp = lane & 7;                  // panel row inside the piece, chunk POSITION in the 128-B row
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] *= inv;
+    for (int j = 0; j < NP0; ++j) {
+      const bool isB = !late && j >= NP0A;
+      int p = late ? NA0 + w4 + 4 * j : (isB ? w4 + 4 * j - NA0 : w4 + 4 * j);
+      if (late && j >= NP1) p = NA0 + w4;                     // (unused slot)
+      const PlaneOp& o = isB ? g.b : g.a;
+      const bool km = isB ? BKM : AKM;
+      const int t0 = isB ? n0 : m0;
+      long off;
+      if (km) {
+        const int panel = p >> 3, k = 8 * (p & 7) + sr;
+        const int f = ((k >> 1) & 1) | (((k >> 3) & 1) << 1);
+        const int c = (((cp >> 1) ^ f) << 1) | (cp & 1);      // source chunk of the row that belongs at position cp
+        int col = t0 + panel * 64 + c * 8;
+        if (col > o.cols - 8) col = o.cols - 8;
+        off = (long)k * o.row_stride + col;
+      } else {
+        const int row = 8 * p + sr;
+        const int c = cp ^ ((row >> 1) & 7);
+        off = row_off(o, t0 + row) + c * 8;
+      }
+      voff[j] = (unsigned)(off * 2);
+      ldso[j] = (isB ? A_BYTES : 0) + p * 1024;
+    }
+  }
+  const int kstepA = AKM ? (int)(2 * KSLOT * g.a.row_stride) : 2 * KSLOT;     // bytes per 64 k
+  const int kstepB = BKM ? (int)(2 * KSLOT * g.b.row_stride) : 2 * KSLOT;
+
+  // ---- fragment addresses (bytes inside a slot; k32 half h adds hoff, MFMA block i / j its own term)
+  int faddr[MI], fbddr[4];
+  int fa_h1, fb_h1;                                           // what the second k32 half adds (k-major) or XORs (k-contiguous)
+  {
+    const int grp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int fsw = ((q4 >> 1) & 1) | ((grp & 1) << 1);
+    const int ksw = (lane >> 1) & 7;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (AKM) {
+        const int c0 = wm * (16 * MI) + 16 * i;
+        faddr[i] = (c0 >> 6) * 8192 + (8 * grp + q4) * 128 + ((((c0 >> 4) & 3) ^ fsw) << 5) + 8 * p4;
+      } else {
+        faddr[i] = (wm * (16 * MI) + 16 * i + (lane & 15)) * 128 + (((lane >> 4) ^ ksw) << 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (BKM) fbddr[j] = A_BYTES + wn * 8192 + (8 * grp + q4) * 128 + ((j ^ fsw) << 5) + 8 * p4;
+      else fbddr[j] = A_BYTES + (wn * 64 + 16 * j + (lane & 15)) * 128 + (((lane >> 4) ^ ksw) << 4);
+    }
+    fa_h1 = AKM ? 4096 : 64;
+    fb_h1 = BKM ? 4096 : 64;
   }
 
-  // ---- epilogue through LDS (the pipeline buffers are dead: every fragment read retired before the last barrier):
-  // each wave transposes its 16 x 64 accumulator blocks so that a lane owns 4 consecutive columns of one row and
-  // the stores / residual loads are 16 bytes per lane, 256 contiguous bytes per row, instead of 4-byte scatters
-  // (measured before: 24k of a 112k-cycle block at K = 1024).
-  const long coff = zo * g.sCo + zi * g.sCi;
-  if (g.ksplit > 1 && g.tile_ctr) {
-    __shared__ unsigned arrived;
-    constexpr long PIECES = MI * 4 * 64;                        // f32x4 pieces per wave
-    const long tile = (long)blockIdx.z * g.ntiles + bid;
-    f32x4* mine = reinterpret_cast<f32x4*>(g.c) + ((tile * g.ksplit + ks) * 8 + wave) * PIECES + lane;
+  f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) st_sc1(mine + (i * 4 + j) * 64, acc[i][j]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave, before the barrier the signal is behind
-    __syncthreads();
-    if (tid == 0) arrived = __hip_atomic_fetch_add(g.tile_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (arrived != (unsigned)(g.ksplit - 1)) return;
-    if (tid == 0) __hip_atomic_store(g.tile_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
-    const f32x4* all = reinterpret_cast<const f32x4*>(g.c) + (tile * g.ksplit * 8 + wave) * PIECES + lane;
-    const long sstride = 8 * PIECES;
-    // every piece of one other split is requested before the first is used (one memory round trip per split, not per
-    // piece); two splits are in flight at a time.  The running sums start from split 0 and take the splits in order.
-    constexpr int NPC = MI * 4;
-    f32x4 sum[NPC];
-#pragma unroll
-    for (int q = 0; q < NPC; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < g.ksplit; s0 += 2) {
-      f32x4 va[NPC], vb[NPC];
-      const bool ha = s0 != ks, hb = s0 + 1 < g.ksplit && s0 + 1 != ks;
-#pragma unroll
-      for (int q = 0; q < NPC; ++q) {
-        va[q] = sum[q]; vb[q] = sum[q];
-        if (ha) ld_sc1(va[q], all + (long)s0 * sstride + q * 64);
-        if (hb) ld_sc1(vb[q], all + (long)(s0 + 1) * sstride + q * 64);
-      }
-#pragma unroll
-      for (int q = 0; q < NPC; q += 2) wait_sc1(va[q], va[q + 1], vb[q], vb[q + 1]);
-#pragma unroll
-      for (int q = 0; q < NPC; ++q) {
-        sum[q] += ha ? va[q] : acc[q / 4][q % 4];
-        if (s0 + 1 < g.ksplit) sum[q] += hb ? vb[q] : acc[q / 4][q % 4];
-      }
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- K range of this workgroup, in intervals of KINT
+  const int nk32 = g.Kp / BK;
+  constexpr int SUB = KINT / 32;                              // k32 sub-steps per interval
+  const int nint_all = (nk32 + SUB - 1) / SUB;
+  int c0 = ks * g.kchunk, c1 = c0 + g.kchunk;
+  if (c1 > nint_all) c1 = nint_all;
+  int sub_end = nk32;                                         // first k32 sub-step that is not computed
+  if (g.band) {
+    const int T = g.bandT;
+    if (g.band == 1) {
+      if (n0 >= 2 * T - m0 || n0 + BN - 1 < T - (m0 + BM - 1)) return;
+    } else {
+      int lo = T - (m0 + BM - 1), hi = 2 * T - m0;
+      if (g.band == 3 && hi > T) hi = T;
+      if (lo < 0) lo = 0;
+      const int b0 = lo / KINT, b1 = (hi + KINT - 1) / KINT;
+      if (b0 > c0) c0 = b0;
+      if (b1 < c1) c1 = b1;
+      if (c1 < c0) c1 = c0;
     }
-#pragma unroll
-    for (int q = 0; q < NPC; ++q) acc[q / 4][q % 4] = sum[q];
   }
-  const bool partial = g.ksplit > 1 && !g.tile_ctr;
-  float* cp = g.c + (partial ? (long)ks * g.split_stride : 0);
-  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (16 * EPI_LD);
-  const int n = n0 + wn * 64 + (lane & 15) * 4;
-  float am = 0.f;
+  const int nc = c1 - c0;
+  const int last_sub = sub_end - (c1 - 1) * SUB;              // valid sub-steps of the last interval (>= SUB: all)
+
+  auto issue = [&](int ci, int st) {                          // this wave's pieces of interval ci -> stage st
+    unsigned char* sbase = smem_raw + st * STAGE;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+    for (int u = 0; u < 2; ++u) {
+      const int kc64 = SINGLE ? 2 * ci + u : ci;              // which 64-k chunk goes into slot u
+      const int sa = kc64 * kstepA, sb = kc64 * kstepB;
+      if (!late) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) stg[((lane >> 4) * 4 + rr) * EPI_LD + j * 16 + (lane & 15)] = acc[i][j][rr];
-#pragma unroll
-    for (int p4 = 0; p4 < 4; ++p4) {
-      const int row = p4 * 4 + (lane >> 4);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 15) * 4);
-      const int m = m0 + wm * (16 * MI) + i * 16 + row;
-      if (m >= g.M || n >= g.N) continue;
-      const long idx = coff + (long)m * g.ldc + n;
-      if (partial) {
-        if (g.vec_out) *reinterpret_cast<f32x4*>(cp + idx) = v;
-        else
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[idx + e] = v[e];
+        for (int j = 0; j < NP0; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(j >= NP0A ? rsB[u] : rsA[u],
+              (__attribute__((address_space(3))) void*)(sbase + u * SLOT + ldso[j]), 16, (int)voff[j], j >= NP0A ? sb : sa, 0, 0);
       } else {
-        bool valid = g.e.row_len ? (m % g.e.rowT) < g.e.row_len[m / g.e.rowT] : true;
-        if (g.e.row_mask) valid = valid && g.e.row_mask[m] != 0.f;
-        if (g.vec_out) am = fmaxf(am, store_out4(g, idx, n, v, valid));
-        else
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) am = fmaxf(am, store_out(g, idx + e, n + e, v[e], valid));
+        for (int j = 0; j < NP1; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA[u], (__attribute__((address_space(3))) void*)(sbase + u * SLOT + ldso[j]),
+                                                  16, (int)voff[j], sa, 0, 0);
       }
     }
-  }
-  if (g.amax_out && !partial) {     // max|C| of this tile for the operand pack of the next product (one float per workgroup)
-    am = wave_max(am);
-    __syncthreads();                // every wave is done with its staging rows
-    float* red = reinterpret_cast<float*>(smem_raw);
-    if (lane == 0) red[wave] = am;
-    __syncthreads();
-    if (tid == 0) {
-      float m = red[0];
+  };
+
+  bf16x8 fa[2][2][MI], fb[2][2][4];                           // [slot][k32 half][block]
+  auto reads = [&](int st) {
+    const unsigned char* sbase = smem_raw + st * STAGE;
 #pragma unroll
-      for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
-      g.amax_out[(long)blockIdx.z * gridDim.x + blockIdx.x] = m;     // (split-K fix-up: one last arriver per tile)
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (AKM) fa[u][h][i] = tr_frag(reinterpret_cast<const __bf16*>(sbase + u * SLOT + faddr[i] + h * fa_h1), 4 * 64);
+          else fa[u][h][i] = *reinterpret_cast<const bf16x8*>(sbase + u * SLOT + (faddr[i] ^ (h * fa_h1)));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (BKM) fb[u][h][j] = tr_frag(reinterpret_cast<const __bf16*>(sbase + u * SLOT + fbddr[j] + h * fb_h1), 4 * 64);
+          else fb[u][h][j] = *reinterpret_cast<const bf16x8*>(sbase + u * SLOT + (fbddr[j] ^ (h * fb_h1)));
+        }
+      }
+  };
+  // nsub: valid k32 sub-steps of this interval (sub-step s = slot u, half h: SINGLE s = 2 u + h; two parts: s = h)
+  auto mfmas = [&](int nsub) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int u = 0; u < (SINGLE ? 2 : 1); ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if ((SINGLE ? 2 * u + h : h) < nsub) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mma<true>(fa[u][h][i], fb[u][h][j], acc[i][j]);
+          if constexpr (!SINGLE) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                acc[i][j] = mma<true>(fa[0][h][i], fb[1][h][j], acc[i][j]);
+                acc[i][j] = mma<true>(fa[1][h][i], fb[0][h][j], acc[i][j]);
+              }
+          }
+        }
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define GL_BARRIER()                                  \
+  do {                                                \
+    __builtin_amdgcn_sched_barrier(0);                \
+    __builtin_amdgcn_s_barrier();                     \
+    __builtin_amdgcn_sched_barrier(0);                \
+  } while (0)
+#define GL_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GL_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+  if (nc > 0) {
+    issue(c0, 0);
+    STAMPX(4);
+    GL_WAIT_DMA();
+    GL_BARRIER();
+    STAMPX(1);
+    if (!late) {
+      for (int t = 0; t < nc; ++t) {
+        STAMP(0);
+        reads(t & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef VILCO_LAB_FINE
+        STAMP(1);
+#endif
+        if (t + 1 < nc) issue(c0 + t + 1, (t + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(2);
+        GL_WAIT_LDS();
+        GL_BARRIER();                                         // X
+        STAMP(4);
+        mfmas(t + 1 < nc ? SUB : last_sub);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(5);
+        GL_WAIT_DMA();
+        STAMP(6);
+        GL_BARRIER();                                         // Y
+        STAMP(7);
+      }
+    } else {
+      for (int t = 0; t < nc; ++t) {
+        STAMP(0);
+        if (t > 0) mfmas(SUB);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(1);
+        GL_WAIT_DMA();
+        STAMP(2);
+        GL_BARRIER();                                         // X
+        STAMP(3);
+        reads(t & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef VILCO_LAB_FINE
+        STAMP(4);
+#endif
+        if (t + 1 < nc) issue(c0 + t + 1, (t + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(5);
+        GL_WAIT_LDS();
+        GL_BARRIER();                                         // Y
+        STAMP(7);
+      }
+      mfmas(last_sub);
     }
   }
+#undef GL_BARRIER
+#undef GL_WAIT_DMA
+#undef GL_WAIT_LDS
+  STAMPX(2);
+  gemm_epilogue<MI, true, false>(g, acc, smem_raw, tid, lane, wave, wm, wn, m0, n0, bid, ks, zo, zi);
   STAMPX(3);
 }
 
@@ -802,6 +1109,7 @@ struct Plan {
   bool tapkm;                     // k=3 conv weight gradient as a k-major x k-major product over zero-padded token rows (make_plan)
   bool k2;                        // precision 4: a barrier interval of the kernel covers two K-steps (64 elements of K)
   bool fixup;                     // split-K finished inside the launch (tile counters) instead of by splitk_reduce_kernel
+  bool gl;                        // gemm_gl_kernel (LDS-DMA staging, 64-element chunks): the fp16 x2 products
 };
 
 // Arrival counters of the split-K fix-up: persistent, zero at load, reset by each tile's last arriver.  One region per
@@ -833,6 +1141,11 @@ unsigned* tile_counters(hipStream_t s) {
   if (n >= FIX_STREAMS) return nullptr;
   streams[n] = s;
   return base + (long)(n++) * FIX_TILES;
+}
+
+inline bool& gl_enabled() {      // VILCO_GEMM_GL=0 / vilco_gemm_set_gl(0): the fp16 x2 products stay on gemm_pp_kernel (rounds 1-4)
+  static bool v = [] { const char* e = getenv("VILCO_GEMM_GL"); return !(e && e[0] == '0'); }();
+  return v;
 }
 
 inline bool tapkm_enabled() {
@@ -914,18 +1227,28 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   // the CUs idle), 288 at 128 (two rounds) and 192 at 192 rows (one round, 75 % busy).  Ties go to the taller tile
   // (fewer B re-reads).  The 192-row tile exists for the default precision only.
   const long tiles192 = ((d->M + 191) / 192) * tn * nbatch;
+  p.k2 = d->precision == 4 && d->band == 0 && k2_enabled();
+  // round 5: the fp16 x2 products run on gemm_gl_kernel (128- or 192-row tiles: two stages of a 64-element chunk of a
+  // 256-row tile do not fit the LDS)
+  // (single-part products: measured in the step, the weight-gradient shapes run 5-15 % slower on it than on gemm_pp_kernel's K2
+  // loop -- 1024 x 3072 x 9082: 103 -> 119 us -- their intervals hold a third of the MFMAs per byte and the late group's DMAs
+  // do not land inside one MFMA phase; VILCO_GEMM_GL_SINGLE=1 selects it anyway)
+  static const bool gl_single = [] { const char* e = getenv("VILCO_GEMM_GL_SINGLE"); return e && e[0] == '1'; }();
+  p.gl = gl_enabled() && (d->precision == 3 || (d->precision == 4 && p.k2 && gl_single));
   if (tiles128 <= 256 || d->M < 2048) {
     p.BM = 128;
   } else {
     const long c128 = ((tiles128 + 255) / 256) * 128, c192 = ((tiles192 + 255) / 256) * 192, c256 = ((tiles256 + 255) / 256) * 256;
     p.BM = 256;
     long best = c256;
-    if ((d->precision == 3 || d->precision == 4) && c192 < best) { p.BM = 192; best = c192; }
+    if (p.gl) { p.BM = 192; best = c192; }
+    else if ((d->precision == 3 || d->precision == 4) && c192 < best) { p.BM = 192; best = c192; }
     if (c128 < best) { p.BM = 128; best = c128; }
   }
   const long tiles = p.BM == 256 ? tiles256 : (p.BM == 192 ? tiles192 : tiles128);
-  p.k2 = d->precision == 4 && d->band == 0 && k2_enabled();
-  const int nk = p.k2 ? (p.Kp / BK + 1) / 2 : p.Kp / BK;       // barrier intervals of the K loop
+  const int nk32p = p.Kp / BK;
+  // barrier intervals of the K loop: gemm_gl_kernel 64 k (two parts) / 128 k (single part), gemm_pp_kernel 32 k (K2: 64)
+  const int nk = p.gl ? (d->precision == 4 ? (nk32p + 3) / 4 : (nk32p + 1) / 2) : (p.k2 ? (nk32p + 1) / 2 : nk32p);
   int ks = 1;
   // Split-K, re-measured in round 2 with tools/lab/ks_try*.sh (kernel + finish, operands packed): what matters is the
   // number of rounds -- a grid of exactly <= 256 workgroups beats a slightly larger one by 15-20 % (1024 x 1024 x 4608:
@@ -936,11 +1259,11 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
     if (tiles >= 176) {
       ks = 1;
     } else if (tiles >= 128) {
-      ks = nk / 32;
+      ks = nk / (p.gl ? 16 : 32);
       if (ks > 3) ks = 3;
     } else {
       ks = (int)(256 / tiles);
-      if (ks > nk / 8) ks = nk / 8;
+      if (ks > nk / (p.gl ? 4 : 8)) ks = nk / (p.gl ? 4 : 8);      // (the same 256 elements of K per split either way)
       if (ks > 16) ks = 16;
     }
     if (ks < 1) ks = 1;
@@ -948,7 +1271,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   // tuning overrides (tools/gemm_tune.py): VILCO_GEMM_BM = 128|256, VILCO_GEMM_KS = forced split count
   // (read once per process: the plan is made twice per launch)
   const int force_bm = tune().bm, force_ks = tune().ks;
-  if (force_bm == 128 || force_bm == 256 || (force_bm == 192 && d->precision >= 3)) p.BM = force_bm;
+  if (force_bm == 128 || (force_bm == 256 && !p.gl) || (force_bm == 192 && d->precision >= 3)) p.BM = force_bm;
   if (force_ks >= 1 && force_ks <= nk) ks = force_ks;
   p.kchunk = (nk + ks - 1) / ks;
   p.ksplit = (nk + p.kchunk - 1) / p.kchunk;
@@ -960,7 +1283,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   p.split_stride = out_span;
   p.part_bytes = p.ksplit > 1 ? align_up(out_span * p.ksplit * 4, 256) : 0;
   p.fixup = false;
-  if (p.ksplit > 1 && fixup_enabled()) {
+  if (p.ksplit > 1 && fixup_enabled() && !p.gl) {
     const long ntiles = tn * ((d->M + p.BM - 1) / p.BM) * nbatch;
     if (ntiles <= FIX_TILES) {      // slots [tile][split] of BM x 128 floats in the accumulators' register layout
       p.fixup = true;
@@ -982,6 +1305,25 @@ void launch_pp_km(const GArgs& g, dim3 grid, hipStream_t s) {
   }();
   (void)once;
   hipLaunchKernelGGL((gemm_pp_kernel<BM, NP, F16, AKM, BKM, K2>), grid, dim3(512), lds, s, g);
+}
+
+template <int BM, bool AKM, bool BKM, bool SINGLE>
+void launch_gl_km(const GArgs& g, dim3 grid, hipStream_t s) {
+  constexpr size_t lds = (size_t)4 * (BM + BN) * 128;          // two stages x two slots x (A + B) x 128 B
+  static const bool once = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_gl_kernel<BM, AKM, BKM, SINGLE>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    return true;
+  }();
+  (void)once;
+  hipLaunchKernelGGL((gemm_gl_kernel<BM, AKM, BKM, SINGLE>), grid, dim3(512), lds, s, g);
+}
+template <int BM, bool SINGLE>
+void launch_gl(const GArgs& g, dim3 grid, hipStream_t s, bool akm, bool bkm) {
+  if (akm && bkm) launch_gl_km<BM, true, true, SINGLE>(g, grid, s);
+  else if (bkm) launch_gl_km<BM, false, true, SINGLE>(g, grid, s);
+  else launch_gl_km<BM, false, false, SINGLE>(g, grid, s);
 }
 
 // operand orientations in use: (kc,kc) forward / convs, (kc,km) dX = dY W, (km,km) dW = dY^T X
@@ -1303,6 +1645,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   g.b.cols = 0;
   if (p.b_km) { g.b.row_stride = align_up(d->N, 32); g.b.cols = (int)align_up(d->N, 32); }
   if (p.tapkm) { g.b.row_stride = d->tapC; g.b.cols = d->N; }                            // X' seen as [rows][3 Cin], row stride Cin
+  g.a.bytes = 2 * (p.a_batch - (g.a.p - planesA)); g.b.bytes = 2 * p.b_batch;      // one part of one batch (gemm_gl_kernel's buffer range)
   g.ldc = d->ldc; g.M = d->M; g.N = d->N; g.Kp = p.Kp;
   g.batch_inner = d->batch_inner; g.sCo = d->sCo; g.sCi = d->sCi;
   g.tiles_n = (d->N + BN - 1) / BN;
@@ -1330,7 +1673,11 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
   {
     const bool ak = p.a_km, bk = p.b_km;
-    if (d->precision == 4 && p.k2) {  // one MFMA per product on the leading fp16 parts, two K-steps per barrier interval
+    if (p.gl) {
+      const bool single = d->precision == 4;
+      if (p.BM == 192) { if (single) launch_gl<192, true>(g, grid, s, ak, bk); else launch_gl<192, false>(g, grid, s, ak, bk); }
+      else { if (single) launch_gl<128, true>(g, grid, s, ak, bk); else launch_gl<128, false>(g, grid, s, ak, bk); }
+    } else if (d->precision == 4 && p.k2) {  // one MFMA per product on the leading fp16 parts, two K-steps per barrier interval
       if (p.BM == 256) launch_pp<256, 2, true, true>(g, grid, s, ak, bk);
       else if (p.BM == 192) launch_pp<192, 2, true, true>(g, grid, s, ak, bk);
       else launch_pp<128, 2, true, true>(g, grid, s, ak, bk);
@@ -1379,6 +1726,11 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
 // fixup_enabled()).  Both sum the splits in the same order: the results are bitwise equal (tests/test_ops_gpu.py).
 extern "C" int vilco_gemm_set_fixup(int32_t on) {
   fixup_enabled() = on != 0;
+  return VILCO_OK;
+}
+
+extern "C" int vilco_gemm_set_gl(int32_t on) {
+  gl_enabled() = on != 0;
   return VILCO_OK;
 }
 
