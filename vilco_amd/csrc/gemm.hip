@@ -88,6 +88,7 @@ struct GArgs {
 
 __device__ __forceinline__ long row_off(const PlaneOp& o, int r) {
   if (r >= o.rows) r = o.rows - 1;
+  if (o.seqT == 0x7fffffff) return (long)r * o.row_stride;          // (uniform: plain operands skip the division)
   return (long)(r / o.seqT) * o.seq_stride + (long)(r % o.seqT) * o.row_stride;
 }
 
@@ -276,35 +277,37 @@ __device__ __forceinline__ void gemm_epilogue(const GArgs& g, f32x4 (&acc)[MI][4
   }
   const bool partial = g.ksplit > 1 && !g.tile_ctr;
   float* cp = g.c + (partial ? (long)ks * g.split_stride : 0);
-  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (16 * EPI_LD);
+  // (round 5) ALL of the wave's blocks are staged first, then ONE rolled loop finishes them: the unrolled form was ~10 k
+  // instructions per kernel, more than the instruction cache keeps -- every launch re-fetched its set-up and epilogue code
+  // line by line (in-kernel stamps: 4.7 k cycles from entry to the first tile load, 3 k for an uncontended epilogue).
+  float* stg = reinterpret_cast<float*>(smem_raw) + wave * (16 * MI * EPI_LD);
   const int n = n0 + wn * 64 + (lane & 15) * 4;
   float am = 0.f;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) stg[((lane >> 4) * 4 + rr) * EPI_LD + j * 16 + (lane & 15)] = acc[i][j][rr];
+      for (int rr = 0; rr < 4; ++rr) stg[(i * 16 + (lane >> 4) * 4 + rr) * EPI_LD + j * 16 + (lane & 15)] = acc[i][j][rr];
+#pragma unroll 1
+  for (int it = 0; it < MI * 4; ++it) {
+    const int row = it * 4 + (lane >> 4);                       // row inside the wave tile (block it >> 2)
+    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 15) * 4);
+    const int m = m0 + wm * (16 * MI) + row;
+    if (m >= g.M || n >= g.N) continue;
+    const long idx = coff + (long)m * g.ldc + n;
+    if (partial) {
+      if (g.vec_out) *reinterpret_cast<f32x4*>(cp + idx) = v;
+      else
 #pragma unroll
-    for (int p4 = 0; p4 < 4; ++p4) {
-      const int row = p4 * 4 + (lane >> 4);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD + (lane & 15) * 4);
-      const int m = m0 + wm * (16 * MI) + i * 16 + row;
-      if (m >= g.M || n >= g.N) continue;
-      const long idx = coff + (long)m * g.ldc + n;
-      if (partial) {
-        if (g.vec_out) *reinterpret_cast<f32x4*>(cp + idx) = v;
-        else
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[idx + e] = v[e];
-      } else {
-        bool valid = g.e.row_len ? (m % g.e.rowT) < g.e.row_len[m / g.e.rowT] : true;
-        if (g.e.row_mask) valid = valid && g.e.row_mask[m] != 0.f;
-        if (g.vec_out) am = fmaxf(am, store_out4(g, idx, n, v, valid));
-        else
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) am = fmaxf(am, store_out(g, idx + e, n + e, v[e], valid));
-      }
+        for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[idx + e] = v[e];
+    } else {
+      bool valid = g.e.row_len ? (m % g.e.rowT) < g.e.row_len[m / g.e.rowT] : true;
+      if (g.e.row_mask) valid = valid && g.e.row_mask[m] != 0.f;
+      if (g.vec_out) am = fmaxf(am, store_out4(g, idx, n, v, valid));
+      else
+#pragma unroll 1
+        for (int e = 0; e < 4; ++e) if (n + e < g.N) am = fmaxf(am, store_out(g, idx + e, n + e, v[e], valid));
     }
   }
   if (g.amax_out && !partial) {     // max|C| of this tile for the operand pack of the next product (one float per workgroup)
@@ -1241,9 +1244,14 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
     const long c128 = ((tiles128 + 255) / 256) * 128, c192 = ((tiles192 + 255) / 256) * 192, c256 = ((tiles256 + 255) / 256) * 256;
     p.BM = 256;
     long best = c256;
-    if (p.gl) { p.BM = 192; best = c192; }
+    if (p.gl) {
+      // gemm_gl_kernel: a round of 128-row tiles takes 0.74 of a round of 192-row tiles, not 2/3 (measured, round 5:
+      // 4608 x 4096 x 1024 as 5 rounds of 128 rows 131 us, as 3 rounds of 192 rows 107 us; 8192^3 3.33 vs 2.74 ms)
+      p.BM = 192; best = c192;
+      if (((tiles128 + 255) / 256) * 142 < best) { p.BM = 128; best = 0; }
+    }
     else if ((d->precision == 3 || d->precision == 4) && c192 < best) { p.BM = 192; best = c192; }
-    if (c128 < best) { p.BM = 128; best = c128; }
+    if (!p.gl && c128 < best) { p.BM = 128; best = c128; }
   }
   const long tiles = p.BM == 256 ? tiles256 : (p.BM == 192 ? tiles192 : tiles128);
   const int nk32p = p.Kp / BK;
@@ -1295,7 +1303,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
 template <int BM, int NP, bool F16, bool AKM, bool BKM, bool K2 = false>
 void launch_pp_km(const GArgs& g, dim3 grid, hipStream_t s) {
   constexpr size_t a_el = AKM ? 32 * ((BM == 192 ? 256 : BM) + 16) : BM * 32, b_el = BKM ? 32 * (BN + 16) : BN * 32;
-  constexpr size_t pipe = (size_t)2 * NP * (a_el + b_el) * sizeof(__bf16), epi = (size_t)8 * 16 * EPI_LD * 4;
+  constexpr size_t pipe = (size_t)2 * NP * (a_el + b_el) * sizeof(__bf16), epi = (size_t)8 * 16 * (BM / 64) * EPI_LD * 4;
   constexpr size_t lds = pipe > epi ? pipe : epi;
   static const bool once = [] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<BM, NP, F16, AKM, BKM, K2>),
