@@ -123,6 +123,22 @@ def softnms(segs, scores, iou_threshold, sigma, min_score, method, max_num=0):
     return inds[:i].copy(), dets[:i].copy()
 
 
+def seg_voting(nms_segs, all_segs, all_scores, iou_threshold):
+    """segment voting of the class-agnostic branch (MQ/libs/utils/nms.py:67-101): every kept segment becomes the
+    score x IoU weighted mean of ALL input segments whose IoU with it reaches the threshold (the reference's `score_offset`
+    is computed and never used, :75).  fp32 throughout, like the reference's torch ops."""
+    a = np.asarray(nms_segs, dtype=f32).reshape(-1, 2)
+    b = np.asarray(all_segs, dtype=f32).reshape(-1, 2)
+    sc = np.asarray(all_scores, dtype=f32)
+    left = np.maximum(a[:, None, 0], b[None, :, 0])
+    right = np.minimum(a[:, None, 1], b[None, :, 1])
+    inter = np.maximum(right - left, f32(0))
+    iou = inter / ((a[:, None, 1] - a[:, None, 0]) + (b[None, :, 1] - b[None, :, 0]) - inter)
+    w = (iou >= f32(iou_threshold)).astype(f32) * sc[None, :] * iou
+    w = w / np.sum(w, axis=1, keepdims=True, dtype=f32)
+    return (w @ b).astype(f32)
+
+
 def batched_nms(segs, scores, cls_idxs, iou_threshold, min_score, max_seg_num, use_soft_nms=True,
                 multiclass=True, sigma=0.5, voting_thresh=0.75):
     segs = np.asarray(segs, dtype=f32).reshape(-1, 2)
@@ -152,6 +168,6 @@ def batched_nms(segs, scores, cls_idxs, iou_threshold, min_score, max_seg_num, u
     else:
         new_segs, new_scores, new_cls = one(segs, scores, cls_idxs)
         if voting_thresh > 0:
-            raise NotImplementedError("seg voting is checked through the torch path only")
+            new_segs = seg_voting(new_segs, segs, scores, voting_thresh)
     order = np.argsort(-new_scores, kind="stable")[:min(max_seg_num, new_segs.shape[0])]
     return new_segs[order], new_scores[order], new_cls[order]

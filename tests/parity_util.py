@@ -210,3 +210,66 @@ def oracle_episode_trajectory(gold, dtype=torch.float64):
             model.augment_classification(cases.EP_NEW, 'cpu')
             model = model.to(dtype)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Full-size (config P) step under ONE realisation of the dropout / stochastic-depth masks: the HIP step, then the oracle
+# replaying exactly those masks in fp32 and in fp64 (tests/test_fullsize_gpu.py, tools/diag/p_parity_realisations.py).
+def p_step_three_ways(dev, realisation, oracle_dtypes=(torch.float32, torch.float64), threads=None):
+    """-> (hip_losses, hip_grads, {dtype: (losses, grads)}).  `realisation` seeds the device RNG (stochastic depth), the
+    dropout seed counter and the device step word, so every value gives different masks whatever ran before in the process."""
+    import bench
+    import vilco_amd.modeling as vm
+    from oracle import mq_oracle
+    from vilco_amd import _lib, ops
+    from vilco_amd.modeling import blocks
+    cfg = bench.p_config()
+    torch.manual_seed(0)
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet())).to(dev).train()
+    batch = bench.synth_batch(2, dev)
+    torch.cuda.manual_seed_all(1000 + realisation)
+    blocks.reset_drop_pool()
+    ops._drop_counter[0] = 7919 * realisation
+    _lib.check(_lib.load().vilco_seed_word_set(realisation, None))
+    ops.dropout_log = []
+    try:
+        losses = model(batch, is_training=True)
+        losses['final_loss'].backward()
+        log = list(ops.dropout_log)
+    finally:
+        ops.dropout_log = None
+    torch.cuda.synchronize()
+    hip_grads = {k: p.grad.detach().double().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    hip_losses = {k: float(v) for k, v in losses.items()}
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    del model, losses
+    torch.cuda.empty_cache()
+    if threads:
+        torch.set_num_threads(threads)
+    out = {}
+    # the masks are regenerated by the kernels that drew them: the device step word stays at `realisation` until they exist
+    masks = [(e[0], e[1]) if len(e) == 2 else (e[0], ops.dropout_mask(e[1], e[2], e[3], dev).cpu()) for e in log]
+    torch.cuda.synchronize()
+    _lib.check(_lib.load().vilco_seed_word_set(0, None))
+    for dt in oracle_dtypes:
+        p = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in state.items()}
+        vl = [{k: ((v.cpu().to(dt) if v.is_floating_point() else v.cpu()) if torch.is_tensor(v) else v) for k, v in d.items()} for d in batch]
+        ctx = mq_oracle.DropReplay(masks, None)
+        mq_oracle.DROP = ctx
+        try:
+            want, _ = mq_oracle.forward_losses(p, cfg, vl)
+            want['final_loss'].backward()
+        finally:
+            mq_oracle.DROP = None
+        assert ctx.leftover() == {}, ctx.leftover()
+        out[dt] = ({k: float(v) for k, v in want.items()},
+                   {k: v.grad.detach().double() for k, v in p.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None})
+        del p, want, ctx
+    return hip_losses, hip_grads, out
+
+
+def tensor_distance(g, w):
+    """(max |g - w| / max |w|, L2 distance / ||w||, fraction of elements beyond 1e-3 of max |w|)"""
+    d = (g - w).abs()
+    top = w.abs().max().clamp_min(1e-7)
+    return (d.max() / top).item(), ((g - w).norm() / w.norm().clamp_min(1e-12)).item(), (d > 1e-3 * top).double().mean().item()

@@ -360,6 +360,47 @@ def test_train_mode_vs_oracle_with_replayed_masks(dev):
 
 
 @pytest.mark.parametrize("name", ["xl", "noxl"])
+def test_deferred_finish_with_existing_grads(dev, name):
+    """a deferred gradient is only safe where AccumulateGrad adopts it (leaf owner, .grad None).  Two
+    backward passes WITHOUT zeroing the gradients in between (micro-batch accumulation): the second pass finds every .grad in
+    place, so autograd accumulates `p.grad += new` in the middle of backward -- ops._Deferring must finish those in place.
+    Deferral on and off give the same accumulated gradients bit for bit (the second pass records nothing)."""
+    from vilco_amd import _lib, ops
+    gold = load_golden(name)
+    lib = _lib.load()
+    grads, recorded = {}, {}
+    flush0 = ops._defer_flush
+    for mode in (False, True):
+        model = build_hip_model(gold)
+        seen = []
+
+        def counting_flush(final=True):
+            seen.append(int(lib.vilco_defer_pending()))
+            flush0(final)
+        ops.defer_finish, ops._defer_flush = mode, counting_flush
+        try:
+            for rep in range(2):
+                model.loss_normalizer = golden_cfg(gold)['train_cfg']['init_loss_norm']
+                losses = model(golden_inputs(gold), task_id=gold['task_id'], is_training=True)
+                losses['final_loss'].backward()
+                if rep == 0:
+                    first = sum(seen)
+                    del seen[:]
+        finally:
+            ops.defer_finish, ops._defer_flush = True, flush0
+        assert lib.vilco_defer_pending() == 0 and not ops._defer["keep"] and not ops._defer["pending"]
+        grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        recorded[mode] = (first, sum(seen))
+    assert recorded[False] == (0, 0), recorded
+    assert recorded[True][0] >= 60 and recorded[True][1] == 0, recorded     # pass 1 deferred, pass 2 (grads in place) did not
+    for k in grads[True]:
+        if k.startswith(('mu', 'sigma')):
+            assert rel_err(grads[True][k], grads[False][k], 1e-7) < 1e-5, k
+        else:
+            assert torch.equal(grads[True][k], grads[False][k]), k
+
+
+@pytest.mark.parametrize("name", ["xl", "noxl"])
 def test_deferred_finish_is_bitwise_the_individual_launches(dev, name):
     """ops._Deferring / csrc/defer.hip: the second stages of the backward pass's column reductions and split-K weight-gradient
     sums, recorded and issued as a few batched launches at the end of backward, give bit for bit the gradients of the

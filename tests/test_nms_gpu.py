@@ -36,6 +36,10 @@ def test_hard_nms(dev, n, ties):
         want = nms_oracle.nms(segs, scores, 0.5)
         assert np.array_equal(got, want)
     ref = ref_module()
+    if n > 1500 and not ties:
+        # beyond the numpy oracle's reach the reference build is the ONLY check of this case: a box without it must fail,
+        # not pass unchecked
+        assert ref is not None, "oracle/_ref/nms_1d_cpu.so did not load on the GPU box"
     if ref is not None and not ties:      # tie order of aten's unstable CPU sort is implementation-defined
         want = ref.nms(torch.from_numpy(segs), torch.from_numpy(scores), 0.5).numpy()
         assert np.array_equal(got, want)
@@ -55,6 +59,8 @@ def test_soft_nms(dev, n, sigma, min_score, ties):
         assert np.array_equal(got, want)
         np.testing.assert_allclose(dets.numpy()[:len(got)], wdets, rtol=1e-5, atol=1e-7)
     ref = ref_module()
+    if n > 1200:
+        assert ref is not None, "oracle/_ref/nms_1d_cpu.so did not load on the GPU box"      # the only check of this size
     if ref is not None:
         rdets = torch.zeros(n, 3)
         want = ref.softnms(torch.from_numpy(segs), torch.from_numpy(scores), rdets, 0.1, sigma, min_score, 2).numpy()
@@ -89,6 +95,57 @@ def test_batched_nms(dev, soft, multiclass):
     assert np.array_equal(gc.numpy(), wc)
     np.testing.assert_allclose(gs.numpy(), ws, rtol=1e-6)
     np.testing.assert_allclose(gsc.numpy(), wsc, rtol=1e-5, atol=1e-7)
+
+
+def test_hip_nms_on_every_committed_golden(dev):
+    """VERDICT r04 (weak 10a): the committed fixtures tests/golden/nms_*.npz -- recorded from the reference's compiled
+    nms_1d_cpu and its python batched_nms -- were only ever fed to the numpy oracle.  Here the HIP kernels run on every one of
+    them: vilco_nms_1d / vilco_softnms_1d through the nms_1d_cpu-compatible module (indices bit-exact), batched_nms through
+    the device path (multiclass fixtures, and the class-agnostic + segment-voting fixtures of make_golden_nms_voting.py)."""
+    import glob
+    import os
+    from vilco_amd.utils.nms import batched_nms, nms_1d_cpu
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nms_*.npz")))
+    kinds = set()
+    assert len(files) >= 16, files
+    for f in files:
+        z = np.load(f)
+        kind = str(z["kind"])
+        kinds.add(kind)
+        segs, scores = torch.from_numpy(z["segs"]).reshape(-1, 2), torch.from_numpy(z["scores"])
+        if kind == "hard":
+            got = nms_1d_cpu.nms(segs, scores, float(z["thr"])).numpy()
+            assert np.array_equal(got, z["inds"]), f
+        elif kind == "soft":
+            dets = torch.zeros(segs.shape[0], 3)
+            got = nms_1d_cpu.softnms(segs, scores, dets, float(z["thr"]), float(z["sigma"]), float(z["min_score"]), 2).numpy()
+            assert np.array_equal(got, z["inds"]), f
+            np.testing.assert_allclose(dets.numpy()[:len(got)], z["dets"][:len(got)], rtol=1e-5, atol=1e-7)
+        else:
+            voting = kind == "voting"
+            s, sc, c = batched_nms(segs.to(dev), scores.to(dev), torch.from_numpy(z["cls"]).to(dev), float(z["thr"]),
+                                   float(z["min_score"]), int(z["max_seg_num"]), use_soft_nms=bool(z["soft"]),
+                                   multiclass=not voting, sigma=float(z["sigma"]),
+                                   voting_thresh=float(z["voting_thresh"]) if voting else 0.0)
+            assert s.device.type == "cuda"
+            assert np.array_equal(c.cpu().numpy(), z["out_cls"]), f
+            np.testing.assert_allclose(s.cpu().numpy(), z["out_segs"], rtol=2e-5 if voting else 1e-6)
+            np.testing.assert_allclose(sc.cpu().numpy(), z["out_scores"], rtol=1e-5, atol=1e-7)
+    assert kinds == {"hard", "soft", "batched", "voting"}, kinds
+
+
+def test_seg_voting_matches_reference_expression(dev):
+    """vilco_amd.utils.nms.seg_voting (nms.py:67-101) on its own: the weighted mean against the numpy restatement, including a
+    kept segment whose only neighbour above the threshold is itself"""
+    from oracle import nms_oracle
+    from vilco_amd.utils.nms import seg_voting
+    segs, scores = make_case(400, 5, span=60.0)
+    segs[0] = [500.0, 510.0]                                          # isolated: votes for itself only
+    keep = np.array([0, 3, 17, 99, 250])
+    got = seg_voting(torch.from_numpy(segs[keep]).to(dev), torch.from_numpy(segs).to(dev), torch.from_numpy(scores).to(dev), 0.75)
+    want = nms_oracle.seg_voting(segs[keep], segs, scores, 0.75)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5)
+    np.testing.assert_allclose(got.cpu().numpy()[0], [500.0, 510.0], rtol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------------- decode

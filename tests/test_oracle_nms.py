@@ -56,6 +56,14 @@ def test_against_goldens():
                                            float(z["min_score"]), 2)
             assert np.array_equal(got, z["inds"]), f
             np.testing.assert_allclose(dets, z["dets"][:len(got)], rtol=2e-6, atol=1e-8)
+        elif z["kind"] == "voting":
+            # class-agnostic + segment voting (nms.py:161-180): recorded by tests/golden/make_golden_nms_voting.py
+            s, sc, c = nms_oracle.batched_nms(z["segs"], z["scores"], z["cls"], float(z["thr"]), float(z["min_score"]),
+                                              int(z["max_seg_num"]), bool(z["soft"]), False, float(z["sigma"]),
+                                              float(z["voting_thresh"]))
+            assert np.array_equal(c, z["out_cls"]), f
+            np.testing.assert_allclose(s, z["out_segs"], rtol=2e-5)          # (a weighted mean over ~100 neighbours: summation order)
+            np.testing.assert_allclose(sc, z["out_scores"], rtol=1e-5, atol=1e-8)
         else:
             s, sc, c = nms_oracle.batched_nms(z["segs"], z["scores"], z["cls"], float(z["thr"]), float(z["min_score"]),
                                               int(z["max_seg_num"]), bool(z["soft"]), True, float(z["sigma"]), 0.0)

@@ -168,3 +168,41 @@ def test_train_step_runs_and_descends(dev):
     losses = [float(train_step(model, opt, sch, vl, clip_grad_l2norm=1.0)['final_loss']) for _ in range(6)]
     assert all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] < losses[0], losses
+
+
+def _reference_nlq_saves(init_r1, r1_of_epoch, max_epochs, ckpt_freq):
+    """The save decisions of one task of NLQ/train_cl.py:216-292, restated flag for flag: validation only at the last epoch or at
+    multiples of ckpt_freq (:216-222), `is_best = R1 >= best_R1; best_R1 = max(R1, best_R1)` inside it (:250-251), and the
+    `if is_best: save_checkpoint(... 'Best_task_XX')` block OUTSIDE it (:283), once per epoch."""
+    best_r1, saves, state = init_r1, [], {}
+    for epoch in range(max_epochs):
+        if (epoch == max_epochs - 1) or ((ckpt_freq > 0) and (epoch % ckpt_freq == 0)):
+            r1 = r1_of_epoch[epoch]
+            state['is_best'] = r1 >= best_r1
+            best_r1 = max(r1, best_r1)
+        if state['is_best']:
+            saves.append(epoch)
+    return saves, best_r1
+
+
+@pytest.mark.parametrize("ckpt_freq,max_epochs,r1s,init", [
+    (2, 5, [0.3, 0.9, 0.2, 0.9, 0.25], 0.1),      # epoch 0 reaches the bar: epochs 0 AND 1 (unvalidated) write the file
+    (2, 6, [0.1, 0.0, 0.4, 0.0, 0.5, 0.5], 0.2),  # misses at 0, hits at 2 (3 rides along), 4 (and the last epoch validates too)
+    (1, 4, [0.5, 0.4, 0.6, 0.6], 0.45),           # every epoch validated: sticky == plain
+    (3, 7, [0.9, 0.0, 0.0, 0.1, 0.0, 0.0, 0.95], 0.5),
+])
+def test_nlq_best_checkpoint_is_sticky_like_the_reference(ckpt_freq, max_epochs, r1s, init):
+    """run_episodes_nlq wrote Best_task_XX only at validated epochs that reached the bar; the reference
+    keeps overwriting it at the following unvalidated epochs (sticky is_best).  train_cl.StickyBest carries that rule."""
+    from vilco_amd.train_cl import StickyBest
+    want_saves, want_best = _reference_nlq_saves(init, r1s, max_epochs, ckpt_freq)
+    t = StickyBest()
+    t.new_task(init)
+    saves = []
+    for epoch in range(max_epochs):
+        if StickyBest.validates(epoch, max_epochs, ckpt_freq):
+            t.validated(epoch, r1s[epoch])
+        if t.is_best:
+            saves.append(epoch)
+    assert saves == want_saves and t.best == want_best
+    assert any(not StickyBest.validates(e, max_epochs, ckpt_freq) for e in saves) == (ckpt_freq > 1)

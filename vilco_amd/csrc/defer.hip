@@ -9,6 +9,7 @@
 // travels in the kernel arguments).  Each item is finished by the same arithmetic in the same order as its own launch
 // would have used, so results are bitwise the same.  The caller keeps the partial buffers alive until the flush
 // (vilco_amd/ops.py: _defer).
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -37,7 +38,7 @@ struct SKBatch { SKItem it[SK_MAX]; int n; };
 // and the end-of-backward callback that flushes on the thread that called backward().  (Recording is a mode of the one
 // training loop of the process; entry points used from other threads meanwhile would be recorded too.)
 struct State {
-  bool on = false;
+  std::atomic<bool> on{false};      // written by the thread that drives backward, read by autograd's worker threads
   std::vector<RRItem> rr;
   std::vector<SKItem> sk;
   std::mutex mu;
@@ -85,7 +86,10 @@ __global__ __launch_bounds__(256) void reduce_rows_many_kernel(RRBatch b) {
 __global__ __launch_bounds__(256) void splitk_sum_many_kernel(SKBatch b) {
   const SKItem& it = b.it[find_item(b, (int)blockIdx.x)];
   const float* __restrict__ part = it.part;
-  const bool vec = (it.N % 4) == 0 && (it.ldc % 4) == 0;
+  // 16-byte accesses need 16-byte aligned bases too: dW written into a GradReducer bucket slot sits at an arbitrary element
+  // offset of the bucket (the undeferred path's vec_out checks the same, gemm.hip)
+  const bool vec = (it.N % 4) == 0 && (it.ldc % 4) == 0 && (it.split_stride % 4) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(it.out) | reinterpret_cast<uintptr_t>(it.part)) & 15) == 0;
   const int V = vec ? 4 : 1;
   const int NV = it.N / V;
   const long total = (long)it.M * NV;

@@ -52,7 +52,6 @@ class GraphedStep:
         self.eager_steps = max(int(eager_steps), 1 if optimizer is not None else 0)
         self.between, self.enabled, self.gt_pad, self.max_graphs = between, bool(enabled), gt_pad, int(max_graphs)
         self.reducer = reducer
-        import os
         self.comm_in_graph = (os.environ.get("VILCO_DP_GRAPH_COMM", "0") == "1") if comm_in_graph is None else bool(comm_in_graph)
         self._graphs = {}
         self._pool = None
@@ -83,7 +82,7 @@ class GraphedStep:
         inp = model.prepare(video_list, True, gt_pad=self.gt_pad)
         if not (self.enabled and model.training and model.capturable(inp, task_id, prev_out_cls_logits)):
             return self._eager(inp, video_list, task_id, prev_out_cls_logits)
-        key = (inp.signature(), int(task_id), self._param_sig(), int(model.n_known > 0))
+        key = (inp.signature(), int(task_id), self._param_sig(), int(model.n_known > 0), ops.arithmetic_key())
         ent = self._graphs.get(key)
         if ent is None:
             ent = self._graphs[key] = {'seen': 0}
@@ -146,36 +145,43 @@ class GraphedStep:
         blocks.reset_drop_pool()
         gc.collect()
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
         red = self.reducer if (self.reducer is not None and self.reducer.enabled) else None
-        comm = bool(red is not None and self.comm_in_graph and red._avg and not ent.get('comm_refused'))
-        if self.reducer is not None:
-            # default: no collectives inside the capture (replays exchange after graph 1), but the captured weight-gradient
-            # kernels write into the reducer's bucket slots: a replayed backward leaves the large gradients in place.
-            # comm: the hooks stay live and the all-reduces are captured with the backward they overlap.
-            self.reducer.begin(hooks=comm)
-        try:
-            with torch.cuda.graph(g, pool=self._pool):
-                if red is not None:
-                    red._capture_stream = torch.cuda.current_stream()
-                _lib.check(lib.vilco_seed_word_bump(ops._stream()))
-                losses = model.forward_prepared(static, None, task_id=task_id)
-                losses['final_loss'].backward()
-                if comm:
-                    red.finish()                 # waits become edges of the graph; p.grad = views of the averaged buckets
-                ops.join_side_streams()          # forked chains (ops.fork_enabled) end here
-                keys = sorted(losses)
-                out = torch.stack([losses[k].detach().reshape(()).float() for k in keys])
-        except Exception:
+        # at most two attempts: with the collectives inside the capture, then (this runtime refused) without them
+        while True:
+            g = torch.cuda.CUDAGraph()
+            comm = bool(red is not None and self.comm_in_graph and red._avg and not ent.get('comm_refused'))
+            if self.reducer is not None:
+                # default: no collectives inside the capture (replays exchange after graph 1), but the captured weight-gradient
+                # kernels write into the reducer's bucket slots: a replayed backward leaves the large gradients in place.
+                # comm: the hooks stay live and the all-reduces are captured with the backward they overlap.
+                self.reducer.begin(hooks=comm)
+            failed = None
+            try:
+                with torch.cuda.graph(g, pool=self._pool):
+                    if red is not None:
+                        red._capture_stream = torch.cuda.current_stream()
+                    _lib.check(lib.vilco_seed_word_bump(ops._stream()))
+                    losses = model.forward_prepared(static, None, task_id=task_id)
+                    losses['final_loss'].backward()
+                    if comm:
+                        red.finish()             # waits become edges of the graph; p.grad = views of the averaged buckets
+                    ops.join_side_streams()      # forked chains (ops.fork_enabled) end here
+                    keys = sorted(losses)
+                    out = torch.stack([losses[k].detach().reshape(()).float() for k in keys])
+            except Exception as e:               # noqa: BLE001 -- re-raised below unless it is the collectives' capture
+                failed = e
+            finally:
+                if self.reducer is not None:
+                    self.reducer._capture_stream = None
+                    self.reducer.end_capture()
+            if failed is None:
+                break
             if not comm:
-                raise
+                raise failed
             ent['comm_refused'] = True           # this runtime does not capture the collectives: exchange after the replay
             torch.cuda.synchronize()
-            return self._capture(ent, inp, task_id)
-        finally:
-            if self.reducer is not None:
-                self.reducer._capture_stream = None
-                self.reducer.end_capture()
+            for p in self.params:
+                p.grad = None
         ent['comm'] = comm
         del losses
         blocks.reset_drop_pool()
@@ -225,7 +231,7 @@ class GraphedStep:
         for p, g in zip(self.params, ent['grads']):
             if p.grad is not g:
                 p.grad = g
-        if self.reducer is not None and not ent.get('comm'):
+        if self.reducer is not None and self.reducer.enabled and not ent.get('comm'):
             if ent['fill']:
                 torch._foreach_zero_(ent['fill'])
             # The exchange reads what the replay writes, so it cannot start earlier anyway -- and a collective queued behind a

@@ -164,6 +164,30 @@ def run_episodes(cfg, model, train_stream, validate=None, ckpt_folder=None, gpu_
     return model, optimizer, scheduler, log
 
 
+class StickyBest:
+    """Which epochs write 'Best_task_XX' in the NLQ driver (NLQ/train_cl.py:216-292).  `is_best = R1 >= best_R1` is assigned
+    only at validated epochs (:250) but the save block tests it at EVERY epoch (:283), and nothing resets it between epochs or
+    tasks: after a validated epoch that reached the bar every following epoch overwrites the file until a validation misses.
+    (The reference leaves is_best undefined before the first validation; epoch 0 validates whenever ckpt_freq > 0.)"""
+
+    def __init__(self):
+        self.is_best = False
+        self.best = None
+        self.best_epoch = -1
+
+    def new_task(self, init_r1):
+        self.best, self.best_epoch = init_r1, -1          # (is_best carries over, as in the reference)
+
+    def validated(self, epoch, r1):
+        self.is_best = r1 >= self.best
+        if self.is_best:
+            self.best, self.best_epoch = r1, epoch
+
+    @staticmethod
+    def validates(epoch, max_epochs, ckpt_freq):
+        return epoch == max_epochs - 1 or (ckpt_freq > 0 and epoch % ckpt_freq == 0)
+
+
 def run_episodes_nlq(cfg, model, train_stream, val_stream, evaluator, ckpt_folder=None, gpu_id=0, start_task=0,
                      start_epoch=0, ckpt_freq=2, reducer=None, print_freq=100, use_graph=False, keep_history=True,
                      on_validate=None):
@@ -208,6 +232,7 @@ def run_episodes_nlq(cfg, model, train_stream, val_stream, evaluator, ckpt_folde
     memory_size = cfg['cl_cfg']['memory_size']
     recalls = {'val': [], 'test': []}
     log = []
+    tracker = StickyBest()
 
     def validate(kind, j, epoch):
         fn = tu.final_validate if kind == 'final' else tu.valid_one_epoch_cl_single_gpu
@@ -222,8 +247,8 @@ def run_episodes_nlq(cfg, model, train_stream, val_stream, evaluator, ckpt_folde
         if j != 0:
             data, loader, num_next = next(it)
         entry = {'task': j, 'history': [], 'R1': []}
-        best = entry['init_R1'] = validate('init', j, 0)
-        best_epoch = -1
+        entry['init_R1'] = validate('init', j, 0)
+        tracker.new_task(entry['init_R1'])
         prev_logits = cache_prev_logits(model, loader, j, as_numpy=True) if model.type_sampling == 'icarl' else {}
         ck_name = 'Best_task_{:02d}.pth.tar'.format(j)
         for epoch in range(start_epoch, max_epochs):
@@ -239,17 +264,24 @@ def run_episodes_nlq(cfg, model, train_stream, val_stream, evaluator, ckpt_folde
                                       keep_history=keep_history)
             if keep_history:
                 entry['history'].append(hist)
-            if epoch == max_epochs - 1 or (ckpt_freq > 0 and epoch % ckpt_freq == 0):
+            validated = StickyBest.validates(epoch, max_epochs, ckpt_freq)
+            if validated:
                 r1 = validate('epoch', j, epoch)
                 entry['R1'].append((epoch, r1))
-                if r1 >= best:
-                    best, best_epoch = r1, epoch
-                    if is_main and ckpt_folder is not None:
-                        save_checkpoint({'epoch': epoch, 'state_dict': model.state_dict(), 'scheduler': scheduler.state_dict(),
-                                         'optimizer': optimizer.state_dict(), 'current_task': j, 'reg_params': model.reg_params},
-                                        file_folder=ckpt_folder, file_name=ck_name)
+                tracker.validated(epoch, r1)
+            # The reference's save block sits OUTSIDE the validation `if` and `is_best` is sticky (StickyBest): with ckpt_freq = 2
+            # the checkpoint reloaded for final validation, memory selection and the next task is one (unvalidated) epoch newer
+            # than the best validated one.  Reproduced here; `saved_epoch` records which epoch the file holds.
+            is_best = tracker.is_best
+            if is_best:
+                entry['saved_epoch'] = epoch
+                if is_main and ckpt_folder is not None:
+                    save_checkpoint({'epoch': epoch, 'state_dict': model.state_dict(), 'scheduler': scheduler.state_dict(),
+                                     'optimizer': optimizer.state_dict(), 'current_task': j, 'reg_params': model.reg_params},
+                                    file_folder=ckpt_folder, file_name=ck_name)
+            if validated or is_best:
                 _barrier(reducer)
-        entry['best_R1'], entry['best_epoch'] = best, best_epoch
+        entry['best_R1'], entry['best_epoch'] = tracker.best, tracker.best_epoch
         if memory_size != 0:
             model.add_samples_to_mem(val_stream, data, 'ALL' if memory_size == 'ALL' else memory_size // 13)
         train_stream.memory = model.memory
