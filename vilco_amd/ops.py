@@ -213,6 +213,46 @@ def _defer_flush(final=True):
         st["seen"].clear()
 
 
+# ---- debug-mode dynamic-range check of the backward operands.  The fp16 x2 planes carry ONE power-of-two
+# scale per tensor: 22 bits for every element within ~2^16 of the tensor's maximum, fewer below, nothing below 2^-40 of it.
+# A gradient tensor whose ROWS span more than that (the mask-ignoring channel attention of a twice-applied stem block: the
+# first padded row at ~1e10 x the rest) needs the bf16 x3 format (8 exponent bits per element).  The model marks
+# the one site it knows statically (ChannelAttention.wide_range); this check finds such tensors wherever they arise:
+#   VILCO_RANGE_CHECK=warn   every Linear backward measures max-row / median-row amax of dZ (a host sync: debug mode only),
+#                            records (M, N, K, spread) in ops.range_events and warns once per shape above 2^20;
+#   VILCO_RANGE_CHECK=auto   ... and runs that call's two backward products in bf16 x3.
+range_check = os.environ.get("VILCO_RANGE_CHECK", "0")
+RANGE_SPREAD_LIMIT = float(2 ** 20)
+range_events = []
+_range_warned = set()
+
+
+def _row_spread(t2d):
+    """max row amax / median of the non-zero row amaxes of a [rows, cols] tensor (1.0 for an all-zero tensor)"""
+    ra = t2d.abs().amax(dim=1)
+    nz = ra[ra > 0]
+    if nz.numel() == 0:
+        return 1.0
+    return float(ra.max() / nz.median())
+
+
+def _range_wide(dz, M, N, K):
+    if range_check not in ("warn", "auto") or _precision != 3 or torch.cuda.is_current_stream_capturing():
+        return False
+    spread = _row_spread(dz.reshape(M, N))
+    if spread <= RANGE_SPREAD_LIMIT:
+        return False
+    range_events.append((int(M), int(N), int(K), spread))
+    if (M, N, K) not in _range_warned:
+        _range_warned.add((M, N, K))
+        import warnings
+        warnings.warn("vilco_amd: the output gradient of a Linear [%d x %d] <- [%d x %d] spans a row-amax spread of %.3g (> 2^20): "
+                      "one fp16 x2 scale per tensor cannot carry it; %s" %
+                      (M, N, M, K, spread, "running its backward products in bf16 x3" if range_check == "auto"
+                       else "mark the call site (bwd_precision=2) or run with VILCO_RANGE_CHECK=auto"))
+    return range_check == "auto"
+
+
 class _Deferring:
     def __init__(self, *params):
         self.ptrs = [p.data_ptr() for p in params if p is not None]
@@ -666,6 +706,10 @@ class _Linear(torch.autograd.Function):
             dz, db = dy, (colsum(dy.view(M, N), param=b) if need_db else None)
         dx = dw = None
         prec = None
+        if ctx.bwd_precision is None and range_check != "0" and _range_wide(dz if dz is not None else dy, M, N, K):
+            if dz is None:                 # (the producer wrote planes only: this call needs the fp32 tensor after all)
+                dz = _act_bwd(dy, aux, ctx.act, lens, ctx.T, False, ctx.drop)[0]
+            ctx.bwd_precision = 2
         if ctx.bwd_precision is not None:
             # a call site whose gradient tensors span more exponent range than one scale per tensor can carry (see
             # `wide_range` in modeling/blocks.py: ChannelAttention): both backward products from the fp32 tensors, in the
