@@ -127,6 +127,12 @@ typedef struct vilco_gemm_desc {
 
 size_t vilco_gemm_workspace(const vilco_gemm_desc* d);
 int vilco_gemm(const vilco_gemm_desc* d, void* stream);
+/* n (1..4) INDEPENDENT products of one shape / orientation / format as ONE launch (round 5: the q / k / v projections of an
+ * attention block -- MQ/libs/modeling/blocks.py:332-344 -- forward and dX; each alone is a 75 %-full round of tiles on 256 CUs).
+ * Requires packed operands (a_planes / b_planes), precision 3, no batch / tap / band, equal M, N, K and orientations, and a
+ * plan without split-K; anything else runs as n vilco_gemm calls in order.  Same arithmetic either way.  VILCO_GEMM_GROUP=0:
+ * always ungrouped. */
+int vilco_gemm_group(const vilco_gemm_desc* descs, int32_t n, void* stream);
 
 /* Timing of the MFMA kernel alone (not the packs, not the split-K reduce): between begin and end every vilco_gemm   */
 /* brackets its main kernel with HIP events on the caller's stream; end waits for them and returns the sum.          */

@@ -127,6 +127,44 @@ def test_range_check_finds_wide_gradients_and_switches_format(dev, monkeypatch):
     assert ops.range_events == []
 
 
+@pytest.mark.parametrize("M,N,K", [(4608, 1024, 1024), (600, 320, 256), (154, 1024, 1024)])
+def test_linear_group_is_bitwise_the_individual_layers(dev, M, N, K):
+    """ops.linear_group / vilco_gemm_group (round 5): the q / k / v projections of an attention block as ONE grouped launch each
+    way (forward, dX).  The grouped kernel runs the same body per product: outputs and every gradient bit for bit those of
+    three ops.linear calls -- at the P shape (192-row tiles, grouped), at a small shape, and at a shape whose plan splits K
+    (M = 154: the library falls back to three launches)."""
+    from vilco_amd import ops
+    torch.manual_seed(3)
+    xs = [torch.randn(2, M // 2, K) for _ in range(3)]
+    ws = [torch.randn(N, K, 1) / math.sqrt(K) for _ in range(3)]
+    bs = [torch.randn(N) for _ in range(3)]
+    dys = [torch.randn(2, M // 2, N).to(dev) for _ in range(3)]
+    res = {}
+    for grouped in (False, True):
+        X = [x.to(dev).requires_grad_(True) for x in xs]
+        W = [w.to(dev).requires_grad_(True) for w in ws]
+        Bs = [b.to(dev).requires_grad_(True) for b in bs]
+        if grouped:
+            Y = ops.linear_group(X, W, Bs)
+        else:
+            Y = [ops.linear(x, w, b) for x, w, b in zip(X, W, Bs)]
+        torch.autograd.backward(Y, dys)
+        res[grouped] = ([y.detach().clone() for y in Y], [t.grad.clone() for t in X + W + Bs])
+    for a, b in zip(res[True][0] + res[True][1], res[False][0] + res[False][1]):
+        assert torch.equal(a, b)
+    want = xs[1].double() @ ws[1].double().squeeze(-1).t() + bs[1].double()
+    assert rel(res[True][0][1].cpu(), want.float()) < TOL_GEMM
+    # the outputs carry their max|y| partials for the pack of the next product, like ops.linear's
+    Y = ops.linear_group([x.to(dev) for x in xs], [w.to(dev) for w in ws], [b.to(dev) for b in bs])
+    for y in Y:
+        parts, n = ops._amax_of(y)
+        if parts is not None:
+            assert abs(float(parts[:n].max()) - float(y.abs().max())) == 0.0
+    # unequal shapes: plain per-layer path
+    Y2 = ops.linear_group([xs[0].to(dev), xs[1][:, :7].contiguous().to(dev)], [w.to(dev) for w in ws[:2]], [b.to(dev) for b in bs[:2]])
+    assert torch.equal(Y2[0], res[False][0][0]) and Y2[1].shape[1] == 7
+
+
 def test_linear_unaligned_k(dev):
     from vilco_amd import ops
     x, w = torch.randn(37, 50), torch.randn(30, 50)

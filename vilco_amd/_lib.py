@@ -73,6 +73,7 @@ SIGNATURES = {
     "vilco_defer_flush": (C.c_int, [c_fp]),
     "vilco_gemm_workspace": (sz, [C.POINTER(GemmDesc)]),
     "vilco_gemm": (C.c_int, [C.POINTER(GemmDesc), c_fp]),
+    "vilco_gemm_group": (C.c_int, [C.POINTER(GemmDesc), i32, c_fp]),
     "vilco_gemm_amax_parts": (i32, [C.POINTER(GemmDesc)]),
     "vilco_gemm_force": (C.c_int, [i32, i32]),
     "vilco_gemm_set_fixup": (C.c_int, [i32]),

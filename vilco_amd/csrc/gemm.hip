@@ -218,7 +218,8 @@ __device__ __forceinline__ void wait_sc1(f32x4& a, f32x4& b, f32x4& c, f32x4& d)
 // before: 24k of a 112k-cycle block at K = 1024).  The pipeline buffers must be dead when this is called.
 template <int MI, bool F16, bool FIXUP>
 __device__ __forceinline__ void gemm_epilogue(const GArgs& g, f32x4 (&acc)[MI][4], unsigned char* smem_raw, int tid, int lane,
-                                              int wave, int wm, int wn, int m0, int n0, int bid, int ks, int zo, int zi) {
+                                              int wave, int wm, int wn, int m0, int n0, int bid, int ks, int zo, int zi,
+                                              int zidx) {          // zidx: batch index of this workgroup (0 in a grouped launch)
   if (F16) {
     const float inv = g.inv_a[0] * g.inv_b[0];
 #pragma unroll
@@ -235,7 +236,7 @@ __device__ __forceinline__ void gemm_epilogue(const GArgs& g, f32x4 (&acc)[MI][4
   if constexpr (FIXUP) if (g.ksplit > 1 && g.tile_ctr) {
     __shared__ unsigned arrived;
     constexpr long PIECES = MI * 4 * 64;                        // f32x4 pieces per wave
-    const long tile = (long)blockIdx.z * g.ntiles + bid;
+    const long tile = (long)zidx * g.ntiles + bid;
     f32x4* mine = reinterpret_cast<f32x4*>(g.c) + ((tile * g.ksplit + ks) * 8 + wave) * PIECES + lane;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -320,7 +321,7 @@ __device__ __forceinline__ void gemm_epilogue(const GArgs& g, f32x4 (&acc)[MI][4
       float m = red[0];
 #pragma unroll
       for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
-      g.amax_out[(long)blockIdx.z * gridDim.x + blockIdx.x] = m;     // (split-K fix-up: one last arriver per tile)
+      g.amax_out[(long)zidx * gridDim.x + blockIdx.x] = m;     // (split-K fix-up: one last arriver per tile)
     }
   }
 }
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
   }
   STAMPX(2);
 
-  gemm_epilogue<MI, F16, true>(g, acc, smem_raw, tid, lane, wave, wm, wn, m0, n0, bid, ks, zo, zi);
+  gemm_epilogue<MI, F16, true>(g, acc, smem_raw, tid, lane, wave, wm, wn, m0, n0, bid, ks, zo, zi, (int)blockIdx.z);
   STAMPX(3);
 }
 
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 //     the wait that retires it", cdna_hip_programming.md 5).
 // SINGLE keeps the two slots and fills them with part 0 of two consecutive 64-element chunks (128 k per interval).
 template <int BM, bool AKM, bool BKM, bool SINGLE>
-__global__ __launch_bounds__(512) void gemm_gl_kernel(GArgs g) {
+__device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
   constexpr int MI = BM / 64;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;       // one slot of one operand
   constexpr int SLOT = A_BYTES + B_BYTES, STAGE = 2 * SLOT;
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(512) void gemm_gl_kernel(GArgs g) {
   }
   const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.z, zo = z / g.batch_inner, zi = z % g.batch_inner;
+  const int zo = z / g.batch_inner, zi = z % g.batch_inner;
   const int ks = blockIdx.y;
 
   const __bf16* pa = g.a.p + ((long)(g.a.has_o ? zo : 0) * g.a.nbi + (g.a.has_i ? zi : 0)) * g.a.batch_stride;
@@ -1018,8 +1019,22 @@ __global__ __launch_bounds__(512) void gemm_gl_kernel(GArgs g) {
 #undef GL_WAIT_DMA
 #undef GL_WAIT_LDS
   STAMPX(2);
-  gemm_epilogue<MI, true, false>(g, acc, smem_raw, tid, lane, wave, wm, wn, m0, n0, bid, ks, zo, zi);
+  gemm_epilogue<MI, true, false>(g, acc, smem_raw, tid, lane, wave, wm, wn, m0, n0, bid, ks, zo, zi, z);
   STAMPX(3);
+}
+
+template <int BM, bool AKM, bool BKM, bool SINGLE>
+__global__ __launch_bounds__(512) void gemm_gl_kernel(GArgs g) {
+  gemm_gl_body<BM, AKM, BKM, SINGLE>(g, (int)blockIdx.z);
+}
+
+// Grouped launch (round 5): up to four INDEPENDENT products of one shape -- the q / k / v projections of an attention block,
+// forward and dX -- as one grid, blockIdx.z = the product.  Each of them alone is 192 tiles on 256 CUs (a 75 %-full round,
+// plus a launch and an end-of-kernel write-back of its own); together the dispatcher packs 3 x 192 tiles into 2.25 rounds.
+struct GArgsN { GArgs g[4]; };
+template <int BM, bool AKM, bool BKM>
+__global__ __launch_bounds__(512) void gemm_gl_group_kernel(GArgsN gg) {
+  gemm_gl_body<BM, AKM, BKM, false>(gg.g[blockIdx.z], 0);
 }
 
 // out = epilogue(alpha * sum_s part[s]).  VEC (16-byte aligned rows, N % 4 == 0: the layout the MFMA kernel's own
@@ -1510,8 +1525,11 @@ extern "C" size_t vilco_gemm_workspace(const vilco_gemm_desc* d) {
   return (size_t)(p.a_bytes + p.b_bytes + p.part_bytes + 512 + SCALE_BYTES);
 }
 
-extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
+// gout / pout non-null: validate, plan and fill the kernel arguments of a product whose operands are already packed, WITHOUT
+// launching anything (vilco_gemm_group collects the members of a grouped launch this way)
+static int gemm_impl(const vilco_gemm_desc* d, void* stream, GArgs* gout, Plan* pout) {
   if (!d || !d->C || (!d->A && !d->a_planes) || (!d->B && !d->b_planes)) return VILCO_ERR_BADARG;
+  if (gout && !(d->a_planes && d->b_planes)) return VILCO_ERR_UNSUPPORTED;
   if (d->a_planes || d->b_planes) {
     // pre-packed operands: untapped problems, or the plain (weight) operand B of a k=3 conv whose taps are on A
     // (k=3 convs: the tapped operand's planes must be the zero-padded per-sequence image, vilco_pack_item.seq_len; checked
@@ -1676,6 +1694,7 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
   g.e = Epi{d->alpha, d->beta, d->bias, d->preact, d->act, d->row_len, d->rowT, d->colscale, d->residual,
             d->res_masked, d->row_mask};
   const int nz = d->batch_outer * d->batch_inner;
+  if (gout) { *gout = g; *pout = p; return VILCO_OK; }
   dim3 grid(g.ntiles, p.ksplit, nz);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
@@ -1723,6 +1742,67 @@ extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) {
     if (blocks > 2048) blocks = 2048;
     if (g.vec_out) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((int)blocks), dim3(256), 0, s, g, nz);
     else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((int)blocks), dim3(256), 0, s, g, nz);
+  }
+  return vilco_launch_status();
+}
+
+extern "C" int vilco_gemm(const vilco_gemm_desc* d, void* stream) { return gemm_impl(d, stream, nullptr, nullptr); }
+
+template <int BM>
+static void launch_gl_group(const GArgsN& gg, int n, int ntiles, hipStream_t s, bool akm, bool bkm) {
+  constexpr size_t lds = (size_t)4 * (BM + BN) * 128;
+  const dim3 grid(ntiles, 1, n);
+#define VILCO_GROUP_LAUNCH(A_, B_)                                                                                      \
+  do {                                                                                                                  \
+    static const bool once = [] {                                                                                       \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_gl_group_kernel<BM, A_, B_>),                             \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                        \
+      (void)hipGetLastError();                                                                                          \
+      return true;                                                                                                      \
+    }();                                                                                                                \
+    (void)once;                                                                                                         \
+    hipLaunchKernelGGL((gemm_gl_group_kernel<BM, A_, B_>), grid, dim3(512), lds, s, gg);                                \
+  } while (0)
+  if (akm && bkm) VILCO_GROUP_LAUNCH(true, true);
+  else if (bkm) VILCO_GROUP_LAUNCH(false, true);
+  else VILCO_GROUP_LAUNCH(false, false);
+#undef VILCO_GROUP_LAUNCH
+}
+
+// n (2..4) independent products of ONE shape, orientation and format in one launch (gemm_gl_group_kernel): operands packed
+// beforehand, precision 3, unbatched, untapped, no band; whatever does not qualify -- a split-K plan, the old kernel, unequal
+// shapes -- runs as n ordinary vilco_gemm calls, in order (same results either way: the kernel body is the same).
+extern "C" int vilco_gemm_group(const vilco_gemm_desc* descs, int32_t n, void* stream) {
+  if (!descs || n < 1 || n > 4) return VILCO_ERR_BADARG;
+  static const bool enabled = [] { const char* e = getenv("VILCO_GEMM_GROUP"); return !(e && e[0] == '0'); }();
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GArgsN gg;
+  Plan p0;
+  bool ok = enabled && n >= 2;
+  for (int i = 0; ok && i < n; ++i) {
+    const vilco_gemm_desc& d = descs[i];
+    Plan p;
+    ok = d.precision == 3 && d.batch_outer == 1 && d.batch_inner == 1 && d.tap_operand == VILCO_TAP_NONE && d.band == 0 &&
+         d.M == descs[0].M && d.N == descs[0].N && d.K == descs[0].K && d.a_kcontig == descs[0].a_kcontig &&
+         d.b_kcontig == descs[0].b_kcontig && d.M > 0 && d.N > 0 && gemm_impl(&d, stream, &gg.g[i], &p) == VILCO_OK &&
+         p.gl && p.ksplit == 1 && (i == 0 || (p.BM == p0.BM && p.a_km == p0.a_km && p.b_km == p0.b_km));
+    if (i == 0) p0 = p;
+  }
+  if (!ok) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = vilco_gemm(&descs[i], stream);
+      if (rc != VILCO_OK) return rc;
+    }
+    return VILCO_OK;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
+  if (p0.BM == 192) launch_gl_group<192>(gg, n, gg.g[0].ntiles, s, p0.a_km, p0.b_km);
+  else launch_gl_group<128>(gg, n, gg.g[0].ntiles, s, p0.a_km, p0.b_km);
+  if (ev0) {
+    hipEventRecord(ev1, s);
+    prof().ev.emplace_back(ev0, ev1);
+    prof().rec.push_back(ProfRec{{descs[0].M, descs[0].N, descs[0].K, n, p0.BM, 1, 3, p0.a_km, p0.b_km, 0x100}});    // (batch field = group size)
   }
   return vilco_launch_status();
 }

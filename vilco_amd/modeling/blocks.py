@@ -262,9 +262,9 @@ class MaskedMHCA(nn.Module):
         return self._attend(q, k, v, q_lens, kv_lens)
 
     def _attend(self, q, k, v, q_lens, kv_lens):
-        q = ops.linear(q, self.query.weight, self.query.bias)
-        k = ops.linear(k, self.key.weight, self.key.bias)
-        v = ops.linear(v, self.value.weight, self.value.bias)
+        # the three projections (blocks.py:332-344) as grouped launches when q, k, v have one shape (self-attention at equal strides)
+        q, k, v = ops.linear_group([q, k, v], [self.query.weight, self.key.weight, self.value.weight],
+                                   [self.query.bias, self.key.bias, self.value.bias])
         o = ops.attention(q, k, v, kv_lens, self.n_head, self.scale,
                           drop_p=self.attn_drop.p if self.training else 0.0)            # attn_drop (blocks.py:394)
         out = ops.linear(o, self.proj.weight, self.proj.bias, ACT_NONE, q_lens, q.shape[1],

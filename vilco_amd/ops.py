@@ -364,12 +364,13 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
          sC=(0, 0), offA=0, offB=0, offC=0, tap=TAP_NONE, tapC=0, tapT=0, alpha=1.0, beta=0.0,
          bias=None, preact=None, act=ACT_NONE, row_len=None, rowT=0, colscale=None, residual=None,
          res_masked=0, precision=None, a_planes=None, b_planes=None, band=0, bandT=0, drop=(0.0, 0), want_amax=False,
-         a_amax=None, b_amax=None, planes_seq=(False, False), row_mask=None):
+         a_amax=None, b_amax=None, planes_seq=(False, False), row_mask=None, _into=None):
     """Raw launch of vilco_gemm; A/B/Cc are fp32 CUDA tensors, offsets in elements.  a_planes / b_planes: operands
     already packed by `pack` (the fp32 tensor may then be None).  want_amax: the call writes ALL of Cc, which goes on
-    into another product -- the kernel leaves max|C| partials and Cc is tagged with them (`_tag_amax`)."""
+    into another product -- the kernel leaves max|C| partials and Cc is tagged with them (`_tag_amax`).
+    _into: (internal, gemm_group) a GemmDesc to fill instead of launching; returns what must stay alive + the amax tag."""
     lib = _lib.load()
-    d = GemmDesc()
+    d = GemmDesc() if _into is None else _into
     d.A = None if A is None else A.data_ptr() + 4 * offA
     d.B = None if B is None else B.data_ptr() + 4 * offB
     d.a_planes, d.b_planes = _p(a_planes), _p(b_planes)
@@ -411,9 +412,23 @@ def gemm(A, B, Cc, M, N, K, a_kc, b_kc, lda, ldb, ldc, batch=(1, 1), sA=(0, 0), 
         if n > 0:
             parts = torch.empty(n, dtype=torch.float32, device=Cc.device)
             d.amax_out = parts.data_ptr()
+    if _into is not None:
+        return (ws, Cc, parts, n)
     _lib.check(lib.vilco_gemm(C.byref(d), _stream()))
     if parts is not None:
         _tag_amax(Cc, parts, n)
+
+
+def gemm_group(calls):
+    """calls: [(args, kwargs) of `gemm`, ...] (2..4 independent products of one shape with packed operands) as ONE launch
+    (vilco_gemm_group; whatever does not qualify runs one by one inside the library -- same results)."""
+    lib = _lib.load()
+    arr = (GemmDesc * len(calls))()
+    keep = [gemm(*a, _into=arr[i], **k) for i, (a, k) in enumerate(calls)]
+    _lib.check(lib.vilco_gemm_group(arr, len(calls), _stream()))
+    for ws, Cc, parts, n in keep:
+        if parts is not None:
+            _tag_amax(Cc, parts, n)
 
 
 # ---- amax partials left by the producing kernel.  The fp16 x2 planes need max|x| of the whole tensor before anything can be
@@ -734,6 +749,80 @@ class _Linear(torch.autograd.Function):
                 dw = _grad_out(w)
                 gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(prec, M), a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
         return dx, dw, db, None, None, None, None, None, None
+
+
+class _LinearGroup(torch.autograd.Function):
+    """(y_i = x_i W_i^T + b_i) for n independent plain Linear layers of ONE shape -- an attention block's q / k / v projections
+    (MQ/libs/modeling/blocks.py:332-344) -- with the n forward products and the n dX products each as one grouped launch
+    (vilco_gemm_group).  Per layer it is _Linear without activation / mask / dropout: same packs, same kernels, same sums."""
+    last_amax = []
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        _chk(*xs, *ws, *bs)
+        K, N = xs[0].shape[-1], ws[0].shape[0]
+        M = xs[0].numel() // K
+        ys = [torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device) for x in xs]
+        pxs = [pack(x, M, K) for x in xs]
+        pws = [weight_planes(w, N, K) for w in ws]
+        gemm_group([((x, w, y, M, N, K, 1, 1, K, K, N), dict(bias=b, a_planes=px, b_planes=pw, want_amax=True))
+                    for x, w, b, y, px, pw in zip(xs, ws, bs, ys, pxs, pws)])
+        ctx.n, ctx.prec = n, _precision
+        _LinearGroup.last_amax = [_amax_of(y) for y in ys]       # (attributes set here do not survive apply(): re-tagged by the caller)
+        ctx.save_for_backward(*xs, *ws, *bs, *pxs, *pws)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        sv = ctx.saved_tensors
+        xs, ws, bs, pxs, pws = sv[:n], sv[n:2 * n], sv[2 * n:3 * n], sv[3 * n:4 * n], sv[4 * n:5 * n]
+        K, N = xs[0].shape[-1], ws[0].shape[0]
+        M = xs[0].numel() // K
+        dys = [dy.contiguous() for dy in dys]
+        dbs = [colsum(dy.view(M, N), param=b) if ctx.needs_input_grad[1 + 2 * n + i] else None for i, (dy, b) in enumerate(zip(dys, bs))]
+        pzs = [pack(dy, M, N, ctx.prec) for dy in dys]
+        need_dx = [ctx.needs_input_grad[1 + i] for i in range(n)]
+        dxs = [torch.empty_like(x) if nd else None for x, nd in zip(xs, need_dx)]
+        calls = [((dy, w, dx, M, K, N, 1, 0, N, K, K), dict(precision=ctx.prec, a_planes=pz, b_planes=pw, want_amax=True))
+                 for dy, w, dx, pz, pw in zip(dys, ws, dxs, pzs, pws) if dx is not None]
+        if len(calls) > 1:
+            gemm_group(calls)                                     # dX_i = dY_i W_i   (NN), one launch
+        else:
+            for a, k in calls:
+                gemm(*a, **k)
+        dws = []
+        for i, (dy, x, w, pz, px) in enumerate(zip(dys, xs, ws, pzs, pxs)):
+            if ctx.needs_input_grad[1 + n + i]:
+                with _DwFork(w), _Deferring(w):
+                    dw = _grad_out(w)
+                    gemm(dy, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(ctx.prec, M), a_planes=pz, b_planes=px)   # dW = dY^T X
+                dws.append(dw)
+            else:
+                dws.append(None)
+        return (None, *dxs, *dws, *dbs)
+
+
+linear_group_enabled = os.environ.get("VILCO_LINEAR_GROUP", "1") != "0"
+
+
+def linear_group(xs, ws, bs):
+    """[x_i W_i^T + b_i]: independent Linear layers of one shape as grouped launches (falls back to `linear` per layer when the
+    shapes differ, a bias is missing, the ambient format is not fp16 x2, or VILCO_LINEAR_GROUP=0)."""
+    n = len(xs)
+    same = (linear_group_enabled and 2 <= n <= 4 and _precision == 3 and _reuse_packs and _weight_cache and range_check == "0"
+            and all(b is not None for b in bs)
+            and all(x.shape == xs[0].shape and w.shape == ws[0].shape for x, w in zip(xs, ws)))
+    if not same:
+        return [linear(x, w, b) for x, w, b in zip(xs, ws, bs)]
+    _LinearGroup.last_amax = []
+    ys = _LinearGroup.apply(n, *xs, *ws, *bs)
+    for y, am in zip(ys, _LinearGroup.last_amax):
+        if am[0] is not None:                       # max|y| partials left by the GEMM epilogue
+            _tag_amax(y, *am)
+    _LinearGroup.last_amax = []
+    return list(ys)
 
 
 def linear(x, w, b=None, act=ACT_NONE, lens=None, T=None, drop_p=0.0, drop_site="dropout", bwd_precision=None):
