@@ -658,7 +658,7 @@ def local_sections(out, args, model, step, eager_step, dev, ms, world, batch):
             del gbig
     if world == 1 and not args.no_targets and args.precision == "f16x2":
         # BASELINE.md 3.3 asks for a bf16 perf run beside the parity run: the SAME step with single-pass bf16 MFMA operands
-        # (1 MFMA per product, 8-bit mantissas).  It does NOT meet the 1e-3 parity bar (median gradient
+        # (1 MFMA per product, 8-bit mantissas).  It does NOT meet the 1e-3 parity bar (DESIGN_LOG.md 3.1: median gradient
         # error 6e-2) and is not the headline.
         from vilco_amd import ops
         try:

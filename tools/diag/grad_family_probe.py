@@ -1,5 +1,5 @@
 """Where does the fp32 reference's 0.1-0.2 (of the tensor maximum) distance from an exact run of itself on `branch.*.mlp.3.weight`
-come from?    dW = sum_t dY[t] X[t]^T: this script runs the oracle at config P (no dropout) in fp32 and in
+come from?  (DESIGN_LOG.md 4, round 4.)  dW = sum_t dY[t] X[t]^T: this script runs the oracle at config P (no dropout) in fp32 and in
 fp64, catches both operands of branch.0's second MLP conv, and compares them.
 Findings (build container, 8 cores, ~3 min): X agrees to 8e-7; dY differs by 0.39 of its maximum on single elements, at PAIRS of
 adjacent tokens (18/19, 77/78) with equal error -- a gradient element that one run routes to token 2j and the other to token 2j+1:

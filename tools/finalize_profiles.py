@@ -25,7 +25,7 @@ out = {"gemm_kernels": {"launches_fetch_pass": fn, "launches_write_pass": wn, "F
 json.dump(out, open(os.path.join(R, 'profiles', RND + '_pmc_traffic.json'), 'w'), indent=1)
 for n in ('bench_kernel_stats.csv', 'pmc_fetch.json', 'pmc_write.json'):
     shutil.copy(g(TAG + '_' + n), os.path.join(R, 'profiles', TAG + '_' + n))
-for n in ('gemm_shapes.txt', 'targets_kernel_stats.csv', 'targets_pmc_fetch.json', 'targets_pmc_write.json', 'attn_insts.txt', 'gpu_tests.txt'):       # optional extras
+for n in ('gemm_shapes.txt', 'gemm_mfma.txt', 'targets_kernel_stats.csv', 'targets_pmc_fetch.json', 'targets_pmc_write.json', 'attn_insts.txt', 'gpu_tests.txt'):       # optional extras
     if os.path.exists(g(TAG + '_' + n)):
         shutil.copy(g(TAG + '_' + n), os.path.join(R, 'profiles', TAG + '_' + n))
 d = json.loads(open(g(TAG + '_bench.json')).read().strip().split('\n')[-1])

@@ -17,3 +17,6 @@ TAG=${TAG}_targets bash tools/prof_targets.sh > /dev/null 2>&1
 bash tools/prof_attn_pmc.sh > gpurun_out/${TAG}_attn_insts.txt 2>&1
 ls -la $R/gpurun_out | grep ${TAG}
 TAG=${TAG} bash tools/prof_targets_pmc.sh > gpurun_out/${TAG}_targets_pmc.txt 2>&1
+# round 5: matrix-pipe busy / LDS counters of the GEMM kernels per shape
+cd $R
+TAG=${TAG} bash tools/prof_gemm_mfma.sh > gpurun_out/${TAG}_gemm_mfma.txt 2>&1

@@ -1893,7 +1893,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
       // dQ and dK/dV are independent once delta exists.  At the long levels neither grid fills the chip in whole rounds
       // (T = 2304, B H = 32: 576 and 1152 workgroups on 512 resident slots -> 2 and 3 rounds for 1.125 and 2.25 rounds of
       // work); on two streams the runtime packs them together.  Only inside a stream capture (a replayed graph has no host
-      // in the loop; an eager second queue made step times erratic) and only where there is a tail to fill.
+      // in the loop; an eager second queue made step times erratic, DESIGN_LOG.md 3.6) and only where there is a tail to fill.
       ForkCtx* f = (long)gq64.x * gq64.y * gq64.z > 512 ? attn_fork(s) : nullptr;
       if (f) {
         hipLaunchKernelGGL(attn_delta64_kernel, dim3((a.Tq + 63) / 64, a.H, a.B), dim3(256), 0, s, a);

@@ -573,7 +573,7 @@ __global__ __launch_bounds__((RING_NA + NCH) * 64) void qkv_pre_fwd_ring_kernel(
   }
 }
 
-// Other forward structures built and measured at [8, 2304, 2304] and removed (r02 / r03):
+// Other forward structures built and measured at [8, 2304, 2304] and removed (r02 / r03; DESIGN_LOG.md 3.4):
 //   * rows of a 4-token tile normalised once into LDS, one token per wave: 288 us -- every wave re-loads the 17
 //     per-channel parameter quads per token and pass;
 //   * channel-split tiles (a wave owns 256 channels of 6 tokens, statistics combined across the waves through LDS, every
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(QT) void qkv_pre_bwd_params_kernel(QkvBwdArgs a, fl
 #pragma unroll
   for (int i = 0; i < 15; ++i) acc[i] = 0.f;
   // two rows per iteration, all 18 loads of the pair issued up front from clamped (always valid) addresses and masked
-  // afterwards: a `valid ? p[i] : 0.f` load is a branch with its own wait
+  // afterwards: a `valid ? p[i] : 0.f` load is a branch with its own wait (DESIGN_LOG.md 3.7)
   struct RowIn { float hm, h0, hp, dy[3], dc[3]; bool valid, lo, hi; };
   auto fetch = [&](long r, RowIn& x) {
     const int t = (int)(r % a.Tout), b = (int)(r / a.Tout);

@@ -1,6 +1,6 @@
 """Losses of the MQ heads as device tensor expressions (reference: MQ/libs/modeling/losses.py:5-168).
 The training step does NOT go through this file: labelling + focal / DIoU / action-localisation losses run as the fused
-kernels `vilco_mq_loss_fwd / _bwd` (csrc/loss.hip, ops.mq_loss).  These functions are the
+kernels `vilco_mq_loss_fwd / _bwd` (csrc/loss.hip, ops.mq_loss; DESIGN_LOG.md 3.5).  These functions are the
 `VILCO_FUSED_LOSS=0` path the fused kernels are tested equal to (tests/test_loss_gpu.py) and what iCaRL / BiC
 distillation terms and the narration SSL loss are built from."""
 import torch

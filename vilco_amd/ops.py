@@ -97,7 +97,7 @@ def _grad_out(w):
 # video stem, the regression head beside the classification head, and the weight-gradient products (nothing in backward
 # waits for them) beside the dX chain -- they fill the CUs that the 75 %-full GEMM rounds of this model's shapes leave
 # idle.  VILCO_GRAPH_STREAMS lists what is forked ("text,heads,dw"; "" = nothing); only active while a stream is capturing
-# (in eager mode a second queue made the step time erratic).
+# (in eager mode a second queue made the step time erratic, DESIGN_LOG.md 3.6).
 _FORKS = set(x for x in os.environ.get("VILCO_GRAPH_STREAMS", "text,heads").split(",") if x)
 _side_streams = {}
 _dw_seen = set()
