@@ -83,7 +83,6 @@ struct GArgs {
   float drop_inv_keep;
   const uint32_t* seed_word;   // device step word mixed into drop_seed (common.h: vilco_step_seed)
   float* amax_out;          // optional: max|stored value| per workgroup (vilco_gemm_desc.amax_out)
-  int prefetch;             // gemm_gl_kernel: L2 prefetch of the operand lines three chunks ahead (VILCO_GEMM_PREFETCH)
   Epi e;
 };
 
@@ -755,6 +754,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GArgs g) {
 //     its own DMAs (vmcnt(0)) just before the barrier that precedes their first reader ("read a staged buffer one phase after
 //     the wait that retires it", cdna_hip_programming.md 5).
 // SINGLE keeps the two slots and fills them with part 0 of two consecutive 64-element chunks (128 k per interval).
+// (Measured and removed, round 5: an L2 prefetch of every wave's own operand lines three chunks ahead -- one 4-byte load per
+// 128-byte line, never waited for -- against the 25 % the step's cold launches lose to back-to-back ones: the replayed P step
+// went 22.5 -> 23.4 ms, GEMM time 12.66 -> 13.7 ms.  The cold share is not load latency.  DESIGN_LOG.md R5.)
 template <int BM, bool AKM, bool BKM, bool SINGLE>
 __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
   constexpr int MI = BM / 64;
@@ -835,39 +837,6 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
   const int kstepA = AKM ? (int)(2 * KSLOT * g.a.row_stride) : 2 * KSLOT;     // bytes per 64 k
   const int kstepB = BKM ? (int)(2 * KSLOT * g.b.row_stride) : 2 * KSLOT;
 
-  // ---- L2 prefetch (round 5).  A chunk's DMAs are issued one interval (~1500 cycles) ahead: enough for lines that sit in the
-  // XCD's L2, not for the step's cold operands (weights from HBM, activations another XCD just wrote: 2500-5000 cycles) -- the
-  // step's launches ran 25 % slower than back to back.  Every wave therefore touches the 128-byte lines of ITS OWN pieces of
-  // the chunk three ahead with one 4-byte load per line (one instruction per operand and part); the values are never used.
-  // The loads are inline asm (hipcc must neither count nor wait for them); their one destination register stays live -- and
-  // therefore allocated -- through every statement until the final drain.  The waits become vmcnt(PFN): the PFN prefetches
-  // issued AFTER a phase's DMAs stay in flight, everything older (the DMAs, earlier prefetches) has landed.
-  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-  const bool pf_on = !SINGLE && g.prefetch != 0;
-  unsigned pfoA = 0, pfoB = 0, pf_dummy = 0;
-  u32x4v pfdA[2], pfdB[2];
-  {
-    const int j = lane >> 3, sr = lane & 7;
-    const int nA = late ? NP1 : NP0A, nB = NP0 - NP0A;
-    const int pA = late ? NA0 + w4 + 4 * (j < nA ? j : 0) : w4 + 4 * (j < nA ? j : 0);
-    const int pB = w4 + 4 * (j < nB ? j : 0);
-    long oa, ob;
-    if (AKM) { int col = m0 + (pA >> 3) * 64; if (col > g.a.cols - 8) col = g.a.cols - 8; oa = (long)(8 * (pA & 7) + sr) * g.a.row_stride + col; }
-    else oa = row_off(g.a, m0 + 8 * pA + sr);
-    if (BKM) { int col = n0 + (pB >> 3) * 64; if (col > g.b.cols - 8) col = g.b.cols - 8; ob = (long)(8 * (pB & 7) + sr) * g.b.row_stride + col; }
-    else ob = row_off(g.b, n0 + 8 * pB + sr);
-    pfoA = (unsigned)(oa * 2); pfoB = (unsigned)(ob * 2);
-    const unsigned na = g.a.bytes > 0xffffffffL ? 0xffffffffu : (unsigned)g.a.bytes;
-    const unsigned nb = g.b.bytes > 0xffffffffL ? 0xffffffffu : (unsigned)g.b.bytes;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const unsigned long long a = (unsigned long long)(pa + (SINGLE ? 0 : q * g.a.plane_stride));
-      const unsigned long long b = (unsigned long long)(pb + (SINGLE ? 0 : q * g.b.plane_stride));
-      pfdA[q] = u32x4v{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, na, 0x00020000u};
-      pfdB[q] = u32x4v{(unsigned)b, (unsigned)(b >> 32) & 0xffffu, nb, 0x00020000u};
-    }
-  }
-
   // ---- fragment addresses (bytes inside a slot; k32 half h adds hoff, MFMA block i / j its own term)
   int faddr[MI], fbddr[4];
   int fa_h1, fb_h1;                                           // what the second k32 half adds (k-major) or XORs (k-contiguous)
@@ -943,16 +912,6 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
     }
   };
 
-  auto prefetch = [&](int ci) {                               // lines of this wave's pieces of interval ci (clamped) -> L2
-    if (ci > c1 - 1) ci = c1 - 1;
-    const int sa = ci * kstepA, sb = ci * kstepB;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(pf_dummy) : "v"(pfoA), "s"(pfdA[u]), "s"(sa) : "memory");
-      if (!late) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(pf_dummy) : "v"(pfoB), "s"(pfdB[u]), "s"(sb) : "memory");
-    }
-  };
-
   bf16x8 fa[2][2][MI], fb[2][2][4];                           // [slot][k32 half][block]
   auto reads = [&](int st) {
     const unsigned char* sbase = smem_raw + st * STAGE;
@@ -1003,19 +962,13 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
     __builtin_amdgcn_s_barrier();                     \
     __builtin_amdgcn_sched_barrier(0);                \
   } while (0)
-#define GL_WAIT_DMA()                                                                     \
-  do {                                                                                    \
-    if (!pf_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
-    else if (late) asm volatile("s_waitcnt vmcnt(2)" : "+v"(pf_dummy)::"memory");         \
-    else asm volatile("s_waitcnt vmcnt(4)" : "+v"(pf_dummy)::"memory");                   \
-  } while (0)
+#define GL_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define GL_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
   if (nc > 0) {
     issue(c0, 0);
     STAMPX(4);
-    if (pf_on) { prefetch(c0 + 1); prefetch(c0 + 2); }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy)::"memory");
+    GL_WAIT_DMA();
     GL_BARRIER();
     STAMPX(1);
     if (!late) {
@@ -1027,7 +980,6 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
         STAMP(1);
 #endif
         if (t + 1 < nc) issue(c0 + t + 1, (t + 1) & 1);
-        if (pf_on) prefetch(c0 + t + 3);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(2);
         GL_WAIT_LDS();
@@ -1041,7 +993,6 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
         GL_BARRIER();                                         // Y
         STAMP(7);
       }
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy)::"memory");     // the last prefetches: their register dies here
     } else {
       for (int t = 0; t < nc; ++t) {
         STAMP(0);
@@ -1058,15 +1009,12 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
         STAMP(4);
 #endif
         if (t + 1 < nc) issue(c0 + t + 1, (t + 1) & 1);
-        if (pf_on) prefetch(c0 + t + 3);
         __builtin_amdgcn_sched_barrier(0);
         STAMP(5);
         GL_WAIT_LDS();
         GL_BARRIER();                                         // Y
         STAMP(7);
       }
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy)::"memory");
-      __builtin_amdgcn_sched_barrier(0);
       mfmas(last_sub);
     }
   }
@@ -1746,10 +1694,6 @@ static int gemm_impl(const vilco_gemm_desc* d, void* stream, GArgs* gout, Plan* 
     if (!g.tile_ctr) return VILCO_ERR_UNSUPPORTED;      // more than FIX_STREAMS streams in one process
   }
   g.amax_out = d->band == 1 ? nullptr : d->amax_out;
-  {
-    static const int pf = [] { const char* e = getenv("VILCO_GEMM_PREFETCH"); return e ? atoi(e) : 1; }();
-    g.prefetch = pf;
-  }
   g.e = Epi{d->alpha, d->beta, d->bias, d->preact, d->act, d->row_len, d->rowT, d->colscale, d->residual,
             d->res_masked, d->row_mask};
   const int nz = d->batch_outer * d->batch_inner;
