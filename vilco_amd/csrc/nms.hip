@@ -44,7 +44,8 @@ __device__ const unsigned long long kExp2fTab[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
     0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
-__device__ __forceinline__ float expf_libm(float x) {
+template <typename TabT>
+__device__ __forceinline__ float expf_libm_tab(float x, const TabT* tab) {
   if (!(x > -80.f && x < 80.f)) return expf(x);          // far tails / NaN: not reachable from an IoU
   const double N = 32.0;
   const double z = (0x1.71547652b82fep+0 * N) * (double)x;
@@ -52,7 +53,7 @@ __device__ __forceinline__ float expf_libm(float x) {
   const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
   kd -= 0x1.8p+52;
   const double r = z - kd;
-  const unsigned long long t = kExp2fTab[ki % 32] + (ki << 47);
+  const unsigned long long t = tab[ki % 32] + (ki << 47);
   const double s = __longlong_as_double((long long)t);
   const double c0 = 0x1.c6af84b912394p-5 / N / N / N, c1 = 0x1.ebfce50fac4f3p-3 / N / N, c2 = 0x1.62e42ff0c52d6p-1 / N;
   const double zz = c0 * r + c1;
@@ -62,6 +63,8 @@ __device__ __forceinline__ float expf_libm(float x) {
   y = y * s;
   return (float)y;
 }
+
+__device__ __forceinline__ float expf_libm(float x) { return expf_libm_tab(x, kExp2fTab); }
 
 __device__ __forceinline__ float iou_1d(float ix1, float ix2, float iarea, float jx1, float jx2, float jarea) {
   const float xx1 = fmaxf(ix1, jx1);
@@ -109,13 +112,16 @@ constexpr int CHW = CH / 64;
 
 struct HardAux { long* kbase; };         // per class: number of keeps before the current chunk
 
+// BY_X1 (round 5, the pre-pass of softnms_reg_kernel): the key is -x1 (rank = position in ascending-start order, ties by input
+// index) and the score travels with the candidate; no counters are touched.
+template <bool BY_X1>
 __global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__ segs, const float* __restrict__ scores,
                                                        const long* __restrict__ seg_off, int nseg,
                                                        long* __restrict__ out_cnt, long* __restrict__ kbase,
                                                        void* ws_raw, long n_total) {
   __shared__ float s_sc[1024];
   const long g0 = (long)blockIdx.x * 256;
-  if (blockIdx.x == 0)
+  if (!BY_X1 && blockIdx.x == 0)
     for (int k = threadIdx.x; k < nseg; k += 256) { out_cnt[k] = 0; kbase[k] = 0; }
   // classes this block's 256 candidates belong to: [c_lo, c_hi]; candidates are class-sorted, so a block spans few classes
   const long g = g0 + threadIdx.x;
@@ -144,11 +150,12 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__
     const int n = (int)(seg_off[c + 1] - off);
     const bool mine = cls == c;
     const int i = mine ? (int)(g - off) : 0;
-    const float si = mine ? scores[off + i] : 0.f;
+    const float si = mine ? (BY_X1 ? -segs[2 * (off + i)] : scores[off + i]) : 0.f;
     int rank = 0;
     for (int t0 = 0; t0 < n; t0 += 1024) {
       __syncthreads();
-      for (int k = threadIdx.x; k < 1024; k += 256) s_sc[k] = t0 + k < n ? scores[off + t0 + k] : -INFINITY;
+      for (int k = threadIdx.x; k < 1024; k += 256)
+        s_sc[k] = t0 + k < n ? (BY_X1 ? -segs[2 * (off + t0 + k)] : scores[off + t0 + k]) : -INFINITY;
       __syncthreads();
       const int cnt = min(1024, n - t0);
       if (mine) {
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const float* __restrict__
       w.x2[rank] = b;
       w.ar[rank] = b - a + 1e-6f;
       w.dead[rank] = 0;
+      if (BY_X1) w.sc[rank] = scores[off + i];
     }
   }
 }
@@ -577,7 +585,310 @@ __global__ __launch_bounds__(NT) void softnms_rows_kernel(const float* __restric
   if (threadIdx.x == 0) out_cnt[cls] = i;
 }
 
+// ------------------------------------------------------------------------------------ soft NMS, register-resident (round 5)
+// softnms_rows_kernel keeps the reference's arrays in global memory: a pick is four dependent L2 round trips (argmax, swap,
+// decay, compaction), ~22 us at n = 30 000 whatever the arithmetic.  Here a candidate never moves: it lives at a HOME (thread,
+// slot) with its score and its two ends in REGISTERS for the whole kernel, and what the reference's array positions are still
+// needed for -- the tie order of the first-maximum pick (nms_cpu.cpp:91-101: strict '<' keeps the lowest position) -- is kept as
+// two 16-bit maps in LDS, position -> home and home -> position, updated exactly as the reference moves its elements:
+//   pick:      the winner goes to position i, the element that sat there to the winner's old position (:103-121);
+//   removals:  swap-with-last in ascending position order (:146-154) == the k-th hole gets the k-th survivor from the end;
+//              holes and tail survivors are ranked through a position bitmap + per-word prefix popcounts (one wave).
+// Homes are dealt in ascending-start order (nms_rank_kernel<true>: wave w owns a contiguous stretch of the time axis), so the
+// fp64 exp of the Gaussian decay runs only in the few (wave, slot) pairs that overlap the pick; everything else is one
+// interval test per candidate.  Same IoU / decay / threshold expressions and the same fp64 exp as the other kernels: indices
+// and decayed scores bit for bit.  One 512-thread workgroup per class, n <= 60 * 512 per class, Gaussian decay (otherwise: rows kernel).
+// 8 waves x 60 slots (two waves per SIMD, 256 registers each: 180 hold the candidates).  The slot loops are unrolled (register
+// arrays), so their bodies are kept minimal: the first build was 81 KB of code -- more than the 64 KB instruction cache -- and
+// spent ~7 us per pick fetching instructions whatever n.  Gaussian decay only (method 2, what batched_nms uses); the deaths of a
+// pick are handled by a rolled loop after the decay.
+constexpr int NTR = 512, NWR = NTR / 64;
+constexpr int RSLOT = 60;
+constexpr int REG_MAXN = RSLOT * NTR;
+constexpr int FILL_CAP = 16000;                     // tail survivors of one pick kept in LDS (more: the global scratch array)
+
+// workgroup barrier for LDS traffic only: the kernel's global accesses (det rows out, nothing read back) are not waited for --
+// __syncthreads() drains them, and a pick's index store sat behind a global round trip on every pick's critical path
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// (score, position) argmax over a wavefront without the LDS crossbar: four DPP steps inside each row of 16 lanes (both registers
+// moved alike), then the four row results through v_readlane.  Order: higher score first, ties to the LOWER position; position
+// 0x7fffffff = no candidate.
+__device__ __forceinline__ void amax_take(float& v, int& p, float ov, int op) {
+  if (op != 0x7fffffff && (p == 0x7fffffff || ov > v || (ov == v && op < p))) { v = ov; p = op; }
+}
+template <int CTRL>
+__device__ __forceinline__ void amax_dpp(float& v, int& p) {
+  const float ov = vilco_dpp<CTRL>(v);
+  const int op = __builtin_amdgcn_update_dpp(0, p, CTRL, 0xF, 0xF, false);
+  amax_take(v, p, ov, op);
+}
+__device__ __forceinline__ void wave_argmax(float& v, int& p) {
+  amax_dpp<0xB1>(v, p);
+  amax_dpp<0x4E>(v, p);
+  amax_dpp<0x141>(v, p);
+  amax_dpp<0x140>(v, p);
+  float rv = vilco_lane(v, 0);
+  int rp = __builtin_amdgcn_readlane(p, 0);
+  amax_take(rv, rp, vilco_lane(v, 16), __builtin_amdgcn_readlane(p, 16));
+  amax_take(rv, rp, vilco_lane(v, 32), __builtin_amdgcn_readlane(p, 32));
+  amax_take(rv, rp, vilco_lane(v, 48), __builtin_amdgcn_readlane(p, 48));
+  v = rv; p = rp;
+}
+
+struct RegLds {
+  unsigned short pos_of[REG_MAXN];                  // home -> array position
+  unsigned short cand_at[REG_MAXN];                 // array position -> home
+  unsigned bits[REG_MAXN / 32];                     // bit p: the element at position p is alive
+  unsigned pref[REG_MAXN / 32 + 1];                 // alive positions in [first, 32 w)
+  unsigned short fill[FILL_CAP];
+  unsigned long long exptab[32];                    // kExp2fTab: a table look-up per exp is an LDS read, not a global round trip
+  float s_val[NWR];
+  int s_pos[NWR];
+  float s_pick[4];
+  int s_flag, s_nalive;
+};
+
+#ifdef VILCO_LAB_NMS   // tools/lab only: cycle stamps of picks 100..131 of class 0, wave 0 (never compiled into the product)
+__device__ unsigned long long vilco_lab_nms_stamps[32 * 8];
+#define NSTAMP(j)                                                                                   \
+  do {                                                                                              \
+    if (blockIdx.x == 0 && wave == 0 && i >= 100 && i < 132) {                                      \
+      const unsigned long long c_ = __builtin_amdgcn_s_memtime();                                   \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+      if (lane == 0) vilco_lab_nms_stamps[(i - 100) * 8 + (j)] = c_;                                \
+    }                                                                                               \
+  } while (0)
+#else
+#define NSTAMP(j) do {} while (0)
+#endif
+__global__ __launch_bounds__(NTR) void softnms_reg_kernel(const long* __restrict__ seg_off, float thr, float sigma, float min_score,
+                                                         int method, long max_num, float* __restrict__ dets,
+                                                         long* __restrict__ out_idx, long* __restrict__ out_cnt, void* ws_raw,
+                                                         long n_total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char reg_lds_raw[];
+  RegLds& L = *reinterpret_cast<RegLds*>(reg_lds_raw);
+  const int cls = blockIdx.x;
+  const long off = seg_off[cls];
+  const int n = (int)(seg_off[cls + 1] - off);
+  if (n <= 0) {
+    if (threadIdx.x == 0) out_cnt[cls] = 0;
+    return;
+  }
+  Ws w = carve(ws_raw, n_total, off);               // x1 / x2 / sc / ind in ascending-start order (nms_rank_kernel<true>)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rmax = (n + NTR - 1) / NTR;             // slots in use (uniform)
+  // Homes: block q of 64 consecutive starts sits on the 64 lanes of slot q / 8 of wave q % 8 -- a (wave, slot) group covers
+  // one stretch of the time axis (a pick overlaps few groups), and the groups a pick does overlap are spread over all waves.
+  const int hbase = wave * 64 + lane;               // home of slot r: hbase + r * NTR
+  const float NINF = -INFINITY;
+  float sc[RSLOT], x1[RSLOT], x2[RSLOT];            // sc = -inf: no candidate here (never was, picked, or dead)
+  float gmn = INFINITY, gmx = NINF;                 // lane r: the stretch [min start, max end] of this wave's slot r
+#pragma unroll
+  for (int r = 0; r < RSLOT; ++r) {
+    sc[r] = NINF; x1[r] = 0.f; x2[r] = 0.f;
+    if (r < rmax) {
+      const int h = hbase + r * NTR;
+      if (h < n) {
+        x1[r] = w.x1[h]; x2[r] = w.x2[h]; sc[r] = w.sc[h];
+        const int orig = w.ind[h];
+        L.pos_of[h] = (unsigned short)orig;
+        L.cand_at[orig] = (unsigned short)h;
+      }
+      const float lo = -wave_max(h < n ? -x1[r] : NINF), hi = wave_max(h < n ? x2[r] : NINF);
+      if (lane == r) { gmn = lo; gmx = hi; }
+    }
+  }
+  for (int k = tid; k < (n + 31) / 32; k += NTR) L.bits[k] = (k * 32 + 32 <= n) ? 0xffffffffu : ((1u << (n & 31)) - 1u);
+  if (tid == 0) L.s_flag = 0;
+  if (tid < 32) L.exptab[tid] = kExp2fTab[tid];
+  lds_barrier();
+
+  int nsegs = n, i = 0;
+  for (; i < nsegs; ++i) {
+    if (max_num > 0 && i >= max_num) break;
+    NSTAMP(0);
+    // ---- (a1) the maximum SCORE: one v_max per candidate, DPP wave reduction, 8-entry fold
+    float lm = sc[0];
+#pragma unroll
+    for (int r = 1; r < RSLOT; ++r) lm = fmaxf(lm, sc[r]);
+    lm = wave_max(lm);
+    if (lane == 0) L.s_val[wave] = lm;
+    lds_barrier();                                                        // #1
+    float gv = L.s_val[0];
+#pragma unroll
+    for (int q = 1; q < NWR; ++q) gv = fmaxf(gv, L.s_val[q]);
+    NSTAMP(1);
+    // ---- (a2) who holds it: ties by the lowest array position (nms_cpu.cpp:91-101); a match is rare code with static r
+    int myp = 0x7fffffff, mine = -1;
+    float bx1 = 0.f, bx2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < RSLOT; ++r) {
+      const bool eq = sc[r] == gv;
+      if (__builtin_expect(__ballot(eq) != 0ull, 0)) {
+        if (eq) {
+          const int p = (int)L.pos_of[hbase + r * NTR];
+          if (p < myp) { myp = p; mine = r; bx1 = x1[r]; bx2 = x2[r]; }
+        }
+      }
+    }
+    // lowest matching position in this wave: DPP max of the negated position (positions < 2^24 are exact in fp32; no match: 2^31)
+    const int wp = (int)(-wave_max(-(float)myp));
+    if (lane == 0) L.s_pos[wave] = wp;
+    lds_barrier();                                                        // #2
+    int rp = L.s_pos[0];
+#pragma unroll
+    for (int q = 1; q < NWR; ++q) rp = min(rp, L.s_pos[q]);
+    NSTAMP(2);
+    // ---- (b) the owner emits det row i and the two elements trade positions; its slot leaves the running
+    const bool owner = mine >= 0 && myp == rp;
+    if (owner) {
+      const int hw = hbase + mine * NTR;
+      float* d = dets + (off + i) * 3;
+      d[0] = bx1; d[1] = bx2; d[2] = gv;
+      out_idx[off + i] = (long)w.ind[hw];            // (a global round trip of the owner's wave only: the barriers do not wait for it)
+      L.s_pick[0] = bx1; L.s_pick[1] = bx2; L.s_pick[2] = bx2 - bx1 + 1e-6f;
+      if (rp != i) {
+        const unsigned short ci = L.cand_at[i];
+        L.cand_at[rp] = ci;
+        L.pos_of[ci] = (unsigned short)rp;
+      }
+      L.cand_at[i] = (unsigned short)hw;
+      L.pos_of[hw] = (unsigned short)i;
+    }
+    const int kill = owner ? mine : -1;
+#pragma unroll
+    for (int r = 0; r < RSLOT; ++r) sc[r] = kill == r ? NINF : sc[r];
+    lds_barrier();                                                        // #3
+    NSTAMP(3);
+    // ---- (c) decay (nms_cpu.cpp:124-143) in the (wave, slot) groups whose stretch meets the pick; the first pick visits
+    // everybody (an initial score below min_score dies there, overlap or not)
+    const float ix1 = L.s_pick[0], ix2 = L.s_pick[1], ia = L.s_pick[2];
+    const int first = i + 1;
+    unsigned long long died = 0;
+    unsigned long long ovm = __ballot(lane < rmax && ix2 > gmn && ix1 < gmx);
+    if (i == 0) ovm = rmax >= 64 ? ~0ull : ((1ull << rmax) - 1ull);
+#pragma unroll
+    for (int g8 = 0; g8 < (RSLOT + 7) / 8; ++g8) {
+      if ((ovm >> (8 * g8)) & 0xffull) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = 8 * g8 + u;
+          if (r < RSLOT && ((ovm >> r) & 1ull)) {
+            if (sc[r] != NINF) {
+              const float xx1 = fmaxf(ix1, x1[r]);
+              const float xx2 = fminf(ix2, x2[r]);
+              const float inter = fmaxf(0.f, xx2 - xx1);
+              if (inter > 0.f) {                                            // (IoU 0: the weight is exp(-0) = 1 exactly)
+                const float ja = x2[r] - x1[r] + 1e-6f;
+                const float ovr = inter / (ia + ja - inter);
+                sc[r] = sc[r] * expf_libm_tab(-(ovr * ovr) / sigma, L.exptab);
+              }
+              if (sc[r] < min_score) {
+                sc[r] = NINF;
+                died |= 1ull << r;
+                const int pd = L.pos_of[hbase + r * NTR];
+                atomicAnd(&L.bits[pd >> 5], ~(1u << (pd & 31)));
+                L.s_flag = 1;
+              }
+            }
+          }
+        }
+      }
+    }
+    lds_barrier();                                                        // #4
+    NSTAMP(5);
+    if (L.s_flag) {                                                         // (uniform)
+      // ---- (d) swap-with-last removals (nms_cpu.cpp:146-154): ranks through the bitmap
+      const int span = nsegs - first;
+      const int w0 = first >> 5, w1 = (nsegs - 1) >> 5;                     // span > 0 here (somebody died)
+      if (wave == 0) {
+        const int nw = w1 - w0 + 1, per = (nw + 63) / 64;
+        const int e0 = w0 + lane * per, e1 = min(w1 + 1, e0 + per);
+        int sum = 0;
+        for (int e = e0; e < e1; ++e) {
+          unsigned b = L.bits[e];
+          if (e == w0) b &= ~((1u << (first & 31)) - 1u);
+          if (e == w1 && (nsegs & 31)) b &= (1u << (nsegs & 31)) - 1u;
+          sum += __popc(b);
+        }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += t;
+        }
+        int run = inc - sum;
+        for (int e = e0; e < e1; ++e) {
+          unsigned b = L.bits[e];
+          if (e == w0) b &= ~((1u << (first & 31)) - 1u);
+          if (e == w1 && (nsegs & 31)) b &= (1u << (nsegs & 31)) - 1u;
+          L.pref[e] = (unsigned)run;
+          run += __popc(b);
+        }
+        if (lane == 63) L.s_nalive = inc;
+        if (lane == 0) L.s_flag = 0;
+      }
+      lds_barrier();                                                      // #4
+      const int n_alive = L.s_nalive;
+      const int new_n = first + n_alive;
+      // alive positions in [first, p)
+      auto alive_before = [&](int p) {
+        const int e = p >> 5;
+        unsigned b = L.bits[e] & ((1u << (p & 31)) - 1u);
+        if (e == w0) b &= ~((1u << (first & 31)) - 1u);
+        return (int)L.pref[e] + __popc(b);
+      };
+      const int tail = nsegs - new_n;                                       // == the number of deaths of this pick
+      unsigned short* fill = tail <= FILL_CAP ? L.fill : nullptr;
+      int* gfill = w.tmp;
+      if (n_alive != span) {
+        for (int p = new_n + tid; p < nsegs; p += NTR) {
+          if ((L.bits[p >> 5] >> (p & 31)) & 1u) {
+            const int t = n_alive - alive_before(p) - 1;                    // rank from the end among the survivors
+            if (fill) fill[t] = L.cand_at[p]; else gfill[t] = (int)L.cand_at[p];
+          }
+        }
+        if (fill) lds_barrier(); else __syncthreads();                    // #5 (the global scratch list needs the full barrier)
+        unsigned long long dd = died;
+        while (dd) {
+          const int r = __builtin_ctzll(dd);
+          dd &= dd - 1;
+          const int pd = L.pos_of[hbase + r * NTR];
+          if (pd < new_n) {
+            const int hidx = (pd - first) - alive_before(pd);               // rank among the holes, ascending
+            const unsigned short c = fill ? fill[hidx] : (unsigned short)gfill[hidx];
+            L.cand_at[pd] = c;
+            L.pos_of[c] = (unsigned short)pd;
+          }
+        }
+        lds_barrier();                                                    // #6 (every rank is taken before the bitmap changes)
+        dd = died;
+        while (dd) {
+          const int r = __builtin_ctzll(dd);
+          dd &= dd - 1;
+          const int pd = L.pos_of[hbase + r * NTR];
+          if (pd < new_n) atomicOr(&L.bits[pd >> 5], 1u << (pd & 31));
+        }
+      }
+      NSTAMP(6);
+      nsegs = new_n;            // (no barrier: the bitmap is next written after two more barriers and read after three)
+    }
+  }
+  if (threadIdx.x == 0) out_cnt[cls] = i;
+}
+
 }  // namespace
+
+#ifdef VILCO_LAB_NMS
+extern "C" int vilco_lab_nms_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(vilco_lab_nms_stamps), sizeof(unsigned long long) * 32 * 8);
+}
+#endif
 
 static bool soft_legacy() {
   static const bool v = [] { const char* e = getenv("VILCO_SOFTNMS_LEGACY"); return e && e[0] == '1'; }();
@@ -603,7 +914,7 @@ extern "C" int vilco_nms_1d(const float* segs, const float* scores, const int64_
   const size_t per = (size_t)(n_total > 0 ? n_total : 1) * 7 * sizeof(float);
   long* kbase = reinterpret_cast<long*>((reinterpret_cast<uintptr_t>(workspace) + per + 255) / 256 * 256);
   const int rblocks = (int)((n_total + 255) / 256);
-  hipLaunchKernelGGL(nms_rank_kernel, dim3(rblocks > 0 ? rblocks : 1), dim3(256), 0, s, segs, scores, so, nseg, oc, kbase,
+  hipLaunchKernelGGL(nms_rank_kernel<false>, dim3(rblocks > 0 ? rblocks : 1), dim3(256), 0, s, segs, scores, so, nseg, oc, kbase,
                      workspace, (long)n_total);
   // a class cannot be longer than n_total: ceil(n_total / CH) chunk rounds cover every class (the workgroups of a class
   // that ended earlier return at once)
@@ -629,8 +940,27 @@ extern "C" int vilco_softnms_1d(const float* segs, const float* scores, const in
   if (nseg == 0) return VILCO_OK;
   if (!segs || !scores || !dets || !out_idx || !workspace) return VILCO_ERR_BADARG;
   if (n_total < 0 || workspace_bytes < vilco_nms_workspace(n_total, nseg)) return VILCO_ERR_WORKSPACE;
-  // (the host knows the total only: every class fits the row-strided kernel when the total does)
-  if (n_total <= (int64_t)SROWS * NT && !soft_legacy())
+  // (the host knows the total only: every class fits a kernel's limit when the total does)
+  static const int soft_reg = [] { const char* e = getenv("VILCO_SOFTNMS_REG"); return e ? atoi(e) : 1; }();
+  if (soft_reg && method == 2 && n_total <= (int64_t)REG_MAXN && !soft_legacy()) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long* so = reinterpret_cast<const long*>(seg_off);
+    long* oc = reinterpret_cast<long*>(out_cnt);
+    const size_t per = (size_t)(n_total > 0 ? n_total : 1) * 7 * sizeof(float);
+    long* kbase = reinterpret_cast<long*>((reinterpret_cast<uintptr_t>(workspace) + per + 255) / 256 * 256);
+    const int rblocks = (int)((n_total + 255) / 256);
+    hipLaunchKernelGGL(nms_rank_kernel<true>, dim3(rblocks > 0 ? rblocks : 1), dim3(256), 0, s, segs, scores, so, nseg, oc, kbase,
+                       workspace, (long)n_total);
+    static const bool once = [] {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&softnms_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sizeof(RegLds));
+      (void)hipGetLastError();
+      return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL(softnms_reg_kernel, dim3(nseg), dim3(NTR), sizeof(RegLds), s, so, iou_threshold, sigma, min_score, method,
+                       (long)max_num, dets, reinterpret_cast<long*>(out_idx), oc, workspace, (long)n_total);
+  } else if (n_total <= (int64_t)SROWS * NT && !soft_legacy())
     hipLaunchKernelGGL(softnms_rows_kernel, dim3(nseg), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), segs,
                        scores, reinterpret_cast<const long*>(seg_off), iou_threshold, sigma, min_score, method,
                        (long)max_num, dets, reinterpret_cast<long*>(out_idx), reinterpret_cast<long*>(out_cnt),
