@@ -7,10 +7,10 @@ d = json.loads(open(os.path.join(ROOT, "profiles", tag + "_bench.json")).read().
 r = d["roofline"]
 stats = os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
-ng = sum(int(x["Calls"]) for x in rows if "gemm_pp_kernel" in x["Name"] or "gemm_gl_kernel" in x["Name"])
+ng = sum(int(x["Calls"]) for x in rows if "gemm_pp_kernel" in x["Name"] or "gemm_gl_" in x["Name"] or "gemm_sp_kernel" in x["Name"])
 gps = int(r.get("launches_per_step", 321))      # GEMM launches per step, counted live by bench.py
 ns = max(1, round(ng / gps))
-gemm_avg = sum(float(x["TotalDurationNs"]) for x in rows if "gemm_pp_kernel" in x["Name"] or "gemm_gl_kernel" in x["Name"]) / ng / 1e3
+gemm_avg = sum(float(x["TotalDurationNs"]) for x in rows if "gemm_pp_kernel" in x["Name"] or "gemm_gl_" in x["Name"] or "gemm_sp_kernel" in x["Name"]) / ng / 1e3
 table = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_table.py"), stats, str(ns), "22"],
                        capture_output=True, text=True).stdout.strip().splitlines()
 head, body = table[0], table[1:]

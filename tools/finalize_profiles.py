@@ -8,13 +8,13 @@ f = json.load(open(g(TAG + '_pmc_fetch.json'))); w = json.load(open(g(TAG + '_pm
 def agg(rows, key):
     tot = n = 0
     for r in rows:
-        if 'gemm_pp_kernel' in r['kernel'] or 'gemm_gl_kernel' in r['kernel']:
+        if 'gemm_pp_kernel' in r['kernel'] or 'gemm_gl_' in r['kernel'] or 'gemm_sp_kernel' in r['kernel']:
             tot += r[key]; n += r['launches']
     return tot, n
 ft, fn = agg(f, 'FETCH_SIZE'); wt, wn = agg(w, 'WRITE_SIZE')
 per = 2 * ft * 1024 / fn + wt * 1024 / wn
 rows = list(csv.DictReader(open(g(TAG + '_bench_kernel_stats.csv'))))
-gg = [r for r in rows if 'gemm_pp_kernel' in r['Name'] or 'gemm_gl_kernel' in r['Name']]
+gg = [r for r in rows if 'gemm_pp_kernel' in r['Name'] or 'gemm_gl_' in r['Name'] or 'gemm_sp_kernel' in r['Name']]
 tot = sum(float(r['TotalDurationNs']) for r in gg); calls = sum(int(r['Calls']) for r in gg)
 out = {"gemm_kernels": {"launches_fetch_pass": fn, "launches_write_pass": wn, "FETCH_SIZE_KB_sum": ft, "WRITE_SIZE_KB_sum": wt,
        "hbm_bytes_per_launch": per, "rocprof_avg_launch_us": tot / calls / 1e3, "rocprof_launches": calls,

@@ -18,7 +18,7 @@ def load(path):
     first = None
     for r in csv.DictReader(open(path)):
         n = r['Kernel_Name'].replace('(anonymous namespace)::', '')
-        if 'gemm_gl_kernel' not in n and 'gemm_pp_kernel' not in n: continue
+        if 'gemm_gl_' not in n and 'gemm_pp_kernel' not in n and 'gemm_sp_kernel' not in n: continue
         n = n[:48]
         if first is None: first = r['Counter_Name']
         agg[n][r['Counter_Name']] += float(r['Counter_Value'])

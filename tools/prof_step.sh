@@ -6,7 +6,7 @@ VILCO_BENCH_SETTLE_S=${SETTLE:-1} rocprofv3 --kernel-trace --stats --output-form
 cp /tmp/ps/s_kernel_stats.csv $R/gpurun_out/${TAG:-step}_kernel_stats.csv
 NS=$(python3 - <<'PY'
 import csv
-n = sum(int(r['Calls']) for r in csv.DictReader(open('/tmp/ps/s_kernel_stats.csv')) if 'gemm_pp_kernel' in r['Name'] or 'gemm_gl_kernel' in r['Name'])
+n = sum(int(r['Calls']) for r in csv.DictReader(open('/tmp/ps/s_kernel_stats.csv')) if 'gemm_pp_kernel' in r['Name'] or 'gemm_gl_' in r['Name'] or 'gemm_sp_kernel' in r['Name'])
 import os
 print(max(1, round(n / int(os.environ.get('GEMMS_PER_STEP', '321')))))
 PY

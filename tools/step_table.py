@@ -7,7 +7,7 @@ tot = sum(float(r['TotalDurationNs']) for r in rows)
 groups = {}
 def grp(n):
     n = n.replace('(anonymous namespace)::', '')
-    for k in ('gemm_gl_kernel', 'gemm_pp_kernel', 'amax_kernel', 'pack_kc', 'pack_tr', 'splitk_reduce', 'attn_bwd_dkdv', 'attn_bwd_dq', 'attn_fwd', 'attn_delta',
+    for k in ('gemm_gl_group_kernel', 'gemm_gl_kernel', 'gemm_sp_kernel', 'gemm_pp_kernel', 'amax_kernel', 'pack_kc', 'pack_tr', 'splitk_reduce', 'attn_bwd_dkdv', 'attn_bwd_dq', 'attn_fwd', 'attn_delta',
               'reduce_rows', 'ln_bwd', 'ln_fwd', 'act_bwd', 'relshift', 'dwconv3', 'colsum', 'permute3', 'scale_add', 'adamw', 'sqnorm',
               'maxpool', 'transpose2d', 'add_pe', 'axpby', 'mask_rows'):
         if k in n: return k

@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(512) void gemm_gl_group_kernel(GArgsN gg) {
   gemm_gl_body<BM, AKM, BKM, false>(gg.g[blockIdx.z], 0);
 }
 
+
 // out = epilogue(alpha * sum_s part[s]).  VEC (16-byte aligned rows, N % 4 == 0: the layout the MFMA kernel's own
 // 16-byte partial stores require): a thread finishes four consecutive columns, and the partials of up to four splits
 // are requested before the first one is added -- a scalar loop over the splits is one memory round trip per split.
