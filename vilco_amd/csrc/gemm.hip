@@ -1267,7 +1267,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
       // gemm_gl_kernel: a round of 128-row tiles takes 0.74 of a round of 192-row tiles, not 2/3 (measured, round 5:
       // 4608 x 4096 x 1024 as 5 rounds of 128 rows 131 us, as 3 rounds of 192 rows 107 us; 8192^3 3.33 vs 2.74 ms)
       p.BM = 192; best = c192;
-      if (((tiles128 + 255) / 256) * 142 < best) { p.BM = 128; best = 0; }
+      if (((tiles128 + 255) / 256) * 150 < best) { p.BM = 128; best = 0; }      // (142 measured; near-ties go to the taller tile: 4608 x 3072 x 1024 92.8 vs 96.6 us)
     }
     else if ((d->precision == 3 || d->precision == 4) && c192 < best) { p.BM = 192; best = c192; }
     if (!p.gl && c128 < best) { p.BM = 128; best = c128; }
