@@ -242,3 +242,34 @@ def test_switching_precision_between_calls_recaptures(dev, seed_word_zero):
     finally:
         ops.set_precision(old_prec)
         ops.dw_precision = old_dw
+
+
+def test_a_replayed_step_never_stalls_the_host(dev, seed_word_zero):
+    """Round 5: the host half of the step (PtTransformer.prepare: MQ/libs/modeling/meta_archs.py:1134-1221, plus the
+    ground-truth table) copied three small host tables from pageable memory -- each such copy waits for the stream to
+    drain, so every step's launches were exposed behind the previous step (1.6 ms of 23.7 at config P,
+    tools/lab/replay_ab.py).  torch's sync debug mode raises on any synchronising call: prepare() and a whole replayed
+    step (clips' features resident on the device, labels / segments on the host as the reference's loader leaves them)
+    must get through it."""
+    from vilco_amd.graph import GraphedStep
+    gold = load_golden("noxl")
+    model = build_hip_model(gold, dev).train()
+    batch = golden_inputs(gold)
+    batch = [dict(x, feats=x['feats'].to(dev), prompt_feature=x['prompt_feature'].to(dev)) if 'prompt_feature' in x
+             else dict(x, feats=x['feats'].to(dev)) for x in batch]
+    gs = GraphedStep(model, None, eager_steps=1)
+    model.loss_normalizer = 100.0
+    for _ in range(3):
+        out = gs(batch, task_id=gold['task_id'])
+    assert gs.stats['replayed'] >= 1
+    torch.cuda.synchronize()
+    old = torch.cuda.get_sync_debug_mode()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        inp = model.prepare(batch, True)
+        for _ in range(2):
+            out = gs(batch, task_id=gold['task_id'])
+    finally:
+        torch.cuda.set_sync_debug_mode(old)
+    assert inp.lens.device.type == 'cuda' and inp.gt is not None
+    assert torch.isfinite(out['final_loss']).item()

@@ -473,7 +473,7 @@ class PtTransformer(nn.Module):
         batched = torch.full((len(feats), feats[0].shape[0], max_len), padding_val, dtype=torch.float32, device=dev)
         for f, dst in zip(feats, batched):
             dst[..., :f.shape[-1]].copy_(f, non_blocking=True)       # H2D (or D2D) of the raw [C, t_i]
-        lens = torch.as_tensor(feats_lens, dtype=torch.int32).to(dev)
+        lens = self._h2d(torch.as_tensor(feats_lens, dtype=torch.int32))
         return batched, lens, max_len
 
     def preprocessing(self, video_list, is_training=True, padding_val=0.0):
@@ -502,7 +502,7 @@ class PtTransformer(nn.Module):
         batched = torch.full((len(feats), feats[0].shape[0], max(lens_h)), padding_val, dtype=torch.float32, device=dev)
         for f, dst in zip(feats, batched):
             dst[..., :f.shape[-1]].copy_(f, non_blocking=True)
-        lens = torch.as_tensor(lens_h, dtype=torch.int32).to(dev)
+        lens = self._h2d(torch.as_tensor(lens_h, dtype=torch.int32))
         narr = None
         if self.training and self.narration_ssl:
             nf = [x['narration_feats'] for x in video_list]
@@ -528,7 +528,16 @@ class PtTransformer(nn.Module):
             gt[b, :2 * n] = x['segments'].reshape(-1).float().cpu()
             gt[b, 2 * nmax:2 * nmax + n] = x['labels'].float().cpu()
             gt[b, 3 * nmax] = n
-        return gt.to(self.device, non_blocking=True)
+        return self._h2d(gt)
+
+    def _h2d(self, host):
+        """small host table -> device without stalling the host: a copy from pageable memory waits for everything queued
+        on the stream before it (one drained queue per step = the next step's ~1.6 ms of launches exposed, measured with
+        tools/lab/replay_ab.py at config P); from a pinned staging block it is just another queued copy"""
+        dev = self.device
+        if dev.type == 'cuda':
+            host = host.pin_memory()
+        return host.to(dev, non_blocking=True)
 
     def prepare(self, video_list, is_training=True, gt_pad=None):
         """Everything `forward` takes from the clip dictionaries, as device tensors: the host half of the step (padding,
