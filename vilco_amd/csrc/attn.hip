@@ -534,6 +534,29 @@ __device__ unsigned long long vilco_lab_attn_stamps[64 * 8];
 #define ASTAMP(i) do {} while (0)
 #endif
 
+// XL kernels: NR rows of position scores (256 B each: 64 keys of one query row of the unshifted matrix, element
+// bd[i][Tq - i + j] = bias + i (ld - 1) + Tq + j) straight into LDS by LDS-DMA, one row per instruction, row r to lds0 + r * 272.
+// Inline asm with scalar addressing (row address and LDS address in SGPRs, the lane's key offset `voff` = 4 min(j, Tk - 1) in
+// one VGPR), for two measured reasons (tools/lab/attn_stamps_xl.py, round 5: the phase that issued the 32 rows took 4.4 k cycles
+// against 1.4 k without them): (1) through __builtin_amdgcn_global_load_lds the compiler's wait-count pass treats every later
+// LDS read as a possible alias of the DMA's LDS write and puts s_waitcnt vmcnt(0) right behind the issue loop -- the prefetch
+// was synchronous; the asm is opaque to it and the kernels wait explicitly where they consume; (2) the per-lane 64-bit
+// address arithmetic was ~10 VALU instructions per row.  M0 carries the LDS address (no other user of M0 in these kernels).
+// `q_first` and `bias` must be wave-uniform.
+template <int NR>
+__device__ __forceinline__ void xl_dma_rows(const float* bias, int ld, int Tq, int q_first, unsigned voff, unsigned lds0) {
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    int qi = q_first + r;
+    qi = qi < Tq ? qi : Tq - 1;
+    const float* row = bias + ((long)qi * (ld - 1) + Tq);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds0 + (unsigned)r * 272u), "v"(voff), "s"(row) : "memory");
+  }
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // XL: XLNet's relative attention (mask mode 3: additive position scores read unshifted from bd[b,h,i,Tq-i+j], the XLNet
 // mask -- keys >= kv_len masked except the diagonal --, dropout on the probabilities): same kernel, three more steps
 template <bool XL>
@@ -560,17 +583,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
   // under the previous tile's MFMAs.  Rows are wave-private: no workgroup barrier is involved.
   constexpr int RSBF = 68;                                   // floats per staged row (272 B: 16-byte aligned, 4 banks per row)
   float* sBias = reinterpret_cast<float*>(sV + 2 * PL64) + wave * 32 * RSBF;
-  [[maybe_unused]] auto bias_dma = [&](int k0) {
-    int j = k0 + lane;
-#pragma unroll 4
-    for (int r = 0; r < 32; ++r) {
-      int qi = q0 + r;
-      qi = qi < a.Tq ? qi : a.Tq - 1;
-      int pcol = a.Tq - qi + j;
-      pcol = pcol < bias_ld ? pcol : bias_ld - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + (long)qi * bias_ld + pcol),
-                                       (__attribute__((address_space(3))) void*)(sBias + r * RSBF), 4, 0, 0);
-    }
+  const int q0s = __builtin_amdgcn_readfirstlane(q0);
+  const unsigned sbias_lds = XL ? (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(sBias)) : 0u;
+  [[maybe_unused]] auto bias_dma = [&](int k0, int g) {      // the 16 rows of query group g
+    const int j = k0 + lane;
+    xl_dma_rows<16>(bias, bias_ld, a.Tq, q0s + 16 * g, 4u * (unsigned)(j < a.Tk ? j : a.Tk - 1), sbias_lds + (unsigned)g * 16u * 272u);
   };
   const float c2 = a.scale * sc.iq * sc.ik * 1.44269504088896340736f;      // log2-domain score = acc * c2
   const __bf16* kbase = a.kn.p + (long)bh * a.kn.batch_stride;
@@ -632,6 +649,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
     const int stamp_t = t;
 #endif
     ASTAMP(0);
+    // XL: this tile's position scores (issued during the previous tile) have landed -- the K / V registers below need every
+    // outstanding load anyway; the next tile's prefetches are issued after this point
+    if constexpr (XL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                // previous tile fully consumed
     lstore();
     __syncthreads();
@@ -665,7 +685,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
       s[0][mi] = c0; s[1][mi] = c1;
     }
     ASTAMP(2);
-    if constexpr (XL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile's position scores have landed
     if constexpr (MASKED && !XL) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -739,14 +758,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { oacc[g][i][0] *= alpha; oacc[g][i][1] *= alpha; oacc[g][i][2] *= alpha; oacc[g][i][3] *= alpha; }
       }
-    }
-    ASTAMP(3);
-    if constexpr (XL) {
-      if (more) {                                   // next tile's position scores: this wave has read its rows (LDS queue in order)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        bias_dma(k0 + BKV);
+      if constexpr (XL) {
+        if (more) {                                 // next tile's position scores of this group's 16 rows: the wave has read them
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (LDS queue in order); group 0's fly under group 1's softmax
+          bias_dma(k0 + BKV, g);
+        }
       }
     }
+    ASTAMP(3);
     // O^T[d][q] += V^T P^T, V^T fragments by transposing reads of the natural tile (keys in the order P sits in the registers)
     bf16x8 vf[2][2];
 #pragma unroll
@@ -774,7 +793,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
   };
 
   if (ntiles > 0) gload(0);
-  if constexpr (XL) { if (ntiles > 0) bias_dma(0); }
+  if constexpr (XL) { if (ntiles > 0) { bias_dma(0, 0); bias_dma(0, 1); } }
   const int nfull = (XL ? (len < a.Tk ? len : a.Tk) : kend) / BKV;      // tiles with all 64 keys valid
   for (int t = 0; t < nfull; ++t) tile(t, t + 1 < ntiles, std::false_type{});
   for (int t = nfull; t < ntiles; ++t) tile(t, t + 1 < ntiles, std::true_type{});
@@ -1081,17 +1100,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
   float* dbias = XL ? a.dbias + row_bh * a.Tk : nullptr;
   constexpr int RSBF = 68;                                   // see attn_fwd64_kernel
   float* sBias = reinterpret_cast<float*>(sV + 2 * PL64) + wave * 32 * RSBF;
+  const int q0s = __builtin_amdgcn_readfirstlane(q0);
+  const unsigned sbias_lds = XL ? (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(sBias)) : 0u;
   [[maybe_unused]] auto bias_dma = [&](int k0) {
     const int j = k0 + lane;
-#pragma unroll 4
-    for (int r = 0; r < 32; ++r) {
-      int qi = q0 + r;
-      qi = qi < a.Tq ? qi : a.Tq - 1;
-      int pcol = a.Tq - qi + j;
-      pcol = pcol < bias_ld ? pcol : bias_ld - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + (long)qi * bias_ld + pcol),
-                                       (__attribute__((address_space(3))) void*)(sBias + r * RSBF), 4, 0, 0);
-    }
+    xl_dma_rows<32>(bias, bias_ld, a.Tq, q0s, 4u * (unsigned)(j < a.Tk ? j : a.Tk - 1), sbias_lds);
   };
   const __bf16* knb = a.kn.p + (long)bh * a.kn.batch_stride;
   const __bf16* vnb = a.vn.p + (long)bh * a.vn.batch_stride;
@@ -1153,12 +1166,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
   auto tile = [&](int t, bool more, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     const int k0 = t * BKV;
+    // XL: this tile's position scores (issued during the previous tile) have landed; waited for HERE, where the K / V
+    // registers need every outstanding load anyway -- not behind the next tile's prefetch just below
+    if constexpr (XL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                // previous tile fully consumed
     lstore();
     __syncthreads();
     if (more) gload(k0 + BKV);
 
-    if constexpr (XL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this tile's position scores have landed (the K / V prefetch too)
     bf16x8 dsf[2][2][2];                            // [group][32-key half][part]: dS^T B fragments, built in registers
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
@@ -1337,17 +1352,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
   const float* bias = XL ? a.bias + row_bh * bias_ld : nullptr;
   constexpr int RSBF = 68;
   float* sBias = reinterpret_cast<float*>(sdO + 2 * PL64);     // [2 stages][64 q][RSBF]
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned sbias_lds = XL ? (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(sBias)) : 0u;
+  const unsigned bias_voff = 4u * (unsigned)(k0 + lane < a.Tk ? k0 + lane : a.Tk - 1);
   [[maybe_unused]] auto bias_dma = [&](int q0, int stage) {     // this wave's 16 query rows of the tile
-    int jcol = k0 + lane;
-#pragma unroll 4
-    for (int r = 0; r < 16; ++r) {
-      int qi = q0 + wave * 16 + r;
-      qi = qi < a.Tq ? qi : a.Tq - 1;
-      int pcol = a.Tq - qi + jcol;
-      pcol = pcol < bias_ld ? pcol : bias_ld - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + (long)qi * bias_ld + pcol),
-                                       (__attribute__((address_space(3))) void*)(sBias + (stage * 64 + __builtin_amdgcn_readfirstlane(wave) * 16 + r) * RSBF), 4, 0, 0);
-    }
+    xl_dma_rows<16>(bias, bias_ld, a.Tq, q0 + wave_s * 16, bias_voff, sbias_lds + (unsigned)(stage * 64 + wave_s * 16) * 272u);
   };
   const bool xl_edge = XL && (k0 + 64 > len || k0 + 64 > a.Tk);      // some key of this workgroup is beyond kv_len / Tk
 
@@ -1362,6 +1371,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
   // staging: thread owns chunks (row = tid >> 3 (+32), 16-byte chunk c = tid & 7) of the Q and the dO tile; query rows
   // >= Tq are ZERO (their probabilities are garbage-but-finite and must meet zeros in dV / dK)
   bf16x8 stQ[2][2], stO[2][2];
+  // lse (threads 0..63) and delta (64..127) of the tile's 64 queries take the same road as the Q / dO tile: one register per
+  // thread, loaded a tile ahead, stored to LDS between the barriers.  Read from global memory inside the tile (round 4) they
+  // were the youngest loads in flight, and the wait for them (vmcnt counts in order) drained the prefetch issued just before.
+  __shared__ __attribute__((aligned(16))) float sLD[128];
+  float stL = 0.f;
   const int srow = tid >> 3, sc8 = tid & 7;
   auto gload = [&](int q0) {
 #pragma unroll
@@ -1375,6 +1389,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
         stO[q][i] = ok ? *reinterpret_cast<const bf16x8*>(donb + q * a.don.part_stride + (long)qr * HDP + sc8 * 8) : z;
       }
     }
+    if (tid < 128) {
+      const int qi = q0 + (tid & 63);
+      stL = qi < a.Tq ? (tid < 64 ? a.lse : a.delta)[row_bh + qi] : 0.f;      // queries >= Tq: 0 (their Q / dO rows are zero)
+    }
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -1386,6 +1404,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
         *reinterpret_cast<bf16x8*>(sdO + q * PL64 + o) = stO[q][i];
       }
     }
+    if (tid < 128) sLD[tid] = stL;
   };
   const f32x2 c2v = {c2, c2};
   constexpr float T37 = 7.2759576141834259e-12f;           // 2^-37: dS' = (P 2^15) ((dP - delta) 2^-37) = dS 2^-22 in plane units
@@ -1411,24 +1430,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
     [[maybe_unused]] const float* sB = sBias + (t & 1) * 64 * RSBF;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {                // 32 queries at a time: one k-step of the dV / dK products
-      // lse and delta of this lane's 8 queries (16 bb + 4 g4 + r of this half); queries >= Tq: 0 (see gload)
+      // lse and delta of this lane's 8 queries (16 bb + 4 g4 + r of this half), from the staged copy; queries >= Tq: 0
       float4 ls[2], dl[2];
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
-        const int qi = q0 + 32 * kh + 16 * bb + 4 * g4;
-        if (qi + 4 <= a.Tq) {
-          ls[bb] = *reinterpret_cast<const float4*>(a.lse + row_bh + qi);
-          dl[bb] = *reinterpret_cast<const float4*>(a.delta + row_bh + qi);
-        } else {
-          float l4[4], d4[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            l4[r] = qi + r < a.Tq ? a.lse[row_bh + qi + r] : 0.f;
-            d4[r] = qi + r < a.Tq ? a.delta[row_bh + qi + r] : 0.f;
-          }
-          ls[bb] = make_float4(l4[0], l4[1], l4[2], l4[3]);
-          dl[bb] = make_float4(d4[0], d4[1], d4[2], d4[3]);
-        }
+        ls[bb] = *reinterpret_cast<const float4*>(sLD + 32 * kh + 16 * bb + 4 * g4);
+        dl[bb] = *reinterpret_cast<const float4*>(sLD + 64 + 32 * kh + 16 * bb + 4 * g4);
       }
       f32x4 s[2], dp[2];
 #pragma unroll
