@@ -268,8 +268,9 @@ int vilco_relshift_bwd(const float* ds, float* dbd, float scale, int32_t B, int3
 /* + 4: sliding window |i - j| <= window below kv_len, Tq == Tk -- NLQ's LocalMaskedMHCA, NLQ/libs/modeling/blocks.py   */
 /* :417-755; only the key tiles a query tile's windows reach are visited);                                           */
 /* precision as vilco_gemm.  hd <= 160 (<= 64 in bf16 x3), hd % 4 == 0.  drop_p > 0: inverted dropout on the attention probabilities      */
-/* (after the softmax, before P V) with the counter-based mask of vilco_dropout: element (bh*Tq + i)*Tk + j of stream   */
-/* drop_seed; forward and backward must be given the same (drop_p, drop_seed).                                         */
+/* (after the softmax, before P V) with a counter-based mask of its own (round 5; vilco_attn_dropout_mask writes it     */
+/* out): one strong hash per row bh*Tq + i of stream drop_seed, a two-multiply finalizer per element (row key, j);      */
+/* forward and backward must be given the same (drop_p, drop_seed).                                                    */
 /* ------------------------------------------------------------------------------------------ */
 int vilco_attn_supported(int32_t hd);
 /* Output amax partials.  The hd = 64 / fp16 x2 / prefix-mask / no-bias / no-dropout kernels can leave max|x| partials of
@@ -355,6 +356,10 @@ int vilco_scale_add_bwd_amax(const float* dout, const float* bval, const float* 
 /* the backward pass is the same call on dy.  x = NULL writes the mask factors (0 or 1/(1-p)) -- what the parity tests  */
 /* hand to the oracle.  nn.Dropout in modeling_xlnet_x.py:308,327,486,488,1201,1228,1280 and blocks.py:226,268,349.      */
 int vilco_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed, uint64_t offset, void* stream);
+/* The mask factors (0 or 1/(1-p)) vilco_attn_fwd / vilco_attn_bwd apply to the attention probabilities under (p, seed):  */
+/* y[rows = B*H*Tq][cols = Tk].  For tests and for replaying a step's masks in the CPU oracle; the reference draws them    */
+/* from torch's Philox stream (nn.Dropout on the probabilities, MQ/libs/modeling/modeling_xlnet_x.py:308).                 */
+int vilco_attn_dropout_mask(float* y, int64_t rows, int32_t cols, float p, uint32_t seed, void* stream);
 /* Step word of the counter-based masks.  Every kernel that draws a dropout mask (vilco_dropout, vilco_act_bwd, the fused  */
 /* epilogue dropout of vilco_gemm, the attention-probability dropout of vilco_attn_*) uses seed + word * 0x9E3779B1, where  */
 /* `word` is ONE 32-bit value in device memory (0 after load: the effective seed is then the argument).  A training step    */

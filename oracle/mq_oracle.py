@@ -33,10 +33,11 @@ DROP = None
 
 class DropReplay:
     def __init__(self, log, mask_fn):
-        """log: ops.dropout_log entries (site, p, seed, shape) or (site, tensor); mask_fn(p, seed, shape) -> factors"""
+        """log: ops.dropout_log entries (site, p, seed, shape) or (site, tensor); mask_fn(p, seed, shape, site) -> factors
+        (the attention-probability site has a mask function of its own)"""
         self.q = {}
         for e in log:
-            m = e[1] if len(e) == 2 else mask_fn(e[1], e[2], e[3])
+            m = e[1] if len(e) == 2 else mask_fn(e[1], e[2], e[3], e[0])
             self.q.setdefault(e[0], []).append(m)
         self.p = {'droppath': 1.0, 'proj_drop': 1.0, 'mlp_drop': 1.0, 'xl': 1.0}     # > 0: every site is live
 

@@ -248,7 +248,7 @@ def p_step_three_ways(dev, realisation, oracle_dtypes=(torch.float32, torch.floa
         torch.set_num_threads(threads)
     out = {}
     # the masks are regenerated by the kernels that drew them: the device step word stays at `realisation` until they exist
-    masks = [(e[0], e[1]) if len(e) == 2 else (e[0], ops.dropout_mask(e[1], e[2], e[3], dev).cpu()) for e in log]
+    masks = [(e[0], e[1]) if len(e) == 2 else (e[0], ops.dropout_mask(e[1], e[2], e[3], dev, e[0]).cpu()) for e in log]
     torch.cuda.synchronize()
     _lib.check(_lib.load().vilco_seed_word_set(0, None))
     for dt in oracle_dtypes:

@@ -283,7 +283,7 @@ def test_xlnet_dropout_matches_oracle_with_same_masks(dev):
         ops.dropout_log = None
     assert [e[0] for e in log] == ['xl_input', 'xl_pos_emb', 'attn_prob', 'xl_attn_out', 'xl_ff_inner', 'xl_ff_out',
                                    'xl_output']
-    masks = {site: ops.dropout_mask(p, seed, shape, dev).double().cpu() for site, p, seed, shape in log}
+    masks = {site: ops.dropout_mask(p, seed, shape, dev, site).double().cpu() for site, p, seed, shape in log}
     for m in masks.values():                  # inverted dropout: factors are 0 or 1/(1-p), about 10 % zeros
         assert set(torch.unique(m.float()).tolist()) <= {0.0, float(torch.tensor(1.0 / (1.0 - 0.1), dtype=torch.float32))}
         assert 0.05 < float((m == 0).double().mean()) < 0.15
@@ -340,7 +340,7 @@ def test_train_mode_vs_oracle_with_replayed_masks(dev):
     p = {k: (v.double() if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point())
          for k, v in gold['state_dict'].items()}
     vl64 = [{k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in d.items()} for d in vl]
-    ctx = mq_oracle.DropReplay(log, lambda pr, seed, shape: ops.dropout_mask(pr, seed, shape, dev).cpu())
+    ctx = mq_oracle.DropReplay(log, lambda pr, seed, shape, site: ops.dropout_mask(pr, seed, shape, dev, site).cpu())
     mq_oracle.DROP = ctx
     try:
         want, _ = mq_oracle.forward_losses(p, cfg, vl64, task_id=gold['task_id'], n_known=gold['n_known'])

@@ -490,8 +490,8 @@ def test_attention_prob_dropout(dev, T, hd):
         (site, p, seed, shape), = ops.dropout_log
     finally:
         ops.dropout_log = None
-    assert shape == (B, H, T, T)
-    m = ops.dropout_mask(p, seed, shape, dev).double().cpu()
+    assert shape == (B, H, T, T) and site == "attn_prob"
+    m = ops.dropout_mask(p, seed, shape, dev, site).double().cpu()
     g = torch.randn(B, T, C)
     o.backward(g.to(dev))
     qd, kd, vd = [t.detach().double().cpu().requires_grad_(True) for t in (q, k, v)]
@@ -552,7 +552,7 @@ def test_attention_randomized_shapes(dev):
         finally:
             ops.dropout_log = None
             ops.set_precision(None)
-        m = ops.dropout_mask(log[0][1], log[0][2], log[0][3], dev).double().cpu() if log else 1.0
+        m = ops.dropout_mask(log[0][1], log[0][2], log[0][3], dev, log[0][0]).double().cpu() if log else 1.0
         g = torch.randn(B, Tq, C)
         o.backward(g.to(dev))
         qd, kd, vd = [t.detach().double().cpu().requires_grad_(True) for t in (q, k, v)]

@@ -37,7 +37,7 @@ for label, dwp in ((("default", 4),) if which == "default" else (("strict", None
     if want_cache is None:
         p = {k: (v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())) for k, v in model.state_dict().items()}
         vl = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d.items()} for d in batch]
-        mq_oracle.DROP = mq_oracle.DropReplay(log, lambda pr, seed, shape: ops.dropout_mask(pr, seed, shape, dev).cpu())
+        mq_oracle.DROP = mq_oracle.DropReplay(log, lambda pr, seed, shape, site: ops.dropout_mask(pr, seed, shape, dev, site).cpu())
         want, _ = mq_oracle.forward_losses(p, cfg, vl)
         want['final_loss'].backward()
         mq_oracle.DROP = None

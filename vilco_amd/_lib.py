@@ -123,6 +123,7 @@ SIGNATURES = {
     "vilco_scale_add_bwd_amax": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, c_fp, c_fp, c_fp, i32, i32, i32,
                                            c_fp, sz, c_fp, C.POINTER(i32), c_fp]),
     "vilco_dropout": (C.c_int, [c_fp, c_fp, i64, f32, C.c_uint32, C.c_uint64, c_fp]),
+    "vilco_attn_dropout_mask": (C.c_int, [c_fp, i64, i32, f32, C.c_uint32, c_fp]),
     "vilco_seed_word_set": (C.c_int, [C.c_uint32, c_fp]),
     "vilco_seed_word_bump": (C.c_int, [c_fp]),
     "vilco_seed_word_get": (C.c_int, [C.POINTER(C.c_uint32)]),

@@ -275,9 +275,11 @@ __device__ __forceinline__ void bias4(float (&bv)[4], const float* bias, int i, 
 // 1/(1-p) of inverted dropout to their outputs: O = inv_keep * (P.M) V, dV = inv_keep * dO^T (P.M), and
 // dS = P (inv_keep M dP - delta) = inv_keep * P (M dP - (1-p) delta), so nothing that enters an MFMA grows beyond its
 // undropped bound (the fp16 operand scales of P and dS stay valid for any p).
+__device__ __forceinline__ uint32_t drop_row(const AttnArgs& a, int bh, int i) {      // key of row (bh, i): common.h
+  return vilco_attn_drop_row(a.drop_seed, (uint64_t)bh * (uint64_t)a.Tq + (uint64_t)i);
+}
 __device__ __forceinline__ float drop_keep(const AttnArgs& a, int bh, int i, int j) {
-  const uint64_t idx = ((uint64_t)bh * (uint64_t)a.Tq + (uint64_t)i) * (uint64_t)a.Tk + (uint64_t)j;
-  return vilco_drop_hash(a.drop_seed, idx) >= a.drop_thresh ? 1.f : 0.f;
+  return vilco_attn_drop_keep(drop_row(a, bh, i), (uint32_t)j, a.drop_thresh) ? 1.f : 0.f;
 }
 
 // score of (query i, key j) after scale + bias: apply the mask
@@ -606,6 +608,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
 #pragma unroll
     for (int i = 0; i < 4; ++i) oacc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  [[maybe_unused]] uint32_t rkey[2] = {0u, 0u};               // XL + dropout: this lane's two rows of the mask (common.h)
+  if constexpr (XL) {
+    if (a.drop_thresh) { rkey[0] = drop_row(a, bh, q0 + (lane & 15)); rkey[1] = drop_row(a, bh, q0 + 16 + (lane & 15)); }
+  }
 
   // staging: thread owns chunks (row = tid >> 3 (+32), 16-byte chunk c = tid & 7) of the K and the V tile (both natural)
   bf16x8 stK[2][2], stV[2][2];
@@ -693,6 +699,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
           if (k0 + mi * 16 + g4 * 4 + r >= kend) { s[0][mi][r] = -INFINITY; s[1][mi][r] = -INFINITY; }
     }
     bf16x8 pb[2][2][2];                             // [group][k-step][part]: P^T B fragments, built in registers
+    [[maybe_unused]] const uint32_t jw0 = (uint32_t)(k0 + g4 * 4) * VILCO_ATTN_DROP_W;      // dropout: key part of the element hash
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       // scores to the log2 domain, then the row maximum over this lane's 16 keys and the 4 lanes of the query
@@ -736,9 +743,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
           psum += p;                                       // v_pk_add_f32 (the denominator is over the undropped probabilities)
           if constexpr (XL) {
             if (a.drop_thresh) {
-              const int j = k0 + (2 * ks + (e >> 2)) * 16 + g4 * 4 + (e & 3);
-              p[0] *= drop_keep(a, bh, qi_g, j);
-              p[1] *= drop_keep(a, bh, qi_g, j + 1);
+              const uint32_t jw = jw0 + (uint32_t)((2 * ks + (e >> 2)) * 16 + (e & 3)) * VILCO_ATTN_DROP_W;
+              p[0] = vilco_attn_drop_keep_w(rkey[g], jw, a.drop_thresh) ? p[0] : 0.f;
+              p[1] = vilco_attn_drop_keep_w(rkey[g], jw + VILCO_ATTN_DROP_W, a.drop_thresh) ? p[1] : 0.f;
             }
           }
           const f16x2 hp = {(_Float16)p[0], (_Float16)p[1]};                 // v_cvt_pk_f16_f32 (round to nearest even)
@@ -1133,6 +1140,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
   for (int g = 0; g < 2; ++g)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dqacc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] uint32_t rkey[2] = {0u, 0u};               // XL + dropout: this lane's two rows of the mask (common.h)
+  if constexpr (XL) {
+    if (a.drop_thresh) { rkey[0] = drop_row(a, bh, q0 + (lane & 15)); rkey[1] = drop_row(a, bh, q0 + 16 + (lane & 15)); }
+  }
 
   // staging: thread owns chunks (row = tid >> 3 (+32), 16-byte chunk c = tid & 7) of the K and the V tile
   bf16x8 stK[2][2], stV[2][2];
@@ -1233,8 +1244,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
               if ((j + 1 >= len && j + 1 != qi_g) || j + 1 >= a.Tk) arg[1] = -INFINITY;
             }
             if (a.drop_thresh) {                                                   // dP of a dropped probability is zero
-              pv[0] *= drop_keep(a, bh, qi_g, j);
-              pv[1] *= drop_keep(a, bh, qi_g, j + 1);
+              const uint32_t jw = (uint32_t)j * VILCO_ATTN_DROP_W;
+              pv[0] = vilco_attn_drop_keep_w(rkey[g], jw, a.drop_thresh) ? pv[0] : 0.f;
+              pv[1] = vilco_attn_drop_keep_w(rkey[g], jw + VILCO_ATTN_DROP_W, a.drop_thresh) ? pv[1] : 0.f;
             }
           }
           const f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};      // P * 2^-22
@@ -1348,6 +1360,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
   const int fbt = (4 * g4 + ((lane & 15) >> 2)) * RS64 + 4 * (lane & 3);
   const int key = k0 + wave * 16 + (lane & 15);
   const float koff = (XL || key < kend) ? 0.f : -INFINITY;       // a masked key: every probability of this lane is exp2(-inf) = 0
+  [[maybe_unused]] const uint32_t keyw = (uint32_t)key * VILCO_ATTN_DROP_W;      // dropout: this lane's key in the element hash
   const int bias_ld = a.Tq + a.Tk;
   const float* bias = XL ? a.bias + row_bh * bias_ld : nullptr;
   constexpr int RSBF = 68;
@@ -1374,7 +1387,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
   // lse (threads 0..63) and delta (64..127) of the tile's 64 queries take the same road as the Q / dO tile: one register per
   // thread, loaded a tile ahead, stored to LDS between the barriers.  Read from global memory inside the tile (round 4) they
   // were the youngest loads in flight, and the wait for them (vmcnt counts in order) drained the prefetch issued just before.
-  __shared__ __attribute__((aligned(16))) float sLD[128];
+  __shared__ __attribute__((aligned(16))) float sLD[192];     // XL + dropout: [128..191] the rows' mask keys (common.h), as bits
   float stL = 0.f;
   const int srow = tid >> 3, sc8 = tid & 7;
   auto gload = [&](int q0) {
@@ -1392,6 +1405,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
     if (tid < 128) {
       const int qi = q0 + (tid & 63);
       stL = qi < a.Tq ? (tid < 64 ? a.lse : a.delta)[row_bh + qi] : 0.f;      // queries >= Tq: 0 (their Q / dO rows are zero)
+    } else if (XL && tid < 192 && a.drop_thresh) {
+      stL = __uint_as_float(drop_row(a, bh, q0 + (tid & 63)));
     }
   };
   auto lstore = [&]() {
@@ -1404,7 +1419,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
         *reinterpret_cast<bf16x8*>(sdO + q * PL64 + o) = stO[q][i];
       }
     }
-    if (tid < 128) sLD[tid] = stL;
+    if (tid < (XL ? 192 : 128)) sLD[tid] = stL;
   };
   const f32x2 c2v = {c2, c2};
   constexpr float T37 = 7.2759576141834259e-12f;           // 2^-37: dS' = (P 2^15) ((dP - delta) 2^-37) = dS 2^-22 in plane units
@@ -1482,7 +1497,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv64_kernel(AttnArg
           // keep its probability out (2^15 * 2^score would leave the fp16 range and meet the zeros as inf * 0)
           if (qa >= a.Tq) arg[0] = -INFINITY;
           if (qa + 1 >= a.Tq) arg[1] = -INFINITY;
-          if (a.drop_thresh) { keep0 = drop_keep(a, bh, qa, key); keep1 = drop_keep(a, bh, qa + 1, key); }
+          if (a.drop_thresh) {
+            const float* rk = sLD + 128 + 32 * kh + 16 * bb + 4 * g4 + r;
+            keep0 = vilco_attn_drop_keep_w(__float_as_uint(rk[0]), keyw, a.drop_thresh) ? 1.f : 0.f;
+            keep1 = vilco_attn_drop_keep_w(__float_as_uint(rk[1]), keyw, a.drop_thresh) ? 1.f : 0.f;
+          }
         }
         f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
         // (dP - delta) 2^-37, delta brought to plane units one scale at a time (see attn_bwd_dq_kernel)

@@ -75,6 +75,24 @@ __device__ __forceinline__ uint32_t vilco_drop_hash(uint32_t seed, uint64_t idx)
   h += seed; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
   return h;
 }
+// Attention-probability dropout (the [B*H, Tq, Tk] masks of vilco_attn_*; round 5).  One strong hash per ROW of the probability
+// matrix (vilco_drop_hash over the row index bh * Tq + i), then a murmur3-style finalizer over row key + j * golden ratio per
+// element: 2 of the quarter-rate 32-bit multiplies per element instead of 4 -- the full hash per element was 28 % of the XLNet
+// forward kernel's cycles (tools/lab/attn_stamps_xl.py).  The kernels keep a lane's row keys in registers (forward / dQ: two
+// rows for the whole kernel) or stage them through LDS with the Q tile (dK-dV).  Same mask in all three kernels and in
+// vilco_attn_dropout_mask; adjacent / strided / cross-row / cross-seed correlations of the drop indicator are at the noise
+// level of 2e7 samples and row / column drop rates have binomial spread (checked on the host with numpy when it was chosen).
+__device__ __forceinline__ uint32_t vilco_attn_drop_row(uint32_t seed, uint64_t row) { return vilco_drop_hash(seed, row); }
+constexpr uint32_t VILCO_ATTN_DROP_W = 0x9E3779B1u;
+// `jw` = j * VILCO_ATTN_DROP_W (callers form it from a per-tile base plus compile-time constants)
+__device__ __forceinline__ bool vilco_attn_drop_keep_w(uint32_t rowkey, uint32_t jw, uint32_t thresh) {
+  uint32_t h = rowkey + jw;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u;
+  return h >= thresh;
+}
+__device__ __forceinline__ bool vilco_attn_drop_keep(uint32_t rowkey, uint32_t j, uint32_t thresh) {
+  return vilco_attn_drop_keep_w(rowkey, j * VILCO_ATTN_DROP_W, thresh);
+}
 // The seed a kernel actually uses: the launch's seed plus the device-resident step word (sync.hip).  A step captured as a
 // hipGraph replays its kernel arguments, so what must change from replay to replay lives in memory: the graph's first node
 // bumps the word (vilco_seed_word_bump) and every mask of the replay moves with it.  Eager launches run with word 0,

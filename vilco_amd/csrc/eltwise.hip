@@ -600,6 +600,26 @@ extern "C" int vilco_dropout(const float* x, float* y, int64_t n, float p, uint3
   return vilco_launch_status();
 }
 
+// the mask factors (0 or 1/(1-p)) of the attention-probability dropout of vilco_attn_* (common.h: vilco_attn_drop_*), for tests
+__global__ __launch_bounds__(EW_THREADS) void attn_dropout_mask_kernel(float* __restrict__ y, long rows, int cols, uint32_t thresh,
+                                                                       float inv_keep, uint32_t seed, const uint32_t* __restrict__ seed_word) {
+  seed = vilco_step_seed(seed, seed_word);
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols;
+    const bool keep = vilco_attn_drop_keep(vilco_attn_drop_row(seed, (uint64_t)r), (uint32_t)(i - r * cols), thresh);
+    y[i] = keep ? inv_keep : 0.f;
+  }
+}
+
+extern "C" int vilco_attn_dropout_mask(float* y, int64_t rows, int32_t cols, float p, uint32_t seed, void* stream) {
+  if (!y || rows < 0 || cols < 0 || !(p >= 0.f) || p >= 1.f) return VILCO_ERR_BADARG;
+  if (rows == 0 || cols == 0) return VILCO_OK;
+  hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(ew_grid(rows * cols)), dim3(EW_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                     y, (long)rows, (int)cols, vilco_drop_threshold_host(p), 1.f / (1.f - p), seed, vilco_seed_word_dev());
+  return vilco_launch_status();
+}
+
 extern "C" int vilco_axpby(float* out, const float* a, const float* b, float alpha, float beta,
                            int64_t n, void* stream) {
   if (!out || !a || n < 0) return VILCO_ERR_BADARG;

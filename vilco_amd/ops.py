@@ -328,10 +328,16 @@ def _new_drop(site, p, shape):
     return (float(p), int(seed))
 
 
-def dropout_mask(p, seed, shape, device):
-    """the mask factors (0 or 1/(1-p)) of the stream (p, seed), as the kernels apply them"""
+def dropout_mask(p, seed, shape, device, site=None):
+    """the mask factors (0 or 1/(1-p)) of the stream (p, seed), as the kernels apply them.  `site` = the site name the
+    dropout log recorded: the attention probabilities ("attn_prob", shape [B, H, Tq, Tk]) have a mask function of their
+    own (csrc/common.h: vilco_attn_drop_*)"""
     m = torch.empty(shape, dtype=torch.float32, device=device)
-    _lib.check(_lib.load().vilco_dropout(None, m.data_ptr(), m.numel(), float(p), int(seed), 0, _stream()))
+    if site == "attn_prob":
+        cols = int(shape[-1])
+        _lib.check(_lib.load().vilco_attn_dropout_mask(m.data_ptr(), m.numel() // max(cols, 1), cols, float(p), int(seed), _stream()))
+    else:
+        _lib.check(_lib.load().vilco_dropout(None, m.data_ptr(), m.numel(), float(p), int(seed), 0, _stream()))
     return m
 
 
