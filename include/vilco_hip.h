@@ -314,6 +314,22 @@ int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* 
                    int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                    uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* dq_amax, float* dk_amax, float* dv_amax,
                    float* dbias_amax, void* workspace, size_t workspace_bytes, void* stream);
+/* Round 5, XLNet's relative attention (mask mode 3, hd = 64, precision 3, Tq = Tk): the backward writes dS -- the gradient  */
+/* of the position scores, modeling_xlnet_x.py:256-288 -- directly as the fp16 x2 operand planes of the UNSHIFTED            */
+/* [Tq][Tq + Tk] view (the layout vilco_pack_many gives an item with relshift = 1, nbatch = B*H), ready for the two          */
+/* band-limited products d(qr) = d(bd) kr and d(kr) = d(bd)^T qr (vilco_gemm_desc.a_planes, band 2 / 3), instead of fp32     */
+/* dS + a pack pass (0.68 GB written, 0.68 GB read and 1.36 GB written again at config P).  `ds_planes`: at least            */
+/* vilco_attn_dsplanes_bytes(B, H, Tq) bytes, 256-byte aligned, whose out-of-band columns (p < Tq - i, p >= Tq + Tk - i of   */
+/* row i) and padding are ZERO: the kernel writes the band only, so a buffer zeroed once can be reused call after call.      */
+/* `dbias` and `dbias_amax` must be NULL with it and Tk a multiple of 64.  ds_planes NULL: exactly vilco_attn_bwd.          */
+size_t vilco_attn_dsplanes_bytes(int32_t B, int32_t H, int32_t T);
+int vilco_attn_bwd_dsplanes(const float* q, const float* k, const float* v, const float* bias,
+                   const int32_t* kv_len, const float* o, const float* lse, const float* dout,
+                   float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
+                   int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
+                   uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* dq_amax, float* dk_amax, float* dv_amax,
+                   float* dbias_amax, void* workspace, size_t workspace_bytes, void* ds_planes, size_t ds_planes_bytes,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Candidate decode of PtTransformer.inference_single_video (MQ meta_archs.py:1594-1692, NLQ meta_archs.py:1253-1338)   */

@@ -403,7 +403,8 @@ def test_attention_precision_modes(dev, mode, tol):
 
 
 @pytest.mark.parametrize("flash,T,hd", [(True, 48, 16), (False, 48, 16), (True, 100, 64), (False, 100, 64),
-                                         (True, 576, 64), (True, 100, 128)])     # 576: several key tiles, band GEMM + relshift pack
+                                         (True, 576, 64), (True, 160, 64), (True, 100, 128)])     # 576: several key tiles, band GEMM,
+# dS as operand planes from the dQ kernel (round 5; 160: a partial last key tile on that path; 100: the fp32 dS + relshift pack path)
 def test_rel_attention(dev, flash, T, hd):
     """XLNet core vs the published formula incl. rel_shift_bnij (modeling_xlnet_x.py:256-320)."""
     from vilco_amd import ops

@@ -114,6 +114,10 @@ SIGNATURES = {
     "vilco_attn_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32,
                                  i32, i32, i32, f32, i32, i32, i32, f32, C.c_uint32, C.POINTER(AttnAmaxIn), c_fp, c_fp, c_fp, c_fp, c_fp, sz,
                                  c_fp]),
+    "vilco_attn_dsplanes_bytes": (sz, [i32, i32, i32]),
+    "vilco_attn_bwd_dsplanes": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32,
+                                          i32, i32, i32, f32, i32, i32, i32, f32, C.c_uint32, C.POINTER(AttnAmaxIn), c_fp, c_fp, c_fp, c_fp,
+                                          c_fp, sz, c_fp, sz, c_fp]),
     "vilco_decode_workspace": (sz, [i32, i32]),
     "vilco_decode": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, f32, f32, c_fp, c_fp, c_fp, c_fp, c_fp, sz, c_fp]),
     "vilco_scale_add_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),

@@ -221,6 +221,10 @@ struct AttnArgs {
   // dropout), so max|v| -- whose scale this call has just folded for its own V planes -- bounds max|o|: the planes' scale is
   // sv * o_scale_mul, o_scale_mul = 2^-ceil(log2(1 / keep)).
   _Float16* op0; long o_plane_stride; float* o_inv_scale; long o_rows32; float o_scale_mul;
+  // XL backward (round 5): dS written as the fp16 x2 operand planes of XLNet's UNSHIFTED [Tq][Tq + Tk] view (pack.h tap mode 4
+  // layout: [part][b*H + h][rows32][cols32], element (i, Tq - i + j)) by attn_bwd_dq64_kernel<true> itself -- the very two
+  // halves it builds for its own dQ product -- instead of fp32 dS + a pack pass over it.  Null: fp32 dS to `dbias`.
+  _Float16* dsp; long ds_plane_stride; long ds_batch_stride; int ds_ld; float* ds_inv_scale;
 };
 
 // registers holding the B-operand fragments of this wave's 16 query rows (all k-steps, all parts)
@@ -1104,7 +1108,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
   const float ds_unscale = DS_INV * sc.ido * sc.iv * (XL ? a.drop_inv_keep : 1.f);      // dS = dS' * this
   const int bias_ld = a.Tq + a.Tk;
   const float* bias = XL ? a.bias + row_bh * bias_ld : nullptr;
-  float* dbias = XL ? a.dbias + row_bh * a.Tk : nullptr;
+  float* dbias = (XL && a.dbias) ? a.dbias + row_bh * a.Tk : nullptr;
+  [[maybe_unused]] _Float16* dsp = (XL && a.dsp) ? a.dsp + (long)bh * a.ds_batch_stride : nullptr;
   constexpr int RSBF = 68;                                   // see attn_fwd64_kernel
   float* sBias = reinterpret_cast<float*>(sV + 2 * PL64) + wave * 32 * RSBF;
   const int q0s = __builtin_amdgcn_readfirstlane(q0);
@@ -1173,6 +1178,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
   };
   const f32x2 c2v = {c2, c2};
   [[maybe_unused]] float am_ds = 0.f;               // XL: max |dS| this thread stored (for the relshift pack's scale)
+  [[maybe_unused]] uint32_t ds_carry[2][2] = {{0u, 0u}, {0u, 0u}};      // XL planes: [group][part] the row stream's previous dword
 
   auto tile = [&](int t, bool more, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
@@ -1229,6 +1235,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
         const f32x2 lv = {-lse2[g], -lse2[g]}, dv = {-dlt[g], -dlt[g]};
         [[maybe_unused]] const int qi_g = q0 + 16 * g + (lane & 15);
         u32x4 h0, h1;
+        [[maybe_unused]] float dsv[2] = {0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           const f32x2 sv = {s[g][e >> 2][e & 3], s[g][e >> 2][(e & 3) + 1]};
@@ -1251,12 +1258,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
           }
           const f32x2 p = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};      // P * 2^-22
           const f32x2 d = p * (pv + dv);                   // dS' = P (dP - delta) 2^-22, |dS'| < 2^15
-          if constexpr (XL) {                              // dS of this pair for the position-term gradients
-            if (qi_g < a.Tq) {
-              float* dst = dbias + (long)qi_g * a.Tk + j;
-              const float v0 = d[0] * ds_unscale, v1 = d[1] * ds_unscale;
-              if (j + 1 < a.Tk) { *reinterpret_cast<float2*>(dst) = make_float2(v0, v1); am_ds = fmaxf(am_ds, fmaxf(fabsf(v0), fabsf(v1))); }
-              else if (j < a.Tk) { dst[0] = v0; am_ds = fmaxf(am_ds, fabsf(v0)); }
+          if constexpr (XL) if (!dsp) {                    // dS of this lane's 4 consecutive keys for the position-term gradients:
+            const float v0 = d[0] * ds_unscale, v1 = d[1] * ds_unscale;      // ONE 16-byte store per two pairs (4-byte aligned: fine)
+            if ((e & 3) == 0) { dsv[0] = v0; dsv[1] = v1; }
+            else if (qi_g < a.Tq) {
+              float* dst = dbias + (long)qi_g * a.Tk + (j - 2);
+              if (j + 1 < a.Tk) {
+                *reinterpret_cast<float4*>(dst) = make_float4(dsv[0], dsv[1], v0, v1);
+                am_ds = fmaxf(fmaxf(am_ds, fmaxf(fabsf(dsv[0]), fabsf(dsv[1]))), fmaxf(fabsf(v0), fabsf(v1)));
+              } else {
+                const float vs[4] = {dsv[0], dsv[1], v0, v1};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (j - 2 + r < a.Tk) { dst[r] = vs[r]; am_ds = fmaxf(am_ds, fabsf(vs[r])); }
+              }
             }
           }
           const f16x2 hp = {(_Float16)d[0], (_Float16)d[1]};
@@ -1266,6 +1281,32 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
           asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hpu), "v"(d[1]));
           h0[e >> 1] = hpu;
           h1[e >> 1] = lo;
+        }
+        if constexpr (XL) {
+          // dS' as the operand planes of the unshifted view (a.dsp): this lane's 4 consecutive keys of a 16-key block are 4
+          // consecutive columns Tq - i + j of row i, both halves exactly as they enter this kernel's own dQ product (value =
+          // part sum * ds_unscale).  A row's stream of columns starts at Tq - i: on odd rows every 8-byte group would sit at a
+          // 2-byte aligned address (measured: such stores made this kernel 40 % slower), so odd rows write the stream shifted by
+          // one element -- each lane's first dword takes its low half from the stream's previous element (lane - 16 holds it:
+          // ds_bpermute; for the first lane group it is the last element of the previous block, carried in ds_carry) -- at
+          // 4-byte aligned addresses; the row's very last element is flushed after the key loop.  Tk % 64 == 0 (host check).
+          if (dsp) {
+            const bool odd = ((a.Tq - qi_g) & 1) != 0;
+            _Float16* rowp = dsp + (long)qi_g * a.ds_ld + (a.Tq - qi_g) - (odd ? 1 : 0);
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb) {
+                const uint32_t d0 = part ? h1[2 * bb] : h0[2 * bb], d1 = part ? h1[2 * bb + 1] : h0[2 * bb + 1];
+                const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - 16) & 63) * 4, (int)d1);
+                const uint32_t pred = g4 > 0 ? r : ds_carry[g][part];
+                ds_carry[g][part] = r;
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 w = {odd ? __builtin_amdgcn_alignbit(d0, pred, 16) : d0, odd ? __builtin_amdgcn_alignbit(d1, d0, 16) : d1};
+                if (qi_g < a.Tq)
+                  *reinterpret_cast<u32x2*>(rowp + part * a.ds_plane_stride + (k0 + (2 * kh + bb) * 16 + g4 * 4)) = w;      // (nontemporal: 2x slower -- the 32-byte pieces need the L2's write combining)
+              }
+          }
         }
         dsf[g][kh][0] = __builtin_bit_cast(bf16x8, h0);
         dsf[g][kh][1] = __builtin_bit_cast(bf16x8, h1);
@@ -1303,6 +1344,19 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
   const int nfull = (XL ? (len < a.Tk ? len : a.Tk) : kend) / BKV;
   for (int t = 0; t < nfull; ++t) tile(t, t + 1 < ntiles, std::false_type{});
   for (int t = nfull; t < ntiles; ++t) tile(t, t + 1 < ntiles, std::true_type{});
+  if constexpr (XL) {
+    if (dsp && g4 == 0 && ntiles > 0) {              // odd rows: the stream's last element (key Tk - 1), left in the carry
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int qi = q0 + 16 * g + (lane & 15);
+        if (qi < a.Tq && ((a.Tq - qi) & 1)) {
+          _Float16* lastp = dsp + (long)qi * a.ds_ld + (a.Tq - qi) + (a.Tk - 1);      // 4-byte aligned; its upper half is out of band
+          *reinterpret_cast<uint32_t*>(lastp) = ds_carry[g][0] >> 16;
+          *reinterpret_cast<uint32_t*>(lastp + a.ds_plane_stride) = ds_carry[g][1] >> 16;
+        }
+      }
+    }
+  }
 
   const float oscale = a.scale * ds_unscale * sc.ik;
   float am = 0.f;
@@ -1320,7 +1374,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq64_kernel(AttnArgs 
     }
   }
   if (a.am_dq) block_amax_out(am, a.am_dq, reinterpret_cast<float*>(smem_raw));
-  if constexpr (XL) { if (a.am_ds) block_amax_out(am_ds, a.am_ds, reinterpret_cast<float*>(smem_raw)); }
+  if constexpr (XL) {
+    if (a.am_ds) block_amax_out(am_ds, a.am_ds, reinterpret_cast<float*>(smem_raw));
+    if (a.dsp && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) { a.ds_inv_scale[0] = ds_unscale; a.ds_inv_scale[1] = 1.f / ds_unscale; }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ backward dK / dV, hd = 64 fast path
@@ -1937,7 +1994,7 @@ int launch_bwd(const AttnArgs& a, hipStream_t s) {
     }
   }
   bool xl_dq = false;                               // XLNet's relative attention: dQ + dS on the fast-path structure
-  if constexpr (HDP == 64 && NP == 2 && F16) xl_dq = fast64_xl_fwd(a, 3) && a.dbias != nullptr;
+  if constexpr (HDP == 64 && NP == 2 && F16) xl_dq = fast64_xl_fwd(a, 3) && (a.dbias != nullptr || a.dsp != nullptr);
   if (xl_dq) {
     if constexpr (HDP == 64 && NP == 2 && F16) {
       constexpr size_t lxl = 2 * 2 * PL64 * sizeof(__bf16) + 4 * 32 * 68 * sizeof(float);
@@ -2213,6 +2270,23 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
                               int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
                               uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* dq_amax, float* dk_amax,
                               float* dv_amax, float* dbias_amax, void* workspace, size_t workspace_bytes, void* stream) {
+  return vilco_attn_bwd_dsplanes(q, k, v, bias, kv_len, o, lse, dout, dq, dk, dv, dbias, B, H, Tq, Tk, hd, scale, mode, window, precision,
+                                 drop_p, drop_seed, amax_in, dq_amax, dk_amax, dv_amax, dbias_amax, workspace, workspace_bytes, nullptr, 0,
+                                 stream);
+}
+
+extern "C" size_t vilco_attn_dsplanes_bytes(int32_t B, int32_t H, int32_t T) {
+  const long r32 = ((long)T + 31) / 32 * 32, c32 = (2L * T + 31) / 32 * 32;
+  return (size_t)(VILCO_PACK_HDR + (long)B * H * r32 * c32 * 2 * 2);
+}
+
+extern "C" int vilco_attn_bwd_dsplanes(const float* q, const float* k, const float* v, const float* bias,
+                              const int32_t* kv_len, const float* o, const float* lse, const float* dout,
+                              float* dq, float* dk, float* dv, float* dbias, int32_t B, int32_t H, int32_t Tq,
+                              int32_t Tk, int32_t hd, float scale, int32_t mode, int32_t window, int32_t precision, float drop_p,
+                              uint32_t drop_seed, const vilco_attn_amax_in* amax_in, float* dq_amax, float* dk_amax,
+                              float* dv_amax, float* dbias_amax, void* workspace, size_t workspace_bytes, void* ds_planes,
+                              size_t ds_planes_bytes, void* stream) {
   int rc = check_common(B, H, Tq, Tk, hd, mode, precision, window);
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
   if (rc != VILCO_OK) return rc;
@@ -2235,6 +2309,15 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   a.am_dq = dq_amax; a.am_dk = dk_amax; a.am_dv = dv_amax;
   if (dbias_amax && !(fast64_xl_fwd(a, precision) && dbias)) return VILCO_ERR_UNSUPPORTED;       // XLNet fast path only (has_bias = 2)
   a.am_ds = dbias_amax;
+  if (ds_planes) {                 // XLNet fast path only; `dbias` / `dbias_amax` are then not written
+    if (dbias || dbias_amax || !fast64_xl_fwd(a, precision) || (Tk % 64) != 0 || !vilco_aligned(ds_planes, 256)) return VILCO_ERR_UNSUPPORTED;
+    if (ds_planes_bytes < vilco_attn_dsplanes_bytes(B, H, Tq)) return VILCO_ERR_WORKSPACE;
+    const long r32 = ((long)Tq + 31) / 32 * 32, c32 = ((long)Tq + Tk + 31) / 32 * 32;
+    unsigned char* u = reinterpret_cast<unsigned char*>(ds_planes);
+    a.dsp = reinterpret_cast<_Float16*>(u + VILCO_PACK_HDR);
+    a.ds_plane_stride = (long)B * H * r32 * c32; a.ds_batch_stride = r32 * c32; a.ds_ld = (int)c32;
+    a.ds_inv_scale = reinterpret_cast<float*>(u) + VILCO_AMAX_MAX_BLOCKS;
+  }
   ScaleWs sw;
   if (precision == 3) {
     const float* const xs[4] = {q, k, v, dout};
@@ -2247,7 +2330,7 @@ extern "C" int vilco_attn_bwd(const float* q, const float* k, const float* v, co
   __bf16* w = reinterpret_cast<__bf16*>(wsb + ATT_SCALE_BYTES);
   PackQueue pq;
   // the hd = 64 fast kernels read every operand from its natural planes only (transposing LDS reads)
-  const bool nat_only = fast64(a, precision) || (fast64_xl_fwd(a, precision) && a.dbias != nullptr);
+  const bool nat_only = fast64(a, precision) || (fast64_xl_fwd(a, precision) && (a.dbias != nullptr || a.dsp != nullptr));
   a.qn = pack_operand(q, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[0], sw.n[0], so, &pq);
   a.don = pack_operand(dout, w, spec_nat(B, H, Tq, HDP), false, B, H, Tq, hd, HDP, NP, s, sw.parts[3], sw.n[3], so + 6, &pq);
   if (!nat_only) {

@@ -1377,11 +1377,43 @@ def _attach_attn_planes(o):
     return o
 
 
-def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, drop=(0.0, 0), window=0):
+# XLNet backward: dS as operand planes of the unshifted view straight from the dQ kernel (vilco_attn_bwd_dsplanes) instead of
+# fp32 dS + a pack of it.  The kernel writes the band only; everything else in the buffer must be zero and stays zero, so ONE
+# buffer per (device, B*H, T) is zeroed when first needed and reused by every later backward (1.36 GB at config P; a step
+# captured as a hipGraph has met it in the eager iterations before the capture).  VILCO_XL_DS_PLANES=0: the fp32 dS + pack path.
+xl_ds_planes = os.environ.get("VILCO_XL_DS_PLANES", "1") != "0"
+_ds_plane_bufs = {}
+
+
+def _xl_ds_planes_buf(B, H, T, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), B, H, T)
+    buf = _ds_plane_bufs.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                      # never allocate-and-zero inside a capture: fall back for this call
+        if len(_ds_plane_bufs) >= 2:
+            _ds_plane_bufs.clear()                           # shapes that keep changing: keep at most two buffers alive
+        buf = torch.zeros(int(_lib.load().vilco_attn_dsplanes_bytes(B, H, T)), dtype=torch.uint8, device=device)
+        _ds_plane_bufs[key] = buf
+    return buf
+
+
+def _flash_bwd(q, k, v, bias, kv_len, o, lse, do, H, scale, mode, want_dbias, drop=(0.0, 0), window=0, ds_planes=None):
+    """ds_planes: (XLNet fast path) buffer the dQ kernel writes dS' operand planes into; the returned dbias is then None"""
     lib = _lib.load()
     B, Tq, Cn = q.shape
     Tk = k.shape[1]
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    if ds_planes is not None:
+        nws = lib.vilco_attn_bwd_workspace(B, H, Tq, Tk, Cn // H, _precision)
+        ws = _ws(nws, q.device)
+        ain = _attn_amax_in(q, k, v, do)
+        _lib.check(lib.vilco_attn_bwd_dsplanes(q.data_ptr(), k.data_ptr(), v.data_ptr(), _p(bias), _p(kv_len), o.data_ptr(),
+                                               lse.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), None,
+                                               B, H, Tq, Tk, Cn // H, scale, mode, int(window), _precision, float(drop[0]),
+                                               int(drop[1]), C.byref(ain[0]) if ain else None, None, None, None, None,
+                                               ws.data_ptr(), nws, ds_planes.data_ptr(), ds_planes.numel(), _stream()))
+        return dq, dk, dv, None
     dbias = torch.empty(B, H, Tq, Tk, dtype=torch.float32, device=q.device) if want_dbias else None
     nws = lib.vilco_attn_bwd_workspace(B, H, Tq, Tk, Cn // H, _precision)
     ws = _ws(nws, q.device)
@@ -1542,15 +1574,21 @@ class _FlashRelAttention(torch.autograd.Function):
         hd = Cn // H
         per_clip = kr.dim() == 3
         sKr = (2 * T * Cn if per_clip else 0, hd)
+        pd = None
+        if (xl_ds_planes and _reuse_packs and _precision == 3 and hd == 64 and T % 64 == 0
+                and lib.vilco_attn_planes_supported(T, T, hd, MASK_XLNET_REL, _precision, 1, float(ctx.drop[0]))):
+            pd = _xl_ds_planes_buf(B, H, T, qw.device)
         dqw, dk, dv, dS = _flash_bwd(qw, k, v, bd, kv_len, o, lse, do.contiguous(), H, scale, MASK_XLNET_REL, True,
-                                     ctx.drop)
+                                     ctx.drop, ds_planes=pd)
         del bd
         sX, sB2 = (T * Cn, hd), (H * T * 2 * T, T * 2 * T)
         dqr = torch.empty_like(qr)
         if _reuse_packs:
-            # d(bd) = scale * unshift(dS) is never materialised: ONE pack of dS in the unshifted [T, 2T] view (per b, h)
-            # feeds dqr = d(bd) kr (k-contiguous) and dkr = [sum_b] d(bd)^T qr (k-major)
-            (pd,) = pack_many([(dS, T, T)], nbatch=B * H, relshift=True)
+            # d(bd) = scale * unshift(dS) is never materialised: dS in the unshifted [T, 2T] view (per b, h) as operand planes --
+            # written by the dQ kernel itself (pd), or ONE pack of the fp32 dS -- feeds dqr = d(bd) kr (k-contiguous) and
+            # dkr = [sum_b] d(bd)^T qr (k-major)
+            if pd is None:
+                (pd,) = pack_many([(dS, T, T)], nbatch=B * H, relshift=True)
             del dS
             gemm(None, kr, dqr, T, hd, 2 * T, 1, 0, 2 * T, Cn, Cn, batch=(B, H), sA=sB2, sB=sKr, sC=sX,
                  alpha=scale, a_planes=pd, band=2, bandT=T)
