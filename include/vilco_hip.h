@@ -322,6 +322,15 @@ int vilco_attn_bwd(const float* q, const float* k, const float* v, const float* 
 /* vilco_attn_dsplanes_bytes(B, H, Tq) bytes, 256-byte aligned, whose out-of-band columns (p < Tq - i, p >= Tq + Tk - i of   */
 /* row i) and padding are ZERO: the kernel writes the band only, so a buffer zeroed once can be reused call after call.      */
 /* `dbias` and `dbias_amax` must be NULL with it and Tk a multiple of 64.  ds_planes NULL: exactly vilco_attn_bwd.          */
+/* XLNet's position scores bd[b][h][i][p] = qr[b][i][h] . kr[(b)][p][h] for the band p in [T - i, 2T - i) of the unshifted    */
+/* [T][2T] matrix -- the part rel_shift_bnij keeps (modeling_xlnet_x.py:204-214, 256-288); the rest of bd is left unwritten.   */
+/* qr [B][T][H*hd], kr [2T][H*hd] (per_clip 0) or [B][2T][H*hd] (per_clip 1: the reference drops out the expanded position     */
+/* embedding per batch element), bd [B][H][T][2T] fp32, read in place by vilco_attn_fwd / _bwd (mask mode 3).  hd = 64,       */
+/* precision 3 only.  Replaces the band-1 vilco_gemm with K = 64 (write-bound at 1.9 TB/s; this kernel: the attention kernels'  */
+/* first product with the qr fragments resident).                                                                             */
+size_t vilco_xl_scores_workspace(int32_t B, int32_t H, int32_t T, int32_t per_clip);
+int vilco_xl_scores(const float* qr, const float* kr, float* bd, int32_t B, int32_t H, int32_t T, int32_t hd,
+                    int32_t per_clip, int32_t precision, void* workspace, size_t workspace_bytes, void* stream);
 size_t vilco_attn_dsplanes_bytes(int32_t B, int32_t H, int32_t T);
 int vilco_attn_bwd_dsplanes(const float* q, const float* k, const float* v, const float* bias,
                    const int32_t* kv_len, const float* o, const float* lse, const float* dout,

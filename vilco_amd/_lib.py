@@ -115,6 +115,8 @@ SIGNATURES = {
                                  i32, i32, i32, f32, i32, i32, i32, f32, C.c_uint32, C.POINTER(AttnAmaxIn), c_fp, c_fp, c_fp, c_fp, c_fp, sz,
                                  c_fp]),
     "vilco_attn_dsplanes_bytes": (sz, [i32, i32, i32]),
+    "vilco_xl_scores_workspace": (sz, [i32, i32, i32, i32]),
+    "vilco_xl_scores": (C.c_int, [c_fp, c_fp, c_fp, i32, i32, i32, i32, i32, i32, c_fp, sz, c_fp]),
     "vilco_attn_bwd_dsplanes": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32,
                                           i32, i32, i32, f32, i32, i32, i32, f32, C.c_uint32, C.POINTER(AttnAmaxIn), c_fp, c_fp, c_fp, c_fp,
                                           c_fp, sz, c_fp, sz, c_fp]),

@@ -854,6 +854,108 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd64_kernel(AttnArgs a) 
   if (a.am_o) block_amax_out(am, a.am_o, reinterpret_cast<float*>(smem_raw));
 }
 
+// ------------------------------------------------------------------------------------------ XLNet position scores
+// bd[b,h,i,p] = qr_i . kr_p for the band p in [T - i, 2T - i) of the UNSHIFTED [T][2T] matrix (modeling_xlnet_x.py:256-288: the
+// only part rel_shift_bnij keeps) -- round 5, replacing the band-limited batched GEMM with K = 64: one K interval per 192 x 128
+// tile means a tile is all prologue and epilogue there (one workgroup per CU, DMA latency and the 98 KB write-back strictly one
+// after the other: 395 us = 1.9 TB/s of writes at config P).  This is the attention kernels' own first product instead: 128
+// query rows per workgroup, 32 per wave with their qr fragments in registers for the whole kernel, the kr tiles of the
+// workgroup's band streamed through LDS (next tile's loads under the current tile's MFMAs), S^T = KR QR^T leaves a lane with 4
+// consecutive p of one query: one float4 store per 16-row block.  a.qn = qr planes, a.kn = kr planes ([H] or, a.mode = 1, [B*H]
+// batches of 2T rows), a.o = bd, a.sc = {1/s, s} of qr and kr.
+__global__ __launch_bounds__(ATT_THREADS, 2) void xl_scores64_kernel(AttnArgs a) {
+  constexpr int HDP = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* sK = reinterpret_cast<__bf16*>(smem_raw);          // [2 parts][64 rows of kr][RS64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bh = b * a.H + h;
+  const int T = a.Tq, P = 2 * a.Tq;
+  const int Q0 = blockIdx.x * F64_Q, q0 = Q0 + wave * 32;
+  const AttnScales sc = *a.sc;
+  const float unscale = sc.iq * sc.ik;
+  const __bf16* kbase = a.kn.p + (long)(a.mode ? bh : h) * a.kn.batch_stride;
+  const int g4 = lane >> 4;
+  const int fbn = (lane & 15) * RS64 + g4 * 8;
+
+  QFrag<HDP, 2> qf[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) load_qfrag<HDP, 2>(qf[g], a.qn, a.qn.p + (long)bh * a.qn.batch_stride, q0 + 16 * g, lane);
+
+  bf16x8 stK[2][2];
+  const int srow = tid >> 3, sc8 = tid & 7;
+  auto gload = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int kr = p0 + srow + 32 * i;
+      kr = kr < a.kn.rows ? kr : a.kn.rows - 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) stK[q][i] = *reinterpret_cast<const bf16x8*>(kbase + q * a.kn.part_stride + (long)kr * HDP + sc8 * 8);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (srow + 32 * i) * RS64 + sc8 * 8;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) *reinterpret_cast<bf16x8*>(sK + q * PL64 + o) = stK[q][i];
+    }
+  };
+  // the workgroup's band: rows Q0 .. min(Q0 + 127, T - 1)
+  const int qlast = (Q0 + F64_Q - 1 < T ? Q0 + F64_Q - 1 : T - 1);
+  const int t_lo = (T - qlast) / 64, t_hi = (P - Q0 + 63) / 64;            // p tiles [t_lo, t_hi)
+  float* orow[2];
+  int irow[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    irow[g] = q0 + 16 * g + (lane & 15);
+    orow[g] = a.o + ((long)bh * T + (irow[g] < T ? irow[g] : T - 1)) * P;
+  }
+  if (t_lo < t_hi) gload(t_lo * 64);
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int p0 = t * 64;
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (t + 1 < t_hi) gload(p0 + 64);
+    if (p0 + 63 < T - (q0 + 31) || p0 >= P - q0) continue;      // (wave-uniform) nothing of this tile lies in this wave's band
+    f32x4 s[2][4];
+    bf16x8 kf[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) kf[0][q] = *reinterpret_cast<const bf16x8*>(sK + q * PL64 + fbn);
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int mi = st >> 1, ks = st & 1;
+      if (st + 1 < 8) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          kf[(st + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(sK + q * PL64 + fbn + ((st + 1) >> 1) * 16 * RS64 + ((st + 1) & 1) * 32);
+      }
+      const f16x8 k0h = __builtin_bit_cast(f16x8, kf[st & 1][0]), k1h = __builtin_bit_cast(f16x8, kf[st & 1][1]);
+      const f16x8 a0 = __builtin_bit_cast(f16x8, qf[0].f[ks][0]), a1 = __builtin_bit_cast(f16x8, qf[0].f[ks][1]);
+      const f16x8 b0 = __builtin_bit_cast(f16x8, qf[1].f[ks][0]), b1 = __builtin_bit_cast(f16x8, qf[1].f[ks][1]);
+      f32x4 c0 = ks ? s[0][mi] : f32x4{0.f, 0.f, 0.f, 0.f}, c1 = ks ? s[1][mi] : f32x4{0.f, 0.f, 0.f, 0.f};
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, a0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, b0, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, a1, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, b1, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, a0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, b0, c1, 0, 0, 0);
+      s[0][mi] = c0; s[1][mi] = c1;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int i = irow[g];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int p = p0 + mi * 16 + g4 * 4;
+        if (i < T && p + 3 >= T - i && p < P - i && p + 3 < P)      // some of the 4 columns lie in row i's band
+          *reinterpret_cast<float4*>(orow[g] + p) = make_float4(s[g][mi][0] * unscale, s[g][mi][1] * unscale, s[g][mi][2] * unscale, s[g][mi][3] * unscale);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dBias)
 template <int HDP, int NP, bool F16, bool DROP>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(AttnArgs a) {
@@ -2254,6 +2356,43 @@ extern "C" int vilco_attn_fwd_planes(const float* q, const float* k, const float
     a.vt = pack_operand(v, w, spec_tr(B, H, Tk, hd), true, B, H, Tk, hd, HDP, NP, s, sw.parts[2], sw.n[2], so + 4, &pq);
   flush_packs(pq, sw, precision == 3, NP, B * H, s);
   return hd <= 32 ? dispatch<32>(a, precision, false, s) : (hd <= 64 ? dispatch<64>(a, precision, false, s) : (hd <= 128 ? dispatch<128>(a, precision, false, s) : dispatch<160>(a, precision, false, s)));
+}
+
+// XLNet position scores (xl_scores64_kernel): bd[B][H][T][2T] (fp32, only the band of every row is written) from qr [B][T][H*64]
+// and kr [2T][H*64] (per_clip = 0) or [B][2T][H*64] (per_clip = 1).  precision 3 (fp16 x2 operand planes), hd = 64.
+extern "C" size_t vilco_xl_scores_workspace(int32_t B, int32_t H, int32_t T, int32_t per_clip) {
+  return (size_t)(planes_bytes(spec_nat(B, H, T, 64), 2) + planes_bytes(spec_nat(per_clip ? B : 1, H, 2 * T, 64), 2) + 2 * ATT_SCALE_BYTES + 1024);
+}
+
+extern "C" int vilco_xl_scores(const float* qr, const float* kr, float* bd, int32_t B, int32_t H, int32_t T, int32_t hd,
+                               int32_t per_clip, int32_t precision, void* workspace, size_t workspace_bytes, void* stream) {
+  if (B < 0 || H <= 0 || T < 0 || !qr || !kr || !bd) return VILCO_ERR_BADARG;
+  if (hd != 64 || precision != 3) return VILCO_ERR_UNSUPPORTED;
+  if (B == 0 || T == 0) return VILCO_OK;
+  if (!workspace || workspace_bytes < vilco_xl_scores_workspace(B, H, T, per_clip)) return VILCO_ERR_WORKSPACE;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  unsigned char* wsb = reinterpret_cast<unsigned char*>(up((long)reinterpret_cast<uintptr_t>(workspace), 256));
+  const int Bk = per_clip ? B : 1;
+  // max|qr|, max|kr| -> {1/s, s}: two amax views (their row counts differ), one launch; the packs fold the partials
+  const float* const xq[4] = {qr, nullptr, nullptr, nullptr};
+  const float* const xk[4] = {kr, nullptr, nullptr, nullptr};
+  const int Tq_[4] = {T, 0, 0, 0}, Tk_[4] = {2 * T, 0, 0, 0};
+  ScaleWs sq = plan_amax(wsb, xq, Tq_, 1, B, H * hd);
+  ScaleWs sk = plan_amax(wsb + ATT_SCALE_BYTES, xk, Tk_, 1, Bk, H * hd);
+  AmaxArgs am;
+  am.op[0] = sq.am.op[0]; am.op[1] = sk.am.op[0];
+  launch_amax(am, 2, s);
+  // AttnScales {iq, sq, ik, sk, ...}: q's pair at sq.out, k's pair right behind it
+  float* scales = sq.out;
+  __bf16* w = reinterpret_cast<__bf16*>(wsb + 2 * ATT_SCALE_BYTES);
+  AttnArgs a = {};
+  a.B = B; a.H = H; a.Tq = T; a.Tk = T; a.hd = hd; a.C = H * hd; a.mode = per_clip ? 1 : 0;
+  a.o = bd;
+  a.qn = pack_operand(qr, w, spec_nat(B, H, T, 64), false, B, H, T, hd, 64, 2, s, sq.parts[0], sq.n[0], scales, nullptr);
+  a.kn = pack_operand(kr, w, spec_nat(Bk, H, 2 * T, 64), false, Bk, H, 2 * T, hd, 64, 2, s, sk.parts[0], sk.n[0], scales + 2, nullptr);
+  a.sc = reinterpret_cast<const AttnScales*>(scales);
+  hipLaunchKernelGGL(xl_scores64_kernel, dim3((T + F64_Q - 1) / F64_Q, H, B), dim3(ATT_THREADS), 2 * PL64 * sizeof(__bf16), s, a);
+  return vilco_launch_status();
 }
 
 extern "C" size_t vilco_attn_bwd_workspace(int32_t B, int32_t H, int32_t Tq, int32_t Tk, int32_t hd, int32_t precision) {

@@ -1382,6 +1382,8 @@ def _attach_attn_planes(o):
 # buffer per (device, B*H, T) is zeroed when first needed and reused by every later backward (1.36 GB at config P; a step
 # captured as a hipGraph has met it in the eager iterations before the capture).  VILCO_XL_DS_PLANES=0: the fp32 dS + pack path.
 xl_ds_planes = os.environ.get("VILCO_XL_DS_PLANES", "1") != "0"
+# XLNet forward: the position scores by vilco_xl_scores (dedicated kernel) instead of the band-limited K = 64 GEMM (VILCO_XL_SCORES=0)
+xl_scores_kernel = os.environ.get("VILCO_XL_SCORES", "1") != "0"
 _ds_plane_bufs = {}
 
 
@@ -1556,8 +1558,15 @@ class _FlashRelAttention(torch.autograd.Function):
         hd = Cn // H
         sKr = (2 * T * Cn if kr.dim() == 3 else 0, hd)
         bd = torch.empty(B, H, T, 2 * T, dtype=torch.float32, device=qw.device)
-        gemm(qr, kr, bd, T, 2 * T, hd, 1, 1, Cn, Cn, 2 * T, batch=(B, H), sA=(T * Cn, hd), sB=sKr,
-             sC=(H * T * 2 * T, T * 2 * T), band=1, bandT=T)      # only the band p in [T-i, 2T-i) is ever read
+        if xl_scores_kernel and hd == 64 and _precision == 3 and qr.is_contiguous() and kr.is_contiguous():
+            lib = _lib.load()        # the attention kernels' first product on (qr, kr): only the band p in [T-i, 2T-i) is written
+            nws = lib.vilco_xl_scores_workspace(B, H, T, int(kr.dim() == 3))
+            ws = _ws(nws, qw.device)
+            _lib.check(lib.vilco_xl_scores(qr.data_ptr(), kr.data_ptr(), bd.data_ptr(), B, H, T, hd, int(kr.dim() == 3), _precision,
+                                           ws.data_ptr(), nws, _stream()))
+        else:
+            gemm(qr, kr, bd, T, 2 * T, hd, 1, 1, Cn, Cn, 2 * T, batch=(B, H), sA=(T * Cn, hd), sB=sKr,
+                 sC=(H * T * 2 * T, T * 2 * T), band=1, bandT=T)      # only the band p in [T-i, 2T-i) is ever read
         ctx.drop = _new_drop("attn_prob", drop_p, (B, H, T, T))
         # the flash kernel reads the unshifted scores in place (mask mode 3): no [T,T] bias tensor, no shift pass
         o, lse = _flash_fwd(qw, k, v, bd, kv_len, H, scale, MASK_XLNET_REL, ctx.drop)
