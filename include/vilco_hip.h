@@ -221,6 +221,13 @@ int vilco_layernorm_bwd(const float* dy, const float* x, const float* y, const f
                         const float* mean, const float* rstd, float* dx, float* dgamma,
                         float* dbeta, int64_t rows, int32_t C, int32_t relu, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* dres (optional, [rows][C]): dx = LayerNorm backward + dres -- the gradient that reaches x over the residual connection  */
+/* around the branch this LayerNorm opens (blocks.py:571-590: x + drop_path(attn(ln1(x))), out + drop_path(mlp(ln2(out)))): */
+/* the sum autograd would form with a kernel of its own.  NULL: exactly vilco_layernorm_bwd.                               */
+int vilco_layernorm_bwd_res(const float* dy, const float* x, const float* y, const float* gamma,
+                            const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
+                            float* dbeta, int64_t rows, int32_t C, int32_t relu, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Depthwise k=3 conv, stride 1|2, zero pad 1, no bias, output masked: MaskedMHCA's query/key/   */

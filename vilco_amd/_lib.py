@@ -93,6 +93,8 @@ SIGNATURES = {
     "vilco_layernorm_bwd_workspace": (sz, [i64, i32]),
     "vilco_layernorm_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32,
                                       i32, c_fp, sz, c_fp]),
+    "vilco_layernorm_bwd_res": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32,
+                                          i32, c_fp, sz, c_fp]),
     "vilco_dwconv3_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
     "vilco_dwconv3_bwd_workspace": (sz, [i32, i32, i32, i32]),
     "vilco_dwconv3_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, sz, c_fp]),

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     float* __restrict__ dx, float* __restrict__ ws, long rows, int C,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, unsigned* sync) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, unsigned* sync, const float* __restrict__ dres) {
   __shared__ float red[LN_WAVES][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long wid = (long)blockIdx.x * LN_WAVES + wave;
@@ -218,6 +218,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
         o.y = rs * (g[i].y - s1 - xh[i].y * s2);
         o.z = rs * (g[i].z - s1 - xh[i].z * s2);
         o.w = rs * (g[i].w - s1 - xh[i].w * s2);
+        if (dres) {                 // the gradient arriving over the residual connection around this LayerNorm's branch
+          const float4 r = *reinterpret_cast<const float4*>(dres + row * C + c);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
         *reinterpret_cast<float4*>(dx + row * C + c) = o;
       }
     }
@@ -405,6 +409,14 @@ extern "C" int vilco_layernorm_bwd(const float* dy, const float* x, const float*
                                    float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t C,
                                    int32_t relu, void* workspace, size_t workspace_bytes,
                                    void* stream) {
+  return vilco_layernorm_bwd_res(dy, x, y, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, rows, C, relu, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vilco_layernorm_bwd_res(const float* dy, const float* x, const float* y,
+                                       const float* gamma, const float* mean, const float* rstd, const float* dres,
+                                       float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t C,
+                                       int32_t relu, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
   if (!dy || !x || !mean || !rstd || !dx || rows < 0 || C <= 0) return VILCO_ERR_BADARG;
   if (relu && !y) return VILCO_ERR_BADARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return VILCO_ERR_BADARG;
@@ -417,8 +429,8 @@ extern "C" int vilco_layernorm_bwd(const float* dy, const float* x, const float*
   dim3 grid(nb);
   float* ws = reinterpret_cast<float*>(workspace);
   unsigned* sync = (dgamma && dbeta) ? vilco_sync_counter(s, VILCO_SITE_LN) : nullptr;   // nb <= 256 blocks: co-resident
-  if (relu) { LN_DISPATCH_B(nv, ln_bwd_kernel, true, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync) }
-  else { LN_DISPATCH_B(nv, ln_bwd_kernel, false, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync) }
+  if (relu) { LN_DISPATCH_B(nv, ln_bwd_kernel, true, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync, dres) }
+  else { LN_DISPATCH_B(nv, ln_bwd_kernel, false, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync, dres) }
   if (dgamma && dbeta && !sync) vilco_reduce_rows(ws, dgamma, dbeta, nb, 2 * C, C, s);  // ws rows: [dgamma | dbeta]
   return vilco_launch_status();
 }

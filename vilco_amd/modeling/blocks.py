@@ -146,10 +146,11 @@ class LayerNorm(nn.Module):
             self.register_parameter('weight', None)
             self.register_parameter('bias', None)
 
-    def forward_tm(self, x, relu=False, planes=None, row_mask=None):
-        """planes: "nat" / "seq" when the output goes straight into a Linear / a k=3 conv; row_mask: see ops.layernorm"""
+    def forward_tm(self, x, relu=False, planes=None, row_mask=None, skip=False):
+        """planes: "nat" / "seq" when the output goes straight into a Linear / a k=3 conv; row_mask: see ops.layernorm;
+        skip: -> (y, x_skip), x_skip = x for the residual connection around the branch y feeds (ops.layernorm)"""
         assert x.shape[-1] == self.num_channels
-        return ops.layernorm(x, self.weight, self.bias, self.eps, relu, planes, row_mask)
+        return ops.layernorm(x, self.weight, self.bias, self.eps, relu, planes, row_mask, skip)
 
     def forward(self, x):
         assert x.dim() == 3 and x.shape[1] == self.num_channels
@@ -241,16 +242,17 @@ class MaskedMHCA(nn.Module):
                 and self.query_norm.eps == self.key_norm.eps == self.value_norm.eps and self.query_norm.affine)
 
     def forward_tm_fused(self, x, lens, ln1, want_h):
-        """(attention output, q_lens, h = ln1(x) or None): ln1 + the three depthwise convs + their LayerNorms in one launch"""
+        """(attention output, q_lens, h = ln1(x) or None, x_skip): ln1 + the three depthwise convs + their LayerNorms in one
+        launch; x_skip = x for the block's skip connection (its gradient is added inside ln1's backward kernel)"""
         s = self.query_conv.stride
         outs = ops.qkv_pre(x, (ln1.weight, ln1.bias, ln1.eps),
                            (self.query_conv.conv.weight, self.key_conv.conv.weight, self.value_conv.conv.weight),
                            ((self.query_norm.weight, self.query_norm.bias), (self.key_norm.weight, self.key_norm.bias),
-                            (self.value_norm.weight, self.value_norm.bias), self.query_norm.eps), lens, s, want_h)
+                            (self.value_norm.weight, self.value_norm.bias), self.query_norm.eps), lens, s, want_h, skip=True)
         q, k, v = outs[:3]
         q_lens = down_lens(lens, s)
         out, q_lens = self._attend(q, k, v, q_lens, q_lens)
-        return out, q_lens, (outs[3] if want_h else None)
+        return out, q_lens, (outs[3] if want_h else None), outs[-1]
 
     def forward_tm(self, x, lens):
         q, q_lens = self.query_conv.forward_tm(x, lens)
@@ -427,29 +429,32 @@ class TransformerBlock(nn.Module):
 
     def forward_tm(self, x, lens, cross_y=None, cross_lens=None):
         need_h = (self.n_ds_strides[0] == 1 and self.n_ds_strides[1] == 1) or (self.adapters is not None and "attn" in self.adapters)
+        # Every residual branch opens with a LayerNorm; its input comes back from that op as `xs` / `out_s` for the skip
+        # connection, so the gradient over the skip is added inside the LayerNorm backward kernel (ops.layernorm `skip`).
         if self.attn.fusable() and self.ln1.affine:
-            a, out_lens, h = self.attn.forward_tm_fused(x, lens, self.ln1, need_h)
+            a, out_lens, h, xs = self.attn.forward_tm_fused(x, lens, self.ln1, need_h)
         else:
-            h = self.ln1.forward_tm(x)
+            h, xs = self.ln1.forward_tm(x, skip=True)
             a, out_lens = self.attn.forward_tm(h, lens)
         if self.adapters is not None and "attn" in self.adapters:
             a = a + self.adapters["attn"].forward_tm(h)          # parallel adapter (meta_archs.py:144-148)
-        skip = ops.maxpool3s2(x, lens) if self.n_ds_strides[0] > 1 else x
+        skip = ops.maxpool3s2(xs, lens) if self.n_ds_strides[0] > 1 else xs
         cs, rs = self._dp(self.drop_path_attn, a)
         out = ops.scale_add(skip, a, cs, rs, out_lens, mask_a=True)
         if self.use_cross_modal and cross_y is not None:
-            c, _ = self.cross_attn.forward_tm(self.ln3.forward_tm(out, planes="nat"), out_lens,
-                                              self.ln3.forward_tm(cross_y, planes="nat"), cross_lens)
+            hq, out_s = self.ln3.forward_tm(out, planes="nat", skip=True)
+            c, _ = self.cross_attn.forward_tm(hq, out_lens, self.ln3.forward_tm(cross_y, planes="nat"), cross_lens)
             cs, rs = self._dp(self.drop_path_attn, c)
-            out = ops.scale_add(out, c, cs, rs, out_lens, mask_a=True)
+            out = ops.scale_add(out_s, c, cs, rs, out_lens, mask_a=True)
         T2 = out.shape[1]
         tr = self.training                                                              # mlp dropouts: blocks.py:533-540
-        m = ops.linear(self.ln2.forward_tm(out, planes="nat"), self.mlp[0].weight, self.mlp[0].bias, ACT_GELU,
+        h2, out_s = self.ln2.forward_tm(out, planes="nat", skip=True)
+        m = ops.linear(h2, self.mlp[0].weight, self.mlp[0].bias, ACT_GELU,
                        drop_p=self.mlp[2].p if tr else 0.0, drop_site="mlp_drop")
         m = ops.linear(m, self.mlp[3].weight, self.mlp[3].bias, ACT_NONE, out_lens, T2,
                        drop_p=self.mlp[4].p if tr else 0.0, drop_site="mlp_drop")
         cs, rs = self._dp(self.drop_path_mlp, m)
-        out = ops.scale_add(out, m, cs, rs)
+        out = ops.scale_add(out_s, m, cs, rs)
         if self.n_ds_strides[0] == 1 and self.n_ds_strides[1] == 1:
             out2 = self.channel_attn.forward_tm(h)
             out = ops.axpby(out, out2, self.t_c_alpha, 1.0 - self.t_c_alpha)

@@ -81,24 +81,29 @@ class TransformerBlock(nn.Module):
         return None, None
 
     def forward_tm(self, x, lens, cross_y=None, cross_lens=None):
+        # the skip connections take their input back from the LayerNorm that opens the branch (ops.layernorm `skip`: the
+        # gradient over the skip is added inside that LayerNorm's backward kernel)
         if self.attn.fusable() and self.ln1.affine:
-            a, out_lens, _ = self.attn.forward_tm_fused(x, lens, self.ln1, False)
+            a, out_lens, _, xs = self.attn.forward_tm_fused(x, lens, self.ln1, False)
         else:
-            a, out_lens = self.attn.forward_tm(self.ln1.forward_tm(x), lens)
-        skip = ops.maxpool3s2(x, lens) if self.n_ds_strides[0] > 1 else x
+            h, xs = self.ln1.forward_tm(x, skip=True)
+            a, out_lens = self.attn.forward_tm(h, lens)
+        skip = ops.maxpool3s2(xs, lens) if self.n_ds_strides[0] > 1 else xs
         cs, rs = self._dp(self.drop_path_attn, a)
         out = ops.scale_add(skip, a, cs, rs, out_lens, mask_a=True)
         if self.use_cross_modal and cross_y is not None:
-            c, _ = self.cross_attn.forward_tm(self.ln3.forward_tm(out), out_lens, self.ln3.forward_tm(cross_y), cross_lens)
+            hq, out_s = self.ln3.forward_tm(out, skip=True)
+            c, _ = self.cross_attn.forward_tm(hq, out_lens, self.ln3.forward_tm(cross_y), cross_lens)
             cs, rs = self._dp(self.drop_path_attn, c)
-            out = ops.scale_add(out, c, cs, rs, out_lens, mask_a=True)
+            out = ops.scale_add(out_s, c, cs, rs, out_lens, mask_a=True)
         tr = self.training
-        m = ops.linear(self.ln2.forward_tm(out), self.mlp[0].weight, self.mlp[0].bias, ACT_GELU,
+        h2, out_s = self.ln2.forward_tm(out, skip=True)
+        m = ops.linear(h2, self.mlp[0].weight, self.mlp[0].bias, ACT_GELU,
                        drop_p=self.mlp[2].p if tr else 0.0, drop_site="mlp_drop")
         m = ops.linear(m, self.mlp[3].weight, self.mlp[3].bias, ACT_NONE, out_lens, out.shape[1],
                        drop_p=self.mlp[4].p if tr else 0.0, drop_site="mlp_drop")
         cs, rs = self._dp(self.drop_path_mlp, m)
-        return ops.scale_add(out, m, cs, rs), out_lens
+        return ops.scale_add(out_s, m, cs, rs), out_lens
 
     def forward(self, x, mask, cross_y=None, cross_y_mask=None, pos_embd=None):
         T = x.shape[-1]

@@ -985,9 +985,11 @@ class _LayerNorm(torch.autograd.Function):
     last_planes = None
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, planes=None, row_mask=None):
+    def forward(ctx, x, gamma, beta, eps, relu, planes=None, row_mask=None, skip=False):
         _chk(x, gamma, beta, row_mask)
         assert row_mask is None or relu, "row_mask: the backward kernel drops masked rows through the ReLU test on the saved output"
+        ctx.skip = bool(skip)
+        ctx.set_materialize_grads(False)
         lib = _lib.load()
         Cn = x.shape[-1]
         rows = x.numel() // Cn
@@ -1012,13 +1014,20 @@ class _LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, rstd, y if relu else None)
         _LayerNorm.last_amax = (parts, n.value)          # picked up by `layernorm` (attributes set here do not survive apply)
         _LayerNorm.last_planes = (buf, seq, _cache_mark()) if buf is not None else None
-        return y
+        # skip: x is returned as a second output (autograd makes it a view of x).  A block that opens a residual branch with
+        # this LayerNorm takes its skip connection from THAT tensor: the gradient over the skip then arrives here, and the
+        # backward kernel adds it to dx itself instead of autograd summing the two with a launch of its own (55 per P step).
+        return (y, x) if skip else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, gamma, mean, rstd, y = ctx.saved_tensors
         lib = _lib.load()
+        if dy is None:                           # only the skip output was used
+            return dskip, None, None, None, None, None, None, None
         dy = dy.contiguous()
+        if dskip is not None:
+            dskip = dskip.contiguous()
         Cn = x.shape[-1]
         rows = x.numel() // Cn
         dx = torch.empty_like(x)
@@ -1026,21 +1035,26 @@ class _LayerNorm(torch.autograd.Function):
         db = torch.empty(Cn, dtype=torch.float32, device=x.device)
         with _Deferring(gamma) as dfr:           # the d-gamma / d-beta column sums may finish with the other deferred ones
             ws = _ws(lib.vilco_layernorm_bwd_workspace(rows, Cn), x.device)
-            _lib.check(lib.vilco_layernorm_bwd(dy.data_ptr(), x.data_ptr(), _p(y), _p(gamma),
-                                               mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                                               dg.data_ptr(), db.data_ptr(), rows, Cn, int(ctx.relu),
-                                               ws.data_ptr(), ws.numel(), _stream()))
+            _lib.check(lib.vilco_layernorm_bwd_res(dy.data_ptr(), x.data_ptr(), _p(y), _p(gamma),
+                                                   mean.data_ptr(), rstd.data_ptr(), _p(dskip), dx.data_ptr(),
+                                                   dg.data_ptr(), db.data_ptr(), rows, Cn, int(ctx.relu),
+                                                   ws.data_ptr(), ws.numel(), _stream()))
             dfr.hold(dg, db)
-        return dx, dg.view_as(gamma), db.view_as(gamma), None, None, None, None
+        return dx, dg.view_as(gamma), db.view_as(gamma), None, None, None, None, None
 
 
-def layernorm(x, gamma, beta, eps=1e-5, relu=False, planes=None, row_mask=None):
+def layernorm(x, gamma, beta, eps=1e-5, relu=False, planes=None, row_mask=None, skip=False):
     """gamma/beta may have the reference's [1,C,1] shape (blocks.py:152-155) or [C].
+    skip: return (y, x_skip) -- x_skip is x as an output of this op; use it for the residual connection around the branch
+    that y feeds, and the backward kernel adds the skip gradient to dx itself (see _LayerNorm.forward).
     planes: "nat" when y feeds a Linear, "seq" when it feeds a k=3 conv -- the kernel then writes y's operand planes as well
     (vilco_layernorm_fwd_planes) and the consumer's `pack` / `pack_tap` finds them on the tensor.
     row_mask (relu only): a contiguous 0 / 1 float mask over the token rows, repeated over the batch -- y[b, t] *= row_mask[t]."""
     _LayerNorm.last_planes = None
-    y = _LayerNorm.apply(x, gamma, beta, float(eps), bool(relu), planes, row_mask)
+    y = _LayerNorm.apply(x, gamma, beta, float(eps), bool(relu), planes, row_mask, bool(skip and fold_skip_grads and x.requires_grad))
+    xs = x
+    if isinstance(y, tuple):
+        y, xs = y
     parts, n = _LayerNorm.last_amax
     _LayerNorm.last_amax = (None, 0)
     made, _LayerNorm.last_planes = _LayerNorm.last_planes, None
@@ -1051,7 +1065,8 @@ def layernorm(x, gamma, beta, eps=1e-5, relu=False, planes=None, row_mask=None):
             y._vilco_tap_planes = (buf, ("tap", int(y.shape[0]), int(y.shape[1]), int(Cn), 3, y._version), mark)
         else:
             y._vilco_planes = (buf, (int(y.numel() // Cn), int(Cn), 3, y._version), mark)
-    return _tag_amax(y, parts, n) if parts is not None else y
+    y = _tag_amax(y, parts, n) if parts is not None else y
+    return (y, xs) if skip else y
 
 
 # ---------------------------------------------------------------------------------------- dwconv / pool
@@ -1381,6 +1396,8 @@ def _attach_attn_planes(o):
 # fp32 dS + a pack of it.  The kernel writes the band only; everything else in the buffer must be zero and stays zero, so ONE
 # buffer per (device, B*H, T) is zeroed when first needed and reused by every later backward (1.36 GB at config P; a step
 # captured as a hipGraph has met it in the eager iterations before the capture).  VILCO_XL_DS_PLANES=0: the fp32 dS + pack path.
+# residual joins: the skip gradient is added inside the LayerNorm backward kernel (VILCO_FOLD_SKIP=0: autograd's own add_)
+fold_skip_grads = os.environ.get("VILCO_FOLD_SKIP", "1") != "0"
 xl_ds_planes = os.environ.get("VILCO_XL_DS_PLANES", "1") != "0"
 # XLNet forward: the position scores by vilco_xl_scores (dedicated kernel) instead of the band-limited K = 64 GEMM (VILCO_XL_SCORES=0)
 xl_scores_kernel = os.environ.get("VILCO_XL_SCORES", "1") != "0"
@@ -1808,8 +1825,10 @@ class _QkvPre(torch.autograd.Function):
     (vilco_qkv_pre_fwd); backward = vilco_qkv_pre_bwd (conv outputs recomputed from h) + LN1's ordinary backward."""
 
     @staticmethod
-    def forward(ctx, x, g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv, lens, stride, eps1, eps, want_h):
+    def forward(ctx, x, g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv, lens, stride, eps1, eps, want_h, skip=False):
         _chk(x, g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv)
+        ctx.skip = bool(skip)            # x returned as a last output: the block's skip connection (see _LayerNorm.forward)
+        ctx.set_materialize_grads(False)
         lib = _lib.load()
         B, T, Cn = x.shape
         To = T // stride
@@ -1829,11 +1848,16 @@ class _QkvPre(torch.autograd.Function):
         _QkvPre.last_amax = (parts, npart)
         ctx.stride, ctx.eps1, ctx.want_h = int(stride), float(eps1), bool(want_h)
         ctx.save_for_backward(x, g1, b1, wq, wk, wv, gq, gk, gv, lens, stats1, stats, h)
-        return (ys[0], ys[1], ys[2], h) if want_h else (ys[0], ys[1], ys[2])
+        outs = (ys[0], ys[1], ys[2], h) if want_h else (ys[0], ys[1], ys[2])
+        return outs + (x,) if skip else outs
 
     @staticmethod
-    def backward(ctx, dq, dk, dv, dh_ext=None):
+    def backward(ctx, dq, dk, dv, *more):
         x, g1, b1, wq, wk, wv, gq, gk, gv, lens, stats1, stats, h = ctx.saved_tensors
+        more = list(more)
+        dh_ext = more.pop(0) if ctx.want_h and more else None
+        dskip = more.pop(0) if ctx.skip and more else None
+        dskip = None if dskip is None else dskip.contiguous()
         lib = _lib.load()
         B, T, Cn = x.shape
         To = T // ctx.stride
@@ -1859,23 +1883,28 @@ class _QkvPre(torch.autograd.Function):
                                              B, T, Cn, ctx.stride, ws.data_ptr(), nws, _stream()))
             del dcs
             ws1 = _ws(lib.vilco_layernorm_bwd_workspace(B * T, Cn), dev)
-            _lib.check(lib.vilco_layernorm_bwd(dh.data_ptr(), x.data_ptr(), None, _p(g1), stats1[0].data_ptr(), stats1[1].data_ptr(),
-                                               dx.data_ptr(), dg1.data_ptr(), db1.data_ptr(), B * T, Cn, 0, ws1.data_ptr(),
-                                               ws1.numel(), _stream()))
+            _lib.check(lib.vilco_layernorm_bwd_res(dh.data_ptr(), x.data_ptr(), None, _p(g1), stats1[0].data_ptr(),
+                                                   stats1[1].data_ptr(), _p(dskip), dx.data_ptr(), dg1.data_ptr(), db1.data_ptr(),
+                                                   B * T, Cn, 0, ws1.data_ptr(), ws1.numel(), _stream()))
             dfr.hold(dpar, dg1, db1)
         dws = [dpar[6 + 3 * j:9 + 3 * j].view_as(w) for j, w in enumerate((wq, wk, wv))]      # already [C][1][3] (qkvpre.hip)
         dgs = [dpar[2 * j].view_as(g) for j, g in enumerate((gq, gk, gv))]
         dbs = [dpar[2 * j + 1].view_as(g) for j, g in enumerate((gq, gk, gv))]
         return (dx, dg1.view_as(g1), db1.view_as(g1), dws[0], dws[1], dws[2], dgs[0], dbs[0], dgs[1], dbs[1], dgs[2], dbs[2],
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
-def qkv_pre(x, ln1, convs, norms, lens, stride, want_h):
+def qkv_pre(x, ln1, convs, norms, lens, stride, want_h, skip=False):
     """x [B,T,C]; ln1 = (weight, bias, eps) of the block's first LayerNorm; convs = three depthwise [C,1,3] weights
-    (query, key, value); norms = three (weight, bias) pairs + one eps -> (q, k, v[, h])."""
+    (query, key, value); norms = three (weight, bias) pairs + one eps -> (q, k, v[, h][, x_skip]).
+    skip: x comes back as the last output, for the block's skip connection (ops.layernorm's `skip`)."""
     (g1, b1, eps1), (wq, wk, wv), ((gq, bq), (gk, bk), (gv, bv), eps) = ln1, convs, norms
-    outs = _QkvPre.apply(x.contiguous(), g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv, lens, int(stride), float(eps1),
-                         float(eps), bool(want_h))
+    x = x.contiguous()
+    fold = bool(skip and fold_skip_grads and x.requires_grad)
+    outs = _QkvPre.apply(x, g1, b1, wq, wk, wv, gq, bq, gk, bk, gv, bv, lens, int(stride), float(eps1),
+                         float(eps), bool(want_h), fold)
+    if skip and not fold:
+        outs = tuple(outs) + (x,)
     parts, n = _QkvPre.last_amax
     _QkvPre.last_amax = (None, 0)
     if parts is not None:
