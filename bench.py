@@ -389,8 +389,12 @@ def main():
             fence()
             eager_x_ms = (time.perf_counter() - t1) / 5 * 1e3
             reducer.enabled = False
-        multi = {"step_mode": "hipGraph replay + in-place bucketed all-reduce after the replay (no overlap with backward)"
-                              if graphed is not None else "eager launches, all-reduce from autograd hooks (overlapped with backward)",
+        staged = graphed is not None and any(e.get('seg_graphs') for e in graphed._graphs.values())
+        multi = {"step_mode": ("backward replayed as %d hipGraphs (heads + losses, then one per backbone stage); every gradient bucket's "
+                               "all-reduce launched behind the stage that completes it, under the stages that follow"
+                               % max(1 + len(e.get('seg_graphs') or ()) for e in graphed._graphs.values())) if staged
+                              else ("hipGraph replay + in-place bucketed all-reduce after the replay (no overlap with backward)"
+                                    if graphed is not None else "eager launches, all-reduce from autograd hooks (overlapped with backward)"),
                  "eager_step_with_hook_exchange_ms": eager_x_ms,
                  "buckets": buckets, "exchange_ms_sum_of_buckets_alone": tot, "ms_per_step_without_exchange": local_ms,
                  "exposed_exchange_ms": ms - local_ms,

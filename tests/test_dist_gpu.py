@@ -47,8 +47,9 @@ def _train(dev, mode, steps=4):
     batch = golden_inputs(gold)
     opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-3))
     red = GradReducer(model, bucket_mb=0.05) if mode != "plain" else None
-    graph = (GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=2, reducer=red, comm_in_graph=(mode == "graph_comm"))
-             if mode in ("graph", "graph_comm") else None)
+    graph = (GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=2, reducer=red, comm_in_graph=(mode == "graph_comm"),
+                         segments=(mode == "graph"))
+             if mode in ("graph", "graph_single", "graph_comm") else None)
     losses, in_slots = [], 0
     for it in range(steps):
         if graph is not None:
@@ -75,6 +76,10 @@ def _train(dev, mode, steps=4):
         assert ops.grad_slot_provider is None
     if graph is not None:
         assert graph.stats['replayed'] == steps - 2, graph.stats
+        nseg = [len(e.get('seg_graphs') or ()) for e in graph._graphs.values() if 'graph' in e]
+        # "graph": the backward captured in stages (one graph per pyramid level of this model + the embedding / stem stage),
+        # the buckets launched between their replays; the other modes: one graph
+        assert (min(nseg) >= 2) if mode == "graph" else (max(nseg) == 0), (mode, nseg)
     return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, in_slots
 
 
@@ -82,9 +87,10 @@ def test_reducer_paths_reproduce_the_single_process_run(dev, one_rank_group):
     l0, s0, _ = _train(dev, "plain")
     l1, s1, in_slots = _train(dev, "hooks")
     assert in_slots >= 40, in_slots                 # the matrices' gradients were produced in place
-    l2, s2, _ = _train(dev, "graph")
-    l3, s3, _ = _train(dev, "graph" if os.environ.get("VILCO_TEST_NO_COMM") else "graph_comm")   # the all-reduces captured inside graph 1 (or the fallback, if the runtime refuses)
-    for other_l, other_s in ((l1, s1), (l2, s2), (l3, s3)):
+    l2, s2, _ = _train(dev, "graph")                # backward replayed in stages, buckets launched between them (round 5)
+    l3, s3, _ = _train(dev, "graph_single" if os.environ.get("VILCO_TEST_NO_COMM") else "graph_comm")   # the all-reduces captured inside graph 1 (or the fallback, if the runtime refuses)
+    l4, s4, _ = _train(dev, "graph_single")         # one graph, the whole exchange after it
+    for other_l, other_s in ((l1, s1), (l2, s2), (l3, s3), (l4, s4)):
         assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(other_l, l0)), (other_l, l0)
         for k in s0:
             # (key / key-norm biases: analytically zero gradients, 1e-12-level noise that Adam turns into +-lr steps)
@@ -111,10 +117,11 @@ def _w2_worker(rank, world, port, mode, q):
                                  seed=40 + rank)                      # every replica trains on its own clips
         opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-3))
         red = GradReducer(model, bucket_mb=0.05)
-        step = GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=2, reducer=red, enabled=(mode == "graph"))
+        step = GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=2, reducer=red, enabled=(mode == "graph"), segments=True)   # (opt-in: vilco_amd/graph.py _DP_SEGMENTS)
         losses = [float(step(batch, task_id=gold['task_id'])['final_loss']) for _ in range(5)]
         in_place = sum(1 for b in red.buckets for p, v in zip(b["params"], b["views"]) if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
-        q.put((rank, losses, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, dict(step.stats), in_place))    # (numpy: by value)
+        stats = dict(step.stats, stage_graphs=max([len(e.get('seg_graphs') or ()) for e in step._graphs.values()] or [0]))
+        q.put((rank, losses, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}, stats, in_place))    # (numpy: by value)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -141,6 +148,7 @@ def _w2_run(mode):
 def test_world2_graph_replay_equals_eager_and_replicas_stay_identical(dev):
     eager, graph = _w2_run("eager"), _w2_run("graph")
     assert graph[0][2]['replayed'] == 3 and graph[1][2]['replayed'] == 3, (graph[0][2], graph[1][2])
+    assert graph[0][2]['stage_graphs'] >= 2         # the replayed backward ran in stages with the exchange between them
     assert graph[0][3] >= 40                       # the captured weight-gradient kernels wrote into the bucket slots
     noise = ('key_norm.bias', '.key.bias')
     for rank in (0, 1):

@@ -55,6 +55,7 @@ class GradReducer:
         self._handed = set()
         self._hooks_live = True
         self._next = 0               # index of the next bucket to launch (strict order)
+        self._order, self._order_hooks = [], []     # first backward: the order in which the gradients became complete
 
     # -- plan -------------------------------------------------------------------------------
     def _build(self):
@@ -64,6 +65,21 @@ class GradReducer:
         dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)      # union over ranks
         used = [p for p, f in zip(cand, flags.tolist()) if f]
         used.reverse()               # parameters() order is roughly forward order -> reverse ~ backward order
+        # Better: the order in which the first backward completed the gradients (recorded by begin()'s hooks; rank 0's order
+        # for everybody).  Buckets then fill in the order backward produces them -- which is what lets a hook-driven or a
+        # stage-by-stage replayed backward (vilco_amd/graph.py) launch them early; module registration order does not (the
+        # text stem and the neck come last in parameters() and finish with the LAST stage of backward).
+        for h in self._order_hooks:
+            h.remove()
+        self._order_hooks = []
+        pos = {pid: i for i, pid in enumerate(self._order)}
+        rank_of = torch.tensor([pos.get(id(p), 1 << 30) for p in cand], dtype=torch.int64, device=cand[0].device)
+        if self.world > 1:
+            dist.broadcast(rank_of, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        rk = dict(zip((id(p) for p in cand), rank_of.tolist()))
+        if any(v < (1 << 30) for v in rk.values()):
+            used.sort(key=lambda p: rk[id(p)])       # stable: parameters the first backward did not reach keep the old order, last
+        self._order = []
         self.buckets, cur, cur_bytes = [], [], 0
         for p in used:
             cur.append(p)
@@ -169,6 +185,11 @@ class GradReducer:
             for b in self.buckets:
                 b["left"], b["work"], b["done"] = len(b["params"]), None, set()
             self._pending = []
+        elif self.enabled and not self._order_hooks:
+            self._order = []
+            for p in self.model.parameters():
+                if p.requires_grad:
+                    self._order_hooks.append(p.register_post_accumulate_grad_hook(lambda param: self._order.append(id(param))))
 
     def finish(self):
         """wait for the collectives and leave the averaged gradient in every planned p.grad (views of the flat
@@ -214,12 +235,25 @@ class GradReducer:
         replayed backward is one graph launch)."""
         if not self.enabled:
             return
+        self.reduce_begin()
+        self.reduce_launch(len(self.buckets))
+        self.reduce_wait()
+
+    # the same exchange in pieces, for a backward replayed in stages (GraphedStep segments): buckets go out in plan order as soon
+    # as the stage that completes their last gradient has been enqueued, and run under the stages that follow
+    def reduce_begin(self):
         if self.buckets is None:
             self._build()
         self.begin(hooks=False)
-        for b in self.buckets:
-            self._launch(b)
-        self._next = len(self.buckets)
+
+    def reduce_launch(self, upto):
+        """launch buckets [already launched, upto) -- every rank with the same `upto` sequence"""
+        while self._next < min(int(upto), len(self.buckets)):
+            self._launch(self.buckets[self._next])
+            self._next += 1
+
+    def reduce_wait(self):
+        self.reduce_launch(len(self.buckets))
         with torch.no_grad():
             for b in self._pending:
                 b["work"].wait()
@@ -265,11 +299,12 @@ class GradReducer:
         """forget the plan (the set of trained parameters changed); the next `finish` builds a new one"""
         self.remove()
         self.buckets, self._slot, self._slot_by_ptr, self._pending = None, {}, {}, []
+        self._order = []
 
     def remove(self):
         from . import ops
         if ops.grad_slot_provider is not None and getattr(ops.grad_slot_provider, "__self__", None) is self:
             ops.grad_slot_provider = None
-        for h in self._hooks:
+        for h in self._hooks + self._order_hooks:
             h.remove()
-        self._hooks = []
+        self._hooks, self._order_hooks = [], []

@@ -31,11 +31,28 @@ from . import _lib, ops
 
 
 _DP_REPLAY_SYNC = os.environ.get("VILCO_DP_REPLAY_SYNC", "1") != "0"
+# data-parallel replays: the backward captured as one hipGraph per stage (heads + losses, then block by block -- ops.seg_cut),
+# the gradient buckets a stage completes launched right behind its replay, under the stages that follow.  0: one graph, the
+# whole exchange after it.
+# Opt-in (VILCO_DP_SEGMENTS=1): bit-exact against the eager reducer on the models of tests/test_dist_gpu.py, but at config P the
+# staged replay's gradients of the XLNet layer's r_w_bias / r_r_bias differ from the one-graph replay's (tools/lab/dp_staged_probe.py,
+# dp_staged_dbg.py: dependent on the forked side streams and on the allocation pattern -- not understood yet), so the default
+# stays the one-graph replay with the exchange behind it.
+_DP_SEGMENTS = os.environ.get("VILCO_DP_SEGMENTS", "0") == "1"
+
+
+def _capture_kw():
+    """with a process group alive, RCCL's watchdog thread polls the events of finished collectives; under the default
+    ("global") capture error mode such a query from ANOTHER thread while this one captures kills the capture -- and the
+    watchdog (seen on a one-rank group: 'operation not permitted when stream is capturing').  thread_local: only this
+    thread's calls are policed."""
+    import torch.distributed as dist
+    return {"capture_error_mode": "thread_local"} if (dist.is_available() and dist.is_initialized()) else {}
 
 
 class GraphedStep:
     def __init__(self, model, optimizer=None, clip_grad_l2norm=-1.0, eager_steps=2, between=None, enabled=True,
-                 gt_pad=8, max_graphs=16, reducer=None, comm_in_graph=None):
+                 gt_pad=8, max_graphs=16, reducer=None, comm_in_graph=None, segments=None):
         """optimizer: a FusedOptimizer (None: forward + backward only, gradients left in p.grad);
         eager_steps: iterations of a new signature run eagerly before its capture (>= 1 with an optimizer: the capture
         must follow an eager update, whose max|w| partials scale the captured weight packs);
@@ -47,12 +64,18 @@ class GraphedStep:
         reducer's autograd hooks stay live during the capture, every collective lands on RCCL's stream behind an event of
         the capture stream, and a replay overlaps the exchange with the rest of backward the way the eager step does.  Needs
         the "nccl" backend; falls back to the exchange after the replay when the capture refuses.  Exercised on one rank
-        (tests/test_dist_gpu.py); not yet on a multi-GPU node, hence opt-in."""
+        (tests/test_dist_gpu.py); not yet on a multi-GPU node, hence opt-in.
+        segments (default: env VILCO_DP_SEGMENTS, OFF -- see _DP_SEGMENTS; only with an enabled reducer and without comm_in_graph): the backward is
+        captured in stages -- graph 1 = forward + heads / losses backward, then one graph per backbone stage, cut at the
+        pyramid levels (ops.seg_cut) -- and a replayed iteration launches every gradient bucket as soon as the stage that
+        completes it has been enqueued: the all-reduces run on the collective's stream under the remaining stages, no
+        collective is captured, and the numbers are those of the single-graph step (same kernels, same order per stage)."""
         self.model, self.optimizer, self.clip = model, optimizer, float(clip_grad_l2norm)
         self.eager_steps = max(int(eager_steps), 1 if optimizer is not None else 0)
         self.between, self.enabled, self.gt_pad, self.max_graphs = between, bool(enabled), gt_pad, int(max_graphs)
         self.reducer = reducer
         self.comm_in_graph = (os.environ.get("VILCO_DP_GRAPH_COMM", "0") == "1") if comm_in_graph is None else bool(comm_in_graph)
+        self.segments = _DP_SEGMENTS if segments is None else bool(segments)
         self._graphs = {}
         self._pool = None
         self._lr_dev = None
@@ -156,21 +179,50 @@ class GraphedStep:
                 # comm: the hooks stay live and the all-reduces are captured with the backward they overlap.
                 self.reducer.begin(hooks=comm)
             failed = None
+            staged = bool(red is not None and self.segments and not comm)
+            tape = ops.SegTape() if staged else None
+            seg_graphs, seg_done = [], []
+            forks = ops._FORKS
             try:
-                with torch.cuda.graph(g, pool=self._pool):
+                ops.seg_tape = tape
+                if staged:
+                    # no forked chains (text side, regression head) in a staged capture: with them the XLNet bias gradients of the
+                    # stage after came out of a replay as zeros (tools/lab/dp_staged_dbg.py: exact without forks, exact with the
+                    # fp32 dS path -- an ordering between the streams of one stage graph and the next that is not understood yet).
+                    # Costs the ~1 ms the forks gain on one GPU; the exchange it lets run under backward is worth several.
+                    ops._FORKS = set()
+                with torch.cuda.graph(g, pool=self._pool, **_capture_kw()):
                     if red is not None:
                         red._capture_stream = torch.cuda.current_stream()
                     _lib.check(lib.vilco_seed_word_bump(ops._stream()))
                     losses = model.forward_prepared(static, None, task_id=task_id)
-                    losses['final_loss'].backward()
+                    ops.seg_tape = None          # (the cuts are on the tape; nothing after the forward makes new ones)
+                    losses['final_loss'].backward()      # staged: stops at the leaves of the last cut
                     if comm:
                         red.finish()             # waits become edges of the graph; p.grad = views of the averaged buckets
                     ops.join_side_streams()      # forked chains (ops.fork_enabled) end here
                     keys = sorted(losses)
                     out = torch.stack([losses[k].detach().reshape(()).float() for k in keys])
+                if staged:
+                    # one graph per stage, last stage first: its roots are the tensors the stage handed on, seeded with what
+                    # the later stages accumulated in the leaves that replaced them
+                    seg_done.append(self._grad_marks())
+                    for st in sorted({r[2] for r in tape.records}, reverse=True):
+                        recs = [r for r in tape.records if r[2] == st and r[1].grad is not None]
+                        if not recs:
+                            continue
+                        gs = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gs, pool=self._pool if self._pool is not None else g.pool(), **_capture_kw()):
+                            red._capture_stream = torch.cuda.current_stream()
+                            torch.autograd.backward([r[0] for r in recs], [r[1].grad for r in recs])
+                            ops.join_side_streams()
+                        seg_graphs.append(gs)
+                        seg_done.append(self._grad_marks())
             except Exception as e:               # noqa: BLE001 -- re-raised below unless it is the collectives' capture
                 failed = e
             finally:
+                ops.seg_tape = None
+                ops._FORKS = forks
                 if self.reducer is not None:
                     self.reducer._capture_stream = None
                     self.reducer.end_capture()
@@ -183,7 +235,9 @@ class GraphedStep:
             for p in self.params:
                 p.grad = None
         ent['comm'] = comm
-        del losses
+        ent['seg_graphs'] = seg_graphs if staged else None
+        ent['seg_marks'] = seg_done if staged else None
+        del losses, tape                 # the cut leaves' .grad buffers stay where the stage graphs read and write them (pool)
         blocks.reset_drop_pool()
         if self._pool is None:
             self._pool = g.pool()
@@ -204,13 +258,15 @@ class GraphedStep:
                     p.grad = torch.zeros_like(p)
                     ent['fill'].append(p.grad)
         ent.update(graph=g, static=static, out=out, keys=keys, grads=[p.grad for p in self.params])
+        if ent.get('seg_graphs') is not None:
+            ent['seg_upto'] = self._bucket_schedule(ent['seg_marks'])
         if self.optimizer is not None:
             opt = self.optimizer
             opt.prepare_step(pin=True)       # plans + pointer tables for THESE gradient tensors, built outside the capture
             if self._lr_dev is None:
                 self._lr_dev = torch.zeros(16, dtype=torch.float32, device=self.params[0].device)
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=self._pool):
+            with torch.cuda.graph(g2, pool=self._pool, **_capture_kw()):
                 opt.step(clip_grad_l2norm=self.clip, lr_dev=self._lr_dev)
             for pl in opt._plans:            # the capture counted an update that did not run
                 pl['count'] -= 1
@@ -222,16 +278,70 @@ class GraphedStep:
         ent['wgen'] = ops._weight_gen[0]
         self.stats['captured'] += 1
 
+    def _grad_marks(self):
+        """(address, version) of every parameter's gradient right now: a stage touched the gradients whose mark moved"""
+        return [None if p.grad is None else (p.grad.data_ptr(), p.grad._version) for p in self.params]
+
+    def _bucket_schedule(self, marks):
+        """marks[k] = _grad_marks() after stage k of the captured backward (0 = graph 1).  -> upto[k]: the buckets [0, upto[k])
+        of the reducer's plan are complete once stage k has run (plan order = launch order on every rank; a bucket waits
+        for the stage that last touches any of its parameters, and for every bucket before it)."""
+        last = {}
+        prev = [None] * len(self.params)
+        for k, m in enumerate(marks):
+            for p, a, b in zip(self.params, prev, m):
+                if b is not None and a != b:
+                    last[id(p)] = k
+            prev = m
+        ready = [max([last.get(id(p), 0) for p in b["params"]] or [0]) for b in self.reducer.buckets]
+        upto, n = [], 0
+        for k in range(len(marks)):
+            while n < len(ready) and max(ready[:n + 1]) <= k:
+                n += 1
+            upto.append(n)
+        upto[-1] = len(ready)
+        return upto
+
     # ------------------------------------------------------------------ replay
+    def _replay_staged(self, ent, inp):
+        """graph 1, then stage by stage; behind every stage the buckets it completed (collectives enqueued on the current
+        stream's order by torch.distributed: they start when that stage is done and run under the next ones)"""
+        red = self.reducer
+        for p, g in zip(self.params, ent['grads']):
+            if p.grad is not g:
+                p.grad = g
+        if ent['fill']:
+            torch._foreach_zero_(ent['fill'])
+        red.reduce_begin()
+        graphs = [ent['graph']] + list(ent['seg_graphs'])
+        if not red._avg and _DP_REPLAY_SYNC:
+            # gloo (CPU-side collectives: tests, two replicas on one GPU): a gloo collective next to a running graph crawls
+            # (seconds per step, see _replay) -- the stages are replayed back to back and the exchange follows, unoverlapped
+            for gk in graphs:
+                gk.replay()
+            torch.cuda.current_stream().synchronize()
+            red.reduce_launch(len(red.buckets))
+        else:
+            for k, gk in enumerate(graphs):
+                gk.replay()
+                red.reduce_launch(ent['seg_upto'][k])
+        red.reduce_wait()
+
     def _replay(self, ent, inp):
         static = ent['static']
         for name, t in inp.tensors():
             getattr(static, name).copy_(t, non_blocking=True)
-        ent['graph'].replay()
+        staged = ent.get('seg_graphs') is not None and self.reducer is not None and self.reducer.enabled
+        if staged:
+            self._replay_staged(ent, inp)
+        else:
+            ent['graph'].replay()
+            for gk in (ent.get('seg_graphs') or ()):      # captured in stages, the exchange switched off since: plain replays
+                gk.replay()
         for p, g in zip(self.params, ent['grads']):
             if p.grad is not g:
                 p.grad = g
-        if self.reducer is not None and self.reducer.enabled and not ent.get('comm'):
+        if self.reducer is not None and self.reducer.enabled and not ent.get('comm') and not staged:
             if ent['fill']:
                 torch._foreach_zero_(ent['fill'])
             # The exchange reads what the replay writes, so it cannot start earlier anyway -- and a collective queued behind a

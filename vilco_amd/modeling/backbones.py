@@ -159,13 +159,22 @@ class ConvTransformerBackbone(nn.Module):
                 for blk in self.txt_stem:
                     q, q_lens = blk.forward_tm(q, q_lens)
 
-        for blk in self.stem:
+        x = ops.seg_cut(x, next_stage=True)              # (staged backward, see below: embeddings | stem blocks | branch blocks)
+        for blk in self.stem[:-1]:
             x, lens = blk.forward_tm(x, lens)            # stem blocks are called without cross_y
+            x = ops.seg_cut(x, next_stage=True)
+        for blk in self.stem[-1:]:
+            x, lens = blk.forward_tm(x, lens)
 
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             q.record_stream(torch.cuda.current_stream())
 
+        # ops.seg_cut: identity, or (a GraphedStep capturing the backward in stages) the cut between two stages: the text
+        # features and every pyramid level go on as leaves -- stage 0 = embeddings + text side + stem, then one per branch block
+        if q is not None:
+            q = ops.seg_cut(q)
+        x = ops.seg_cut(x, next_stage=True)
         feats, all_lens = [x], [lens]
         for idx, blk in enumerate(self.branch):
             if idx == 0:
@@ -177,6 +186,7 @@ class ConvTransformerBackbone(nn.Module):
                 x, lens = blk.forward_tm(x, lens)
             else:
                 x, lens = blk.forward_tm(x, lens, q, q_lens)
+            x = ops.seg_cut(x, next_stage=True)
             feats.append(x)
             all_lens.append(lens)
         return feats, all_lens

@@ -121,8 +121,14 @@ def side_stream(name, device=None):
 def join_side_streams():
     """make the current stream wait for everything forked so far (end of a captured backward)"""
     cur = torch.cuda.current_stream()
+    capturing = torch.cuda.is_current_stream_capturing()
     for (name, dev), st in _side_streams.items():
         if dev == cur.device_index:
+            if capturing:                       # a backward captured in stages: only the streams this capture forked into
+                with torch.cuda.stream(st):     # (an event of a stream outside the capture cannot be waited for inside it)
+                    live = torch.cuda.is_current_stream_capturing()
+                if not live:
+                    continue
             cur.wait_stream(st)
     _dw_seen.clear()
 
@@ -444,6 +450,36 @@ def gemm_group(calls):
 # The tag is ignored once the tensor's version counter moved (in-place edits) or another precision is active.
 produce_amax = os.environ.get("VILCO_PRODUCER_AMAX", "1") != "0"
 AMAX_PARTS = 2048
+
+
+# ---- cuts of the autograd graph (vilco_amd.graph.GraphedStep, data-parallel replays).  With a tape active the
+# backbone hands every pyramid level on as a detached LEAF (`seg_cut`): the backward of the step then runs as one
+# torch.autograd.backward call per stage -- heads + losses first, then block by block -- each stops at the previous stage's
+# leaves, whose accumulated .grad seeds the next call.  The stages are captured as separate hipGraphs, and between their
+# replays the gradient buckets that are already complete go out on the collective's stream under the rest of backward.
+class SegTape:
+    def __init__(self):
+        self.records = []          # (root tensor, leaf that continued the forward, stage that produced the root)
+        self.stage = 0
+
+
+seg_tape = None
+
+
+def seg_cut(x, next_stage=False):
+    """x -> the tensor the forward continues with: x itself, or (tape active) a leaf sharing its memory.
+    next_stage: what follows belongs to the next stage."""
+    tape = seg_tape
+    if tape is None or not torch.is_tensor(x) or not x.requires_grad:
+        return x
+    leaf = x.detach().requires_grad_(True)
+    for k in ("_vilco_amax", "_vilco_planes", "_vilco_tap_planes"):     # producer-written operand planes / maxima travel along
+        if hasattr(x, k):
+            setattr(leaf, k, getattr(x, k))
+    tape.records.append((x, leaf, tape.stage))
+    if next_stage:
+        tape.stage += 1
+    return leaf
 
 
 def _tag_amax(t, parts, n):
