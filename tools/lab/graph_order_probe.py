@@ -1,0 +1,41 @@
+"""Is work queued right behind a hipGraph launch ordered after the WHOLE graph?  (in the staged data-parallel replay it
+was not.)  A graph with a forked branch writes `flag = step` at its very end; right behind the replay (a) an eager kernel on the same
+stream and (b) another stream through an event read the flag."""
+import torch
+dev = torch.device("cuda:0")
+x = torch.randn(4096, 4096, device=dev); y = torch.randn(4096, 4096, device=dev)
+step = torch.zeros(1, device=dev); flag = torch.zeros(1, device=dev); acc = torch.zeros(4096, 4096, device=dev)
+side, other = torch.cuda.Stream(), torch.cuda.Stream()
+def body():
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        z = x
+        for _ in range(6): z = (z @ y) * 1e-3
+    w = x
+    for _ in range(3): w = (w @ y) * 1e-3
+    cur.wait_stream(side)
+    acc.copy_(w + z)
+    flag.copy_(step)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    for _ in range(2): body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        body()
+    bad_a = bad_b = 0
+    n = 300
+    snaps_a, snaps_b = [], []
+    for i in range(1, n + 1):
+        step.fill_(float(i))
+        g.replay()
+        snaps_a.append(flag.clone())                       # (a) eager kernel right behind the launch, same stream
+        ev = torch.cuda.Event(); ev.record(s)
+        other.wait_event(ev)
+        with torch.cuda.stream(other):
+            snaps_b.append(flag.clone())                   # (b) another stream behind an event recorded after the launch
+    torch.cuda.synchronize()
+    bad_a = sum(int(float(t) != float(i)) for i, t in enumerate(snaps_a, 1))
+    bad_b = sum(int(float(t) != float(i)) for i, t in enumerate(snaps_b, 1))
+print("replays %d: stale reads by the eager kernel behind the launch %d, by the other stream behind an event %d" % (n, bad_a, bad_b))

@@ -34,10 +34,14 @@ _DP_REPLAY_SYNC = os.environ.get("VILCO_DP_REPLAY_SYNC", "1") != "0"
 # data-parallel replays: the backward captured as one hipGraph per stage (heads + losses, then block by block -- ops.seg_cut),
 # the gradient buckets a stage completes launched right behind its replay, under the stages that follow.  0: one graph, the
 # whole exchange after it.
-# Opt-in (VILCO_DP_SEGMENTS=1): bit-exact against the eager reducer on the models of tests/test_dist_gpu.py, but at config P the
-# staged replay's gradients of the XLNet layer's r_w_bias / r_r_bias differ from the one-graph replay's (tools/lab/dp_staged_probe.py,
-# dp_staged_dbg.py: dependent on the forked side streams and on the allocation pattern -- not understood yet), so the default
-# stays the one-graph replay with the exchange behind it.
+# Opt-in (VILCO_DP_SEGMENTS=1).  Bit-exact against the eager reducer on the models of tests/test_dist_gpu.py; at config P equal to
+# the one-graph replay up to the order in which the cut leaves accumulate their gradients (<= 2.4e-4 of a tensor's maximum,
+# tools/lab/dp_staged_dbg2.py) -- PROVIDED the host waits for a stage before it queues that stage's buckets: queued
+# asynchronously behind the stage graphs, the small gradients (the ones gathered into their bucket by a copy) came back from the
+# exchange with an earlier step's values or garbage from about the fifth replay on, non-deterministically (a timing-dependent
+# hazard not understood yet; plain ordering behind a graph launch holds, tools/lab/graph_order_probe.py).  _replay_staged
+# therefore synchronises before every group of buckets (VILCO_DP_STAGE_SYNC=0 drops it: wrong results); the collectives still
+# run under the stages that follow.  Not the default until it has met a multi-GPU node.
 _DP_SEGMENTS = os.environ.get("VILCO_DP_SEGMENTS", "0") == "1"
 
 
@@ -314,7 +318,7 @@ class GraphedStep:
             torch._foreach_zero_(ent['fill'])
         red.reduce_begin()
         graphs = [ent['graph']] + list(ent['seg_graphs'])
-        if not red._avg and _DP_REPLAY_SYNC:
+        if (not red._avg and _DP_REPLAY_SYNC) or os.environ.get("VILCO_DP_STAGE_LATE") == "1":      # (_LATE: debugging aid)
             # gloo (CPU-side collectives: tests, two replicas on one GPU): a gloo collective next to a running graph crawls
             # (seconds per step, see _replay) -- the stages are replayed back to back and the exchange follows, unoverlapped
             for gk in graphs:
@@ -322,9 +326,13 @@ class GraphedStep:
             torch.cuda.current_stream().synchronize()
             red.reduce_launch(len(red.buckets))
         else:
+            hsync = os.environ.get("VILCO_DP_STAGE_SYNC", "1") != "0"      # see _DP_SEGMENTS: required on this runtime
             for k, gk in enumerate(graphs):
                 gk.replay()
-                red.reduce_launch(ent['seg_upto'][k])
+                if ent['seg_upto'][k] > red._next:
+                    if hsync:
+                        torch.cuda.current_stream().synchronize()
+                    red.reduce_launch(ent['seg_upto'][k])
         red.reduce_wait()
 
     def _replay(self, ent, inp):
