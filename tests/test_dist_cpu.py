@@ -254,3 +254,26 @@ def test_ewc_mas_importance_is_averaged_over_ranks():
         want = (res[0][kind][1] + res[1][kind][1]) / 2
         assert not np.allclose(res[0][kind][1], res[1][kind][1])          # the shards really differ
         assert np.allclose(res[0][kind][0], want, atol=1e-6) and np.allclose(res[1][kind][0], want, atol=1e-6)
+
+
+def test_stage_bucket_schedule():
+    """GraphedStep._bucket_schedule (the backward replayed in stages, vilco_amd/graph.py): a bucket may go out after stage k only
+    if every gradient in it -- and in every bucket before it, the launch order being the plan order on all ranks -- was last
+    touched in a stage <= k; the last stage releases everything."""
+    import types
+    from vilco_amd.graph import GraphedStep
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(6)]
+    gs = GraphedStep.__new__(GraphedStep)
+    gs.params = ps
+    # plan: bucket 0 = {p0, p1}, bucket 1 = {p2}, bucket 2 = {p3, p4}; p5 is planned nowhere
+    gs.reducer = types.SimpleNamespace(buckets=[{"params": [ps[0], ps[1]]}, {"params": [ps[2]]}, {"params": [ps[3], ps[4]]}])
+    N = None
+    marks = [
+        [(10, 0), N, N, N, N, N],                       # stage 0 (graph 1) produced p0's gradient
+        [(10, 0), (11, 0), (12, 0), N, N, N],           # stage 1: p1, p2
+        [(10, 0), (11, 1), (12, 0), (13, 0), N, N],     # stage 2: p1 again (used twice), p3
+        [(10, 0), (11, 1), (12, 0), (13, 0), N, (15, 0)],   # stage 3: only the unplanned p5; p4 never gets one (zero-filled)
+    ]
+    assert gs._bucket_schedule(marks) == [0, 0, 3, 3]     # bucket 0 waits for stage 2 (p1), bucket 1 behind it; p4 (no gradient) is ready from the start
+    marks2 = [[(10, 0), (11, 0), N, N, N, N], [(10, 0), (11, 0), N, (13, 0), (14, 0), N], [(10, 0), (11, 0), (12, 0), (13, 0), (14, 0), N]]
+    assert gs._bucket_schedule(marks2) == [1, 1, 3]       # bucket 2 is complete after stage 1 but must not overtake bucket 1
