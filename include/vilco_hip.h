@@ -147,6 +147,10 @@ int vilco_gemm_set_fixup(int32_t on);
  * K chunks staged by LDS-DMA in whole 128-byte lines; default), 0 = gemm_pp_kernel (rounds 1-4: 32-element K-steps staged through
  * registers).  Initial value: environment VILCO_GEMM_GL=0 selects the old kernel. */
 int vilco_gemm_set_gl(int32_t on);
+/* Round 5: a two-part product of 257..512 192-row tiles (between one and two rounds on the 256 CUs) is launched as ONE full round */
+/* of 192-row tiles over its first rows + one round of 128-row tiles over the rest (same arithmetic per tile, disjoint rows).   */
+/* 0 (default: measured, no gain in the step) / 1; env VILCO_GEMM_TAIL128.                                                     */
+int vilco_gemm_set_tail128(int32_t on);
 /* floats written to desc->amax_out by vilco_gemm(desc) (depends on the tile / split-K plan); 0: not available */
 int32_t vilco_gemm_amax_parts(const vilco_gemm_desc* desc);
 int vilco_gemm_profile_begin(void);

@@ -165,6 +165,37 @@ def test_linear_group_is_bitwise_the_individual_layers(dev, M, N, K):
     assert torch.equal(Y2[0], res[False][0][0]) and Y2[1].shape[1] == 7
 
 
+@pytest.mark.parametrize("M,N,K,k3", [(4608, 2048, 256, False), (2304, 4096, 128, False), (3300, 1024, 192, False), (4600, 1024, 64, True)])
+def test_gemm_tail_round_of_128_row_tiles_is_bitwise(dev, M, N, K, k3):
+    """Round 5 (vilco_gemm_set_tail128): a two-part product of 257..512 192-row tiles runs as one full round of 192-row tiles over
+    its first rows + one round of 128-row tiles over the rest.  A tile's arithmetic does not depend on its height: outputs and
+    the input gradient (the same split on the dX product) bit for bit those of the single launch -- at 384 tiles (the split
+    applies), at a ragged M, through the k = 3 conv path (tap image operand), and checked against float64."""
+    from vilco_amd import ops, _lib
+    lib = _lib.load()
+    torch.manual_seed(5)
+    x = torch.randn(2, M // 2, K)
+    w = torch.randn(N, K, 3 if k3 else 1) / math.sqrt(K * (3 if k3 else 1))
+    b = torch.randn(N)
+    dy = torch.randn(2, M // 2, N).to(dev)
+    lens = torch.tensor([M // 2, M // 2 - 5], dtype=torch.int32).to(dev)
+    res = {}
+    try:
+        for on in (0, 1):
+            _lib.check(lib.vilco_gemm_set_tail128(on))
+            X, W, Bp = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+            y = ops.conv3(X, W, Bp, lens) if k3 else ops.linear(X, W, Bp)
+            y.backward(dy)
+            res[on] = (y.detach().clone(), X.grad.clone(), W.grad.clone(), Bp.grad.clone())
+    finally:
+        _lib.check(lib.vilco_gemm_set_tail128(0))      # (the library's default: measured, no gain in the step)
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+    if not k3:
+        want = x.double() @ w.double().squeeze(-1).t() + b.double()
+        assert rel(res[1][0].cpu(), want.float()) < TOL_GEMM
+
+
 def test_linear_unaligned_k(dev):
     from vilco_amd import ops
     x, w = torch.randn(37, 50), torch.randn(30, 50)

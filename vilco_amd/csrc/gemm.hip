@@ -72,6 +72,7 @@ struct GArgs {
   int batch_inner;
   long sCo, sCi;
   int tiles_n, ntiles;
+  int tm0;                // first row tile of this launch (a product launched as two row ranges of different tile heights)
   int ksplit, kchunk;   // kchunk = K-steps per split
   long split_stride;    // elements between split slabs
   unsigned* tile_ctr;   // split-K fix-up: arrival counter per (batch, tile); null = partial slabs + splitk_reduce_kernel
@@ -787,7 +788,7 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
     const int nwg = g.ntiles, q = nwg >> 3, r = nwg & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
-  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+  const int tm = bid / g.tiles_n + g.tm0, tn = bid % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int zo = z / g.batch_inner, zi = z % g.batch_inner;
   const int ks = blockIdx.y;
@@ -1167,6 +1168,11 @@ unsigned* tile_counters(hipStream_t s) {
 
 inline bool& gl_enabled() {      // VILCO_GEMM_GL=0 / vilco_gemm_set_gl(0): the fp16 x2 products stay on gemm_pp_kernel (rounds 1-4)
   static bool v = [] { const char* e = getenv("VILCO_GEMM_GL"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
+inline bool& tail128_enabled() {      // VILCO_GEMM_TAIL128=1 / vilco_gemm_set_tail128(1): see gemm_impl (off by default: measured, no gain)
+  static bool v = [] { const char* e = getenv("VILCO_GEMM_TAIL128"); return e && e[0] == '1'; }();
   return v;
 }
 
@@ -1680,6 +1686,7 @@ static int gemm_impl(const vilco_gemm_desc* d, void* stream, GArgs* gout, Plan* 
   g.batch_inner = d->batch_inner; g.sCo = d->sCo; g.sCi = d->sCi;
   g.tiles_n = (d->N + BN - 1) / BN;
   g.ntiles = g.tiles_n * ((d->M + p.BM - 1) / p.BM);
+  g.tm0 = 0;
   g.ksplit = p.ksplit; g.kchunk = p.kchunk; g.split_stride = p.split_stride;
   g.inv_a = inv_a; g.inv_b = inv_b;
   g.band = d->band; g.bandT = d->bandT;
@@ -1700,6 +1707,38 @@ static int gemm_impl(const vilco_gemm_desc* d, void* stream, GArgs* gout, Plan* 
   const int nz = d->batch_outer * d->batch_inner;
   if (gout) { *gout = g; *pout = p; return VILCO_OK; }
   dim3 grid(g.ntiles, p.ksplit, nz);
+  // Between one and two rounds of 192-row tiles (384 tiles on 256 CUs: the k = 3 head convs at 9082 rows, 4608 x 2048, 2304 x 4096 ...)
+  // the second round is half empty and costs a whole one.  Two launches instead: ONE full round of 192-row tiles over the first
+  // rows, the remaining rows as one round of 128-row tiles (a round of those costs 0.74 of a 192-row round, see make_plan):
+  // 1.74 instead of 2 round-units on paper.  Same tiles' arithmetic as either height alone (a tile's K order does not depend on
+  // its height), row ranges disjoint, bit-identical results (tests/test_ops_gpu.py).  MEASURED (tools/lab/tail128_ab.sh, operands
+  // packed): 9082 x 1024 x 3072 184.9 -> 178.4 us, 4608 x 2048 x 1024 / 2304 x 4096 x 1024 / 9216 x 1024 x 1024 unchanged (69 us), the
+  // P step 20.49 -> 20.63 ms: the second launch starts only when the first has drained, and a lone round of 128-row tiles costs
+  // more than the 0.74 it costs inside a multi-round launch.  OFF by default (VILCO_GEMM_TAIL128=1 / vilco_gemm_set_tail128(1)).
+  if (tail128_enabled() && p.gl && d->precision == 3 && p.BM == 192 && p.ksplit == 1 && nz == 1 && !g.amax_out && d->band == 0 &&
+      g.ntiles > 256 && g.ntiles <= 512 && g.tiles_n <= 128 && (256 % g.tiles_n) == 0) {
+    const int rows1 = (256 / g.tiles_n) * 192;                        // one full round of 192-row tiles (a multiple of 128 rows)
+    const long rem_tiles = (long)((d->M - rows1 + 127) / 128) * g.tiles_n;
+    if (rows1 < d->M && rem_tiles <= 256) {
+      const bool ak = p.a_km, bk = p.b_km;
+      GArgs g1 = g, g2 = g;
+      g1.ntiles = 256; g1.tm0 = 0;
+      g2.ntiles = (int)rem_tiles; g2.tm0 = rows1 / 128;
+      hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;      // (every profile pair owns its two events)
+      if (prof().on) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2); hipEventCreate(&e3); hipEventRecord(e0, s); }
+      launch_gl<192, false>(g1, dim3(g1.ntiles, 1, 1), s, ak, bk);
+      if (e0) { hipEventRecord(e1, s); hipEventRecord(e2, s); }
+      launch_gl<128, false>(g2, dim3(g2.ntiles, 1, 1), s, ak, bk);
+      if (e0) {
+        hipEventRecord(e3, s);
+        prof().ev.emplace_back(e0, e1);
+        prof().rec.push_back(ProfRec{{rows1, d->N, d->K, nz, 192, 1, d->precision, p.a_km, p.b_km, p.a_tap | (p.b_tap << 4)}});
+        prof().ev.emplace_back(e2, e3);
+        prof().rec.push_back(ProfRec{{d->M - rows1, d->N, d->K, nz, 128, 1, d->precision, p.a_km, p.b_km, p.a_tap | (p.b_tap << 4)}});
+      }
+      return vilco_launch_status();
+    }
+  }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
   {
@@ -1823,6 +1862,11 @@ extern "C" int vilco_gemm_set_fixup(int32_t on) {
 
 extern "C" int vilco_gemm_set_gl(int32_t on) {
   gl_enabled() = on != 0;
+  return VILCO_OK;
+}
+
+extern "C" int vilco_gemm_set_tail128(int32_t on) {
+  tail128_enabled() = on != 0;
   return VILCO_OK;
 }
 
