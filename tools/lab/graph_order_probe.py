@@ -39,3 +39,34 @@ with torch.cuda.stream(s):
     bad_a = sum(int(float(t) != float(i)) for i, t in enumerate(snaps_a, 1))
     bad_b = sum(int(float(t) != float(i)) for i, t in enumerate(snaps_b, 1))
 print("replays %d: stale reads by the eager kernel behind the launch %d, by the other stream behind an event %d" % (n, bad_a, bad_b))
+
+# (c) the other direction: does a graph launch wait for EAGER work queued before it on the same stream?  A long eager chain ends by
+# writing `val = i`; the graph's first node copies `val` (main branch) and a forked branch copies it too.
+val = torch.zeros(1, device=dev); snap_main = torch.zeros(1, device=dev); snap_side = torch.zeros(1, device=dev)
+def body2():
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        snap_side.copy_(val)
+        z = x
+        for _ in range(2): z = (z @ y) * 1e-3
+    snap_main.copy_(val)
+    w = (x @ y) * 1e-3
+    cur.wait_stream(side)
+    acc.copy_(w + z)
+with torch.cuda.stream(s):
+    for _ in range(2): body2()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        body2()
+    res_m, res_s = [], []
+    for i in range(1, 201):
+        t = x
+        for _ in range(4): t = (t @ y) * 1e-3            # ~1 ms of eager work ...
+        val.fill_(float(i)); val.add_(t[0, 0] * 0)          # ... whose last kernels set val = i
+        g2.replay()
+        res_m.append(snap_main.clone()); res_s.append(snap_side.clone())
+    torch.cuda.synchronize()
+    bm = sum(int(float(a) != float(i)) for i, a in enumerate(res_m, 1)); bs = sum(int(float(a) != float(i)) for i, a in enumerate(res_s, 1))
+print("eager work before the launch, 200 replays: stale reads by the graph's first node %d, by its forked branch's first node %d" % (bm, bs))
