@@ -507,6 +507,35 @@ def test_dropout_op(dev):
     assert not torch.equal(y2, y)
 
 
+def test_attention_dropout_mask_statistics(dev):
+    """Round 5: the attention-probability mask has a function of its own (one strong hash per mask row + a two-multiply finalizer
+    per element, csrc/common.h).  Drop rate, independence of neighbours along both axes and across seeds, binomial spread of the
+    per-row / per-column rates -- what a Bernoulli mask has and a careless cheap hash does not (the first candidate had a
+    correlation of -0.0036 between elements 64 columns apart)."""
+    from vilco_amd import ops
+    p, shape = 0.1, (2, 4, 768, 768)
+    d = (ops.dropout_mask(p, 1234, shape, dev, "attn_prob") == 0).float().reshape(-1, shape[-1])
+    d2 = (ops.dropout_mask(p, 1235, shape, dev, "attn_prob") == 0).float().reshape(-1, shape[-1])
+    keep = ops.dropout_mask(p, 1234, shape, dev, "attn_prob")
+    assert set(keep.unique().tolist()) <= {0.0, float(torch.tensor(1.0 / (1.0 - p), dtype=torch.float32))}
+    rate = float(d.mean())
+    n = d.numel()
+    assert abs(rate - p) < 4 * math.sqrt(p * (1 - p) / n) + 1e-4, rate
+    x, y = d - rate, d2 - rate
+    var = rate * (1 - rate)
+
+    def corr(a, b):
+        return float((a * b).mean()) / var
+    tol = 5.0 / math.sqrt(n)                       # five standard errors of a sample correlation
+    for lag in (1, 2, 3, 4, 16, 64, 128, 256):
+        assert abs(corr(x[:, :-lag], x[:, lag:])) < tol, ("columns", lag)
+        assert abs(corr(x[:-lag], x[lag:])) < tol, ("rows", lag)
+    assert abs(corr(x, y)) < tol                   # another seed: another mask
+    for axis, m in ((1, shape[-1]), (0, d.shape[0])):
+        sd = float(d.mean(axis).std())
+        assert 0.85 < sd / math.sqrt(var / m) < 1.15, (axis, sd)
+
+
 @pytest.mark.parametrize("T,hd", [(100, 16), (130, 64), (130, 128), (130, 144)])
 def test_attention_prob_dropout(dev, T, hd):
     """attention with dropout on the probabilities == reference attention with the same mask (fwd + grads)."""
