@@ -28,8 +28,8 @@ def run(seg, calls, reduce=True):
             snaps[c] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
     red.remove()
     return snaps
-calls = (2, 3, 6)
-a = run(False, calls); b = run(True, calls); b2 = run(True, calls)
+calls = tuple(int(x) for x in os.environ.get('CALLS', '2,3,6').split(','))
+a = run(False, calls); b = run(True, calls); b2 = run(True, calls) if os.environ.get('TWICE', '1') == '1' else b
 for c in calls:
     bad = sorted(((float((a[c][k] - b[c][k]).abs().max() / (a[c][k].abs().max() + 1e-30)), k) for k in a[c] if not torch.equal(a[c][k], b[c][k])), reverse=True)
     rep = sum(int(not torch.equal(b[c][k], b2[c][k])) for k in b[c])

@@ -70,3 +70,33 @@ with torch.cuda.stream(s):
     torch.cuda.synchronize()
     bm = sum(int(float(a) != float(i)) for i, a in enumerate(res_m, 1)); bs = sum(int(float(a) != float(i)) for i, a in enumerate(res_s, 1))
 print("eager work before the launch, 200 replays: stale reads by the graph's first node %d, by its forked branch's first node %d" % (bm, bs))
+
+# (d) the same two directions under DEEP host run-ahead: nine launches of a 200-node graph per iteration with eager kernels between
+# them, no synchronisation for many iterations (the staged data-parallel replay's pattern)
+import os
+NIT, NG = int(os.environ.get("NIT", "80")), 9
+val2 = torch.zeros(1, device=dev); first = torch.zeros(1, device=dev); last = torch.zeros(1, device=dev)
+buf = torch.zeros(1 << 16, device=dev)
+def body3():
+    first.copy_(val2)
+    t = buf
+    for _ in range(200): t = t * 1.0001 + 1.0
+    buf.copy_(t * 0)
+    last.copy_(val2 + buf[0])
+with torch.cuda.stream(s):
+    for _ in range(2): body3()
+    torch.cuda.synchronize()
+    g3 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g3, stream=s):
+        body3()
+    A, Bv, want = [], [], []
+    for i in range(NIT):
+        for k in range(NG):
+            v = float(i * 16 + k + 1)
+            val2.fill_(v)                                  # eager, before the launch
+            g3.replay()
+            A.append(first.clone()); Bv.append(last.clone()); want.append(v)      # eager, behind the launch
+    torch.cuda.synchronize()
+    ba = sum(int(float(a) != w) for a, w in zip(A, want)); bb = sum(int(float(b) != w) for b, w in zip(Bv, want))
+    firstbad = next((i for i, (a, b, w) in enumerate(zip(A, Bv, want)) if float(a) != w or float(b) != w), None)
+print("deep run-ahead, %d launches: graph's first node read a stale eager value %d times, eager kernel behind the launch read a stale graph value %d times (first at launch %s)" % (len(want), ba, bb, firstbad))

@@ -37,6 +37,24 @@ import torch
 import torch.distributed as dist
 
 DEFAULT_BUCKET_MB = 64      # xGMI rings are per-link bound: few large collectives beat many small ones
+import os as _os
+_DEBUG_NO_COLLECTIVE = _os.environ.get("VILCO_DP_DEBUG_NO_COLLECTIVE") == "1"      # one-rank debugging aid (tools/lab/dp_staged_dbg2.py)
+
+
+_DEBUG_SLOW_COPY = _os.environ.get("VILCO_DP_DEBUG_SLOW_COPY") == "1"
+
+
+def _copy_list(dst, src):
+    if _DEBUG_SLOW_COPY:
+        for d, s_ in zip(dst, src):
+            d.copy_(s_)
+    else:
+        torch._foreach_copy_(dst, src)
+
+
+class _NoWork:
+    def wait(self):
+        return True
 
 
 class GradReducer:
@@ -163,9 +181,12 @@ class GradReducer:
                 src.append(p.grad)
                 dst.append(v)
         if src:
-            torch._foreach_copy_(dst, src)
+            _copy_list(dst, src)
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+        if _DEBUG_NO_COLLECTIVE and self.world == 1:
+            b["work"] = _NoWork()
+        else:
+            b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         self._pending.append(b)
 
     # -- per step ---------------------------------------------------------------------------
@@ -267,7 +288,7 @@ class GradReducer:
                         src.append(v)
                         dst.append(p.grad)
                 if src:
-                    torch._foreach_copy_(dst, src)
+                    _copy_list(dst, src)
         self._pending = []
         self._release_slots()
 
