@@ -11,6 +11,8 @@ from vilco_amd import ops
 from vilco_amd.dist import GradReducer
 from vilco_amd.graph import GraphedStep
 dev = torch.device("cuda:0")
+if os.environ.get('NOGC') == '1':
+    import gc; gc.disable()
 def run(seg, calls, reduce=True):
     torch.manual_seed(0)
     model = vm.make_meta_arch('LocPointTransformer', **dict(bench.p_config(), xlnet_config=bench.P_XLNET)).to(dev).train()
@@ -29,6 +31,8 @@ def run(seg, calls, reduce=True):
     red.remove()
     return snaps
 calls = tuple(int(x) for x in os.environ.get('CALLS', '2,3,6').split(','))
+if os.environ.get('STREAM') == '1':
+    _st = torch.cuda.Stream(); _ctx = torch.cuda.stream(_st); _ctx.__enter__()
 a = run(False, calls); b = run(True, calls); b2 = run(True, calls) if os.environ.get('TWICE', '1') == '1' else b
 for c in calls:
     bad = sorted(((float((a[c][k] - b[c][k]).abs().max() / (a[c][k].abs().max() + 1e-30)), k) for k in a[c] if not torch.equal(a[c][k], b[c][k])), reverse=True)

@@ -100,3 +100,20 @@ with torch.cuda.stream(s):
     ba = sum(int(float(a) != w) for a, w in zip(A, want)); bb = sum(int(float(b) != w) for b, w in zip(Bv, want))
     firstbad = next((i for i, (a, b, w) in enumerate(zip(A, Bv, want)) if float(a) != w or float(b) != w), None)
 print("deep run-ahead, %d launches: graph's first node read a stale eager value %d times, eager kernel behind the launch read a stale graph value %d times (first at launch %s)" % (len(want), ba, bb, firstbad))
+
+# (e) as (c), with a small H2D copy from pinned memory (an SDMA transfer) between the eager work and the launch -- the pattern of a
+# training step: ... eager kernels of the previous step, prepare()'s pinned H2D copies, graph launch
+pin = torch.zeros(8, dtype=torch.int32).pin_memory(); dst_small = torch.zeros(8, dtype=torch.int32, device=dev)
+with torch.cuda.stream(s):
+    res_m, res_s = [], []
+    for i in range(1, 201):
+        t = x
+        for _ in range(4): t = (t @ y) * 1e-3
+        val.fill_(float(i)); val.add_(t[0, 0] * 0)
+        pin.fill_(i)
+        dst_small.copy_(pin, non_blocking=True)             # SDMA H2D, queued behind the eager kernels
+        g2.replay()
+        res_m.append(snap_main.clone()); res_s.append(snap_side.clone())
+    torch.cuda.synchronize()
+    bm = sum(int(float(a) != float(i)) for i, a in enumerate(res_m, 1)); bs = sum(int(float(a) != float(i)) for i, a in enumerate(res_s, 1))
+print("eager work, then a pinned H2D copy, then the launch, 200 replays: stale reads by the graph's first node %d, by its forked branch %d" % (bm, bs))

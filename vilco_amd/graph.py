@@ -34,15 +34,15 @@ _DP_REPLAY_SYNC = os.environ.get("VILCO_DP_REPLAY_SYNC", "1") != "0"
 # data-parallel replays: the backward captured as one hipGraph per stage (heads + losses, then block by block -- ops.seg_cut),
 # the gradient buckets a stage completes launched right behind its replay, under the stages that follow.  0: one graph, the
 # whole exchange after it.
-# Opt-in (VILCO_DP_SEGMENTS=1).  Bit-exact against the eager reducer on the models of tests/test_dist_gpu.py; at config P equal to
-# the one-graph replay up to the order in which the cut leaves accumulate their gradients (<= 2.4e-4 of a tensor's maximum,
-# tools/lab/dp_staged_dbg2.py) -- PROVIDED the host waits for a stage before it queues that stage's buckets: queued
-# asynchronously behind the stage graphs, the small gradients (the ones gathered into their bucket by a copy) came back from the
-# exchange with an earlier step's values or garbage from about the fifth replay on, non-deterministically (a timing-dependent
-# hazard not understood yet; plain ordering behind a graph launch holds, tools/lab/graph_order_probe.py).  _replay_staged
-# therefore synchronises before every group of buckets (VILCO_DP_STAGE_SYNC=0 drops it: wrong results); the collectives still
-# run under the stages that follow.  Not the default until it has met a multi-GPU node.
-_DP_SEGMENTS = os.environ.get("VILCO_DP_SEGMENTS", "0") == "1"
+# Default for replays with a live reducer (VILCO_DP_SEGMENTS=0: one graph, the whole exchange behind it).  Bit-exact against the
+# eager reducer on the models of tests/test_dist_gpu.py; at config P equal to the one-graph replay up to the order in which the
+# cut leaves accumulate their gradients (<= 2.4e-4 of a tensor's maximum, tools/lab/dp_staged_dbg2.py, 60 calls, run-to-run
+# identical) -- ON A STREAM OF ITS OWN: replayed on the default (null) stream with the buckets queued asynchronously between
+# the stage graphs, the small gradients (the ones gathered into their bucket by a copy) came back stale or as garbage once the
+# host ran ahead (not RCCL, not the multi-tensor copy, not Python's GC; exact on any created stream).  _replay therefore moves
+# the staged replay to a private stream.  VILCO_DP_STAGE_SYNC=1 adds a host wait before every bucket group (the first
+# workaround; not needed any more).
+_DP_SEGMENTS = os.environ.get("VILCO_DP_SEGMENTS", "1") != "0"
 
 
 def _capture_kw():
@@ -63,13 +63,13 @@ class GraphedStep:
         between: callable run eagerly between backward and the update of every iteration;
         gt_pad: ground-truth rows are padded to this many segments per clip so that their count does not key the graph;
         reducer: a dist.GradReducer -- eager iterations exchange gradients from its autograd hooks (overlapped with
-        backward), replayed ones right after graph 1 (`reduce_now`, averaged in place);
+        backward), replayed ones stage by stage (`segments`, below) or right after graph 1 (`reduce_now`, averaged in place);
         comm_in_graph (default: env VILCO_DP_GRAPH_COMM, off): capture the bucketed RCCL all-reduces INSIDE graph 1 -- the
         reducer's autograd hooks stay live during the capture, every collective lands on RCCL's stream behind an event of
         the capture stream, and a replay overlaps the exchange with the rest of backward the way the eager step does.  Needs
         the "nccl" backend; falls back to the exchange after the replay when the capture refuses.  Exercised on one rank
         (tests/test_dist_gpu.py); not yet on a multi-GPU node, hence opt-in.
-        segments (default: env VILCO_DP_SEGMENTS, OFF -- see _DP_SEGMENTS; only with an enabled reducer and without comm_in_graph): the backward is
+        segments (default: env VILCO_DP_SEGMENTS, on; only with an enabled reducer and without comm_in_graph): the backward is
         captured in stages -- graph 1 = forward + heads / losses backward, then one graph per backbone stage, cut at the
         pyramid levels (ops.seg_cut) -- and a replayed iteration launches every gradient bucket as soon as the stage that
         completes it has been enqueued: the all-reduces run on the collective's stream under the remaining stages, no
@@ -189,12 +189,8 @@ class GraphedStep:
             forks = ops._FORKS
             try:
                 ops.seg_tape = tape
-                if staged:
-                    # no forked chains (text side, regression head) in a staged capture: with them the XLNet bias gradients of the
-                    # stage after came out of a replay as zeros (tools/lab/dp_staged_dbg.py: exact without forks, exact with the
-                    # fp32 dS path -- an ordering between the streams of one stage graph and the next that is not understood yet).
-                    # Costs the ~1 ms the forks gain on one GPU; the exchange it lets run under backward is worth several.
-                    ops._FORKS = set()
+                if staged and os.environ.get("VILCO_DP_STAGE_FORKS", "1") == "0":
+                    ops._FORKS = set()           # (debugging aid: a staged capture without the forked text / regression-head chains)
                 with torch.cuda.graph(g, pool=self._pool, **_capture_kw()):
                     if red is not None:
                         red._capture_stream = torch.cuda.current_stream()
@@ -326,7 +322,12 @@ class GraphedStep:
             torch.cuda.current_stream().synchronize()
             red.reduce_launch(len(red.buckets))
         else:
-            hsync = os.environ.get("VILCO_DP_STAGE_SYNC", "1") != "0"      # see _DP_SEGMENTS: required on this runtime
+            mode = os.environ.get("VILCO_DP_STAGE_SYNC", "0")      # see _DP_SEGMENTS: "1" a host wait before every bucket group,
+            hsync = mode == "1"                                    # "step" one per step (on the previous step's end), "0" none (default)
+            if mode == "step":
+                ev = getattr(self, "_step_done", None)
+                if ev is not None:
+                    ev.synchronize()
             for k, gk in enumerate(graphs):
                 gk.replay()
                 if ent['seg_upto'][k] > red._next:
@@ -334,6 +335,9 @@ class GraphedStep:
                         torch.cuda.current_stream().synchronize()
                     red.reduce_launch(ent['seg_upto'][k])
         red.reduce_wait()
+        if os.environ.get("VILCO_DP_STAGE_SYNC", "0") == "step":
+            self._step_done = torch.cuda.Event()
+            self._step_done.record()
 
     def _replay(self, ent, inp):
         static = ent['static']
@@ -341,7 +345,15 @@ class GraphedStep:
             getattr(static, name).copy_(t, non_blocking=True)
         staged = ent.get('seg_graphs') is not None and self.reducer is not None and self.reducer.enabled
         if staged:
-            self._replay_staged(ent, inp)
+            # on a stream of its own, never the default (null) stream: there, with the buckets queued asynchronously between the
+            # stage graphs and the host running ahead, small gradients came back from the exchange stale (see _DP_SEGMENTS)
+            if getattr(self, "_seg_stream", None) is None:
+                self._seg_stream = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self._seg_stream.wait_stream(cur)
+            with torch.cuda.stream(self._seg_stream):
+                self._replay_staged(ent, inp)
+            cur.wait_stream(self._seg_stream)
         else:
             ent['graph'].replay()
             for gk in (ent.get('seg_graphs') or ()):      # captured in stages, the exchange switched off since: plain replays
