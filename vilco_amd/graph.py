@@ -31,6 +31,7 @@ from . import _lib, ops
 
 
 _DP_REPLAY_SYNC = os.environ.get("VILCO_DP_REPLAY_SYNC", "1") != "0"
+_OWN_STREAM = os.environ.get("VILCO_GRAPH_OWN_STREAM", "1") != "0"      # replays leave the default (null) stream: GraphedStep._replay
 # data-parallel replays: the backward captured as one hipGraph per stage (heads + losses, then block by block -- ops.seg_cut),
 # the gradient buckets a stage completes launched right behind its replay, under the stages that follow.  0: one graph, the
 # whole exchange after it.
@@ -40,7 +41,7 @@ _DP_REPLAY_SYNC = os.environ.get("VILCO_DP_REPLAY_SYNC", "1") != "0"
 # identical) -- ON A STREAM OF ITS OWN: replayed on the default (null) stream with the buckets queued asynchronously between
 # the stage graphs, the small gradients (the ones gathered into their bucket by a copy) came back stale or as garbage once the
 # host ran ahead (not RCCL, not the multi-tensor copy, not Python's GC; exact on any created stream).  _replay therefore moves
-# the staged replay to a private stream.  VILCO_DP_STAGE_SYNC=1 adds a host wait before every bucket group (the first
+# every replay off the null stream.  VILCO_DP_STAGE_SYNC=1 adds a host wait before every bucket group (the first
 # workaround; not needed any more).
 _DP_SEGMENTS = os.environ.get("VILCO_DP_SEGMENTS", "1") != "0"
 
@@ -340,20 +341,36 @@ class GraphedStep:
             self._step_done.record()
 
     def _replay(self, ent, inp):
+        """Never on the default (null) stream: graph launches with asynchronous eager work queued between them -- bucket gathers
+        and copy-backs, a `between` penalty adding into the gradients, the learning-rate store -- went wrong there once the host
+        ran ahead of the device (exact on any created stream).  Called with the null stream current, the replay
+        moves to a stream of its own, ordered behind and in front of the caller's by events."""
+        cur = torch.cuda.current_stream()
+        own = cur
+        # (a bare forward + backward replay -- nothing queued between graph launches -- is verified exact on the null stream,
+        # tools/lab/replay_runahead_check.py, and stays there: the two event waits cost ~0.1 ms per step)
+        exposed = (self.optimizer is not None or self.between is not None or
+                   (self.reducer is not None and self.reducer.enabled))
+        if exposed and cur == torch.cuda.default_stream(cur.device) and _OWN_STREAM:
+            if getattr(self, "_own_stream", None) is None:
+                self._own_stream = torch.cuda.Stream(device=cur.device)
+            own = self._own_stream
+            own.wait_stream(cur)
+        with torch.cuda.stream(own):
+            self._replay_body(ent, inp)
+        if own is not cur:
+            cur.wait_stream(own)
+        self.stats['replayed'] += 1
+        out = ent['out'].clone()
+        return {k: out[i] for i, k in enumerate(ent['keys'])}
+
+    def _replay_body(self, ent, inp):
         static = ent['static']
         for name, t in inp.tensors():
             getattr(static, name).copy_(t, non_blocking=True)
         staged = ent.get('seg_graphs') is not None and self.reducer is not None and self.reducer.enabled
         if staged:
-            # on a stream of its own, never the default (null) stream: there, with the buckets queued asynchronously between the
-            # stage graphs and the host running ahead, small gradients came back from the exchange stale (see _DP_SEGMENTS)
-            if getattr(self, "_seg_stream", None) is None:
-                self._seg_stream = torch.cuda.Stream()
-            cur = torch.cuda.current_stream()
-            self._seg_stream.wait_stream(cur)
-            with torch.cuda.stream(self._seg_stream):
-                self._replay_staged(ent, inp)
-            cur.wait_stream(self._seg_stream)
+            self._replay_staged(ent, inp)
         else:
             ent['graph'].replay()
             for gk in (ent.get('seg_graphs') or ()):      # captured in stages, the exchange switched off since: plain replays
@@ -380,6 +397,3 @@ class GraphedStep:
             ent['opt_graph'].replay()
             opt.note_replays(1)
             opt._opt_called = True           # torch's LR schedulers check that optimizer.step() ran before scheduler.step()
-        self.stats['replayed'] += 1
-        out = ent['out'].clone()
-        return {k: out[i] for i, k in enumerate(ent['keys'])}
