@@ -238,6 +238,29 @@ def dryrun_parts(dev, rank):
     return model, fwd_bwd
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N ranks as children of this process (one per GPU, rendezvous on
+    127.0.0.1 at a free port), their stdout / stderr relayed, exit status = theirs.  Runs before any GPU call here."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        rc = proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        rc = proc.wait()
+    sys.exit(rc)
+
+
 def main():
     if os.environ.get("VILCO_BENCH_WATCHDOG"):          # (diagnosis: dump every thread's stack after this many seconds, keep running)
         import faulthandler
@@ -256,6 +279,11 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N` (no launcher): start the N ranks as CHILD processes under torch.distributed.run --
+        # the launch line of MQ/train_cl.sh:2 -- before this process has made any GPU call, relay their output (rank 0 prints
+        # the JSON line) and leave with their status.  Never an exec: a parent that had touched the GPU must not be replaced.
+        return self_launch(args.gpus)
 
     dry = os.environ.get("VILCO_BENCH_DRYRUN", "0") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))

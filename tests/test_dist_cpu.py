@@ -155,6 +155,24 @@ def test_bench_protocol_two_ranks():
     assert mg["ms_per_step_without_exchange"] > 0 and mg["exchange_ms_sum_of_buckets_alone"] > 0
 
 
+def test_bench_bare_gpus_form_self_launches():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE: bench.py starts its two ranks as child processes
+    itself (before any GPU call), relays rank 0's single JSON line and leaves with the children's status."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VILCO_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
+
+
 class _FakeDetector(torch.nn.Module):
     """stands in for the model in the evaluator-format plumbing: deterministic segments per video id"""
     use_adapt = False
