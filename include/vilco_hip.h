@@ -586,6 +586,16 @@ int vilco_softnms_1d(const float* segs, const float* scores, const int64_t* seg_
                      int64_t n_total, float iou_threshold, float sigma, float min_score,
                      int32_t method, int64_t max_num, float* dets, int64_t* out_idx,
                      int64_t* out_cnt, void* workspace, size_t workspace_bytes, void* stream);
+/* Which device kernel a class of a vilco_softnms_1d call runs on is chosen per class from its size:
+ *   kind 0  register-resident kernel (method 2 = Gaussian, nms_cpu.cpp:131-136; n <= 30 720)
+ *   kind 1  row-strided kernel       (methods 0 / 1 / 2, nms_cpu.cpp:122-137;   n <= 65 536)
+ *   kind 2  one-pass-per-pick kernel (any method, any n)
+ * vilco_nms_set_kernel(-1) (the default) = the lowest kind that can take the class; kind k >= 0 = no kernel below kind k
+ * (tests run every kernel on the same inputs this way).  Returns the previous setting.  All kernels produce the
+ * reference's indices and scores bit for bit.  vilco_nms_last_kernels(): bit k set = the last vilco_softnms_1d call
+ * launched kind k (host-side bookkeeping of the calling thread's last call; not synchronised). */
+int vilco_nms_set_kernel(int32_t kind);
+int vilco_nms_last_kernels(void);
 
 #ifdef __cplusplus
 }

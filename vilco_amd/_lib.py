@@ -173,6 +173,8 @@ SIGNATURES = {
     "vilco_nms_1d": (C.c_int, [c_fp, c_fp, c_fp, i32, i64, f32, c_fp, c_fp, c_fp, sz, c_fp]),
     "vilco_softnms_1d": (C.c_int, [c_fp, c_fp, c_fp, i32, i64, f32, f32, f32, i32, i64, c_fp, c_fp, c_fp,
                                    c_fp, sz, c_fp]),
+    "vilco_nms_set_kernel": (C.c_int, [i32]),
+    "vilco_nms_last_kernels": (C.c_int, []),
 }
 
 _lib = None

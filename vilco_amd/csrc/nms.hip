@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NT) void softnms_kernel(const float* __restrict__ s
                                                      long max_num, float* __restrict__ dets,
                                                      long* __restrict__ out_idx,
                                                      long* __restrict__ out_cnt, void* ws_raw,
-                                                     long n_total) {
+                                                     long n_total, int n_lo, int n_hi) {
   __shared__ int s_scan[NW + 1];
   __shared__ float s_val[NW];
   __shared__ int s_pos[NW];
@@ -307,6 +307,7 @@ __global__ __launch_bounds__(NT) void softnms_kernel(const float* __restrict__ s
     if (threadIdx.x == 0) out_cnt[cls] = 0;
     return;
   }
+  if (n <= n_lo || n > n_hi) return;                // (another soft kernel of this call owns the class)
   Ws w = carve(ws_raw, n_total, off);
   const float* sg = segs + off * 2;
   for (int i = threadIdx.x; i < n; i += NT) {
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(NT) void softnms_rows_kernel(const float* __restric
                                                           long max_num, float* __restrict__ dets,
                                                           long* __restrict__ out_idx,
                                                           long* __restrict__ out_cnt, void* ws_raw,
-                                                          long n_total) {
+                                                          long n_total, int n_lo, int n_hi) {
   __shared__ int s_cnt[SROWS * NW + 1];
   __shared__ float s_val[NW];
   __shared__ int s_pos[NW];
@@ -438,6 +439,7 @@ __global__ __launch_bounds__(NT) void softnms_rows_kernel(const float* __restric
     if (threadIdx.x == 0) out_cnt[cls] = 0;
     return;
   }
+  if (n <= n_lo || n > n_hi) return;                // (another soft kernel of this call owns the class)
   Ws w = carve(ws_raw, n_total, off);
   float* __restrict__ X1 = w.x1; float* __restrict__ X2 = w.x2; float* __restrict__ SC = w.sc; float* __restrict__ AR = w.ar;
   int* __restrict__ IND = w.ind; int* __restrict__ TMP = w.tmp;
@@ -669,7 +671,7 @@ __device__ unsigned long long vilco_lab_nms_stamps[32 * 8];
 __global__ __launch_bounds__(NTR) void softnms_reg_kernel(const long* __restrict__ seg_off, float thr, float sigma, float min_score,
                                                          int method, long max_num, float* __restrict__ dets,
                                                          long* __restrict__ out_idx, long* __restrict__ out_cnt, void* ws_raw,
-                                                         long n_total) {
+                                                         long n_total, int n_hi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char reg_lds_raw[];
   RegLds& L = *reinterpret_cast<RegLds*>(reg_lds_raw);
   const int cls = blockIdx.x;
@@ -679,6 +681,7 @@ __global__ __launch_bounds__(NTR) void softnms_reg_kernel(const long* __restrict
     if (threadIdx.x == 0) out_cnt[cls] = 0;
     return;
   }
+  if (n > n_hi) return;                             // (a class beyond the register file: softnms_rows_kernel / softnms_kernel own it)
   Ws w = carve(ws_raw, n_total, off);               // x1 / x2 / sc / ind in ascending-start order (nms_rank_kernel<true>)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rmax = (n + NTR - 1) / NTR;             // slots in use (uniform)
@@ -831,9 +834,11 @@ __global__ __launch_bounds__(NTR) void softnms_reg_kernel(const long* __restrict
           run += __popc(b);
         }
         if (lane == 63) L.s_nalive = inc;
-        if (lane == 0) L.s_flag = 0;
       }
-      lds_barrier();                                                      // #4
+      lds_barrier();                                                      // #4b
+      // (reset only now: every wave has read the flag -- it read it before it arrived at #4b -- and the next pick's deaths
+      // are three barriers away.  Resetting inside the block above raced with a late wave's read of it: ADVICE r5)
+      if (tid == 0) L.s_flag = 0;
       const int n_alive = L.s_nalive;
       const int new_n = first + n_alive;
       // alive positions in [first, p)
@@ -890,10 +895,28 @@ extern "C" int vilco_lab_nms_read(unsigned long long* out) {
 }
 #endif
 
-static bool soft_legacy() {
-  static const bool v = [] { const char* e = getenv("VILCO_SOFTNMS_LEGACY"); return e && e[0] == '1'; }();
-  return v;
+// Which soft-NMS kernel takes a class is decided PER CLASS on the device (the host knows the total only): every launched kernel
+// covers a range of class sizes (n_lo, n_hi] and its workgroups leave at once for classes outside it.
+//   kind 0  softnms_reg_kernel   Gaussian decay (method 2), n <= REG_MAXN
+//   kind 1  softnms_rows_kernel  any method, n <= SROWS * NT
+//   kind 2  softnms_kernel       any method, any n
+// vilco_nms_set_kernel(-1) = automatic (the fastest kernel that can take the class); k >= 0 = nothing faster than kind k.
+static int g_soft_kind = [] {
+  const char* l = getenv("VILCO_SOFTNMS_LEGACY");
+  if (l && l[0] == '1') return 2;
+  const char* r = getenv("VILCO_SOFTNMS_REG");
+  if (r && atoi(r) == 0) return 1;
+  return -1;
+}();
+static int g_soft_last = 0;
+
+extern "C" int vilco_nms_set_kernel(int32_t kind) {
+  const int prev = g_soft_kind;
+  if (kind >= -1 && kind <= 2) g_soft_kind = kind;
+  return prev;
 }
+
+extern "C" int vilco_nms_last_kernels(void) { return g_soft_last; }
 
 extern "C" size_t vilco_nms_workspace(int64_t n_total, int32_t nseg) {
   // 7 words per candidate (x1, x2, score, area, index, keep list / scratch, dead flag) + one counter per class
@@ -940,12 +963,14 @@ extern "C" int vilco_softnms_1d(const float* segs, const float* scores, const in
   if (nseg == 0) return VILCO_OK;
   if (!segs || !scores || !dets || !out_idx || !workspace) return VILCO_ERR_BADARG;
   if (n_total < 0 || workspace_bytes < vilco_nms_workspace(n_total, nseg)) return VILCO_ERR_WORKSPACE;
-  // (the host knows the total only: every class fits a kernel's limit when the total does)
-  static const int soft_reg = [] { const char* e = getenv("VILCO_SOFTNMS_REG"); return e ? atoi(e) : 1; }();
-  if (soft_reg && method == 2 && n_total <= (int64_t)REG_MAXN && !soft_legacy()) {
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const long* so = reinterpret_cast<const long*>(seg_off);
-    long* oc = reinterpret_cast<long*>(out_cnt);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long* so = reinterpret_cast<const long*>(seg_off);
+  long* oc = reinterpret_cast<long*>(out_cnt);
+  long* oi = reinterpret_cast<long*>(out_idx);
+  const int first = g_soft_kind < 0 ? 0 : g_soft_kind;
+  const long cap = n_total < 0x7fffffffL ? n_total : 0x7fffffffL;      // no class is longer than the total
+  int lo = 0, used = 0;                                                   // classes of size <= lo are taken
+  if (first <= 0 && method == 2) {
     const size_t per = (size_t)(n_total > 0 ? n_total : 1) * 7 * sizeof(float);
     long* kbase = reinterpret_cast<long*>((reinterpret_cast<uintptr_t>(workspace) + per + 255) / 256 * 256);
     const int rblocks = (int)((n_total + 255) / 256);
@@ -959,16 +984,21 @@ extern "C" int vilco_softnms_1d(const float* segs, const float* scores, const in
     }();
     (void)once;
     hipLaunchKernelGGL(softnms_reg_kernel, dim3(nseg), dim3(NTR), sizeof(RegLds), s, so, iou_threshold, sigma, min_score, method,
-                       (long)max_num, dets, reinterpret_cast<long*>(out_idx), oc, workspace, (long)n_total);
-  } else if (n_total <= (int64_t)SROWS * NT && !soft_legacy())
-    hipLaunchKernelGGL(softnms_rows_kernel, dim3(nseg), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), segs,
-                       scores, reinterpret_cast<const long*>(seg_off), iou_threshold, sigma, min_score, method,
-                       (long)max_num, dets, reinterpret_cast<long*>(out_idx), reinterpret_cast<long*>(out_cnt),
-                       workspace, (long)n_total);
-  else
-    hipLaunchKernelGGL(softnms_kernel, dim3(nseg), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), segs,
-                       scores, reinterpret_cast<const long*>(seg_off), iou_threshold, sigma, min_score, method,
-                       (long)max_num, dets, reinterpret_cast<long*>(out_idx), reinterpret_cast<long*>(out_cnt),
-                       workspace, (long)n_total);
+                       (long)max_num, dets, oi, oc, workspace, (long)n_total, (int)REG_MAXN);
+    lo = REG_MAXN;
+    used |= 1;
+  }
+  if (first <= 1 && (cap > lo || !used)) {
+    hipLaunchKernelGGL(softnms_rows_kernel, dim3(nseg), dim3(NT), 0, s, segs, scores, so, iou_threshold, sigma, min_score, method,
+                       (long)max_num, dets, oi, oc, workspace, (long)n_total, lo, SROWS * NT);
+    lo = SROWS * NT;
+    used |= 2;
+  }
+  if (cap > lo || !used) {
+    hipLaunchKernelGGL(softnms_kernel, dim3(nseg), dim3(NT), 0, s, segs, scores, so, iou_threshold, sigma, min_score, method,
+                       (long)max_num, dets, oi, oc, workspace, (long)n_total, lo, 0x7fffffff);
+    used |= 4;
+  }
+  g_soft_last = used;
   return vilco_launch_status();
 }

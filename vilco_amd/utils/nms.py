@@ -55,6 +55,32 @@ def _run_soft(segs, scores, seg_off, nseg, iou_threshold, sigma, min_score, meth
     return dets, out_idx, out_cnt
 
 
+SOFT_KERNELS = {"auto": -1, "reg": 0, "rows": 1, "legacy": 2}
+
+
+class soft_kernel:
+    """`with soft_kernel("rows"): ...` -- no soft-NMS device kernel faster than the named one inside the block
+    (vilco_nms_set_kernel; include/vilco_hip.h).  Every kernel returns the reference's indices bit for bit; the switch
+    exists so that tests and measurements can run each of them on the same inputs."""
+
+    def __init__(self, kind):
+        self.kind = SOFT_KERNELS[kind] if isinstance(kind, str) else int(kind)
+
+    def __enter__(self):
+        self.prev = _lib.load().vilco_nms_set_kernel(self.kind)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().vilco_nms_set_kernel(self.prev)
+        return False
+
+
+def last_soft_kernels():
+    """names of the device kernels the last soft-NMS call launched"""
+    m = _lib.load().vilco_nms_last_kernels()
+    return {k for k, v in SOFT_KERNELS.items() if v >= 0 and (m >> v) & 1}
+
+
 class _Nms1dModule:
     """stand-in for the compiled python module `nms_1d_cpu`"""
 
