@@ -151,6 +151,9 @@ int vilco_gemm_set_gl(int32_t on);
 /* of 192-row tiles over its first rows + one round of 128-row tiles over the rest (same arithmetic per tile, disjoint rows).   */
 /* 0 (default: measured, no gain in the step) / 1; env VILCO_GEMM_TAIL128.                                                     */
 int vilco_gemm_set_tail128(int32_t on);
+/* Generation of the process-wide GEMM configuration: bumped by vilco_gemm_force / _set_fixup / _set_gl / _set_tail128.  The host
+ * side keys captured hipGraphs on it (a replay runs the plan that was recorded, not the current configuration). */
+int64_t vilco_gemm_config_gen(void);
 /* floats written to desc->amax_out by vilco_gemm(desc) (depends on the tile / split-K plan); 0: not available */
 int32_t vilco_gemm_amax_parts(const vilco_gemm_desc* desc);
 int vilco_gemm_profile_begin(void);

@@ -50,6 +50,39 @@ class DropReplay:
         return {k: len(v) for k, v in self.q.items() if v}
 
 
+# ---- sign decisions of the LayerNorm -> ReLU sites handed in from outside (tests/test_fullsize_gpu.py).  A pre-activation within
+# rounding of zero takes one side or the other depending on the arithmetic; an implementation that is not bit-identical to this
+# restatement can land on the other side of such an element, after which every gradient upstream differs by a discrete amount.
+# RELU = ReluReplay(masks) makes this run take the SAME side as the run that produced `masks` (y = x * mask: the output differs
+# from relu(x) by the size of the near-zero pre-activation, the derivative is the other run's) and records where the sides
+# differed and how far from zero those pre-activations were.  None: plain torch.relu.
+RELU = None
+
+
+class ReluReplay:
+    def __init__(self, masks):
+        """masks: {site: bool tensor in this oracle's layout [B, C, T]} -- sites without an entry take their own side"""
+        self.masks = dict(masks)
+        self.events = []          # (site, elements that changed side, max |pre-activation| among them / max |pre-activation|)
+        self.seen = set()
+
+    def __call__(self, site, x):
+        m = self.masks.get(site)
+        if m is None:
+            return torch.relu(x)
+        assert tuple(m.shape) == tuple(x.shape), (site, tuple(m.shape), tuple(x.shape))
+        self.seen.add(site)
+        diff = (x.detach() > 0) != m
+        n = int(diff.sum())
+        if n:
+            self.events.append((site, n, float(x.detach().abs()[diff].max() / x.detach().abs().max().clamp_min(1e-30))))
+        return x * m.to(x.dtype)
+
+
+def _relu(site, x):
+    return torch.relu(x) if RELU is None else RELU(site, x)
+
+
 class DropRandom:
     def __init__(self, dropout=0.1, droppath=0.1, xl=0.1, seed=0):
         self.p = {'droppath': droppath, 'proj_drop': dropout, 'mlp_drop': dropout, 'xl': xl}
@@ -279,7 +312,7 @@ def backbone(p, cfg, x, mask, text=None, text_mask=None, training=True, adapter_
         x, mask = masked_conv1d(x, mask, p[pre + 'embd.%d.conv.weight' % i], p.get(pre + 'embd.%d.conv.bias' % i))
         if m['embd_with_ln']:
             x = ln(p, pre + 'embd_norm.%d.' % i, x)
-        x = torch.relu(x)
+        x = _relu(pre + 'embd_norm.%d' % i, x)
     if m['use_abs_pe']:
         pe = sinusoid_pe(m['max_seq_len'], m['embd_dim'], x.dtype)
         if (not training) and T >= m['max_seq_len']:
@@ -292,7 +325,7 @@ def backbone(p, cfg, x, mask, text=None, text_mask=None, training=True, adapter_
             q, qm = masked_conv1d(q, qm, p[pre + 'txt_embd.%d.conv.weight' % i], p.get(pre + 'txt_embd.%d.conv.bias' % i))
             if m['embd_with_ln']:
                 q = ln(p, pre + 'txt_embd_norm.%d.' % i, q)
-            q = torch.relu(q)
+            q = _relu(pre + 'txt_embd_norm.%d' % i, q)
         for i in range(arch[1]):
             q, qm = transformer_block(p, pre + 'txt_stem.%d.' % i, q, qm, n_head, 1, 0.8)
         q_mask = qm.squeeze(1).long()
@@ -327,12 +360,12 @@ def neck(p, cfg, feats, masks):
     return feats, masks
 
 
-def head_trunk(p, pre, cfg, x, mask):
+def head_trunk(p, pre, cfg, x, mask, level=0):
     for i in range(cfg['head_num_layers'] - 1):
         x, _ = masked_conv1d(x, mask, p[pre + 'head.%d.conv.weight' % i], p.get(pre + 'head.%d.conv.bias' % i))
         if cfg['head_with_ln']:
             x = ln(p, pre + 'norm.%d.' % i, x)
-        x = torch.relu(x)
+        x = _relu(pre + 'norm.%d@%d' % (i, level), x)
     return x
 
 
@@ -340,9 +373,9 @@ def heads(p, cfg, feats, masks):
     """PtTransformerClsHead / RegHead forward (meta_archs.py:259-275, 334-349) + the permutes of :848-852."""
     cls, reg = [], []
     for l, (f, m) in enumerate(zip(feats, masks)):
-        c, _ = masked_conv1d(head_trunk(p, 'cls_head.', cfg, f, m), m, p['cls_head.cls_head.conv.weight'],
+        c, _ = masked_conv1d(head_trunk(p, 'cls_head.', cfg, f, m, l), m, p['cls_head.cls_head.conv.weight'],
                              p['cls_head.cls_head.conv.bias'])
-        r, _ = masked_conv1d(head_trunk(p, 'reg_head.', cfg, f, m), m, p['reg_head.offset_head.conv.weight'],
+        r, _ = masked_conv1d(head_trunk(p, 'reg_head.', cfg, f, m, l), m, p['reg_head.offset_head.conv.weight'],
                              p['reg_head.offset_head.conv.bias'])
         cls.append(c.permute(0, 2, 1))
         reg.append(F.relu(r * p['reg_head.scale.%d.scale' % l]).permute(0, 2, 1))

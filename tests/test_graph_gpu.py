@@ -273,3 +273,56 @@ def test_a_replayed_step_never_stalls_the_host(dev, seed_word_zero):
         torch.cuda.set_sync_debug_mode(old)
     assert inp.lens.device.type == 'cuda' and inp.gt is not None
     assert torch.isfinite(out['final_loss']).item()
+
+
+def test_deep_run_ahead_replays_equal_the_synchronised_run(dev, seed_word_zero):
+    """240 replays over rotating batches with the host running as far ahead as the queue allows (no
+    synchronisation at all, small eager copies queued between the graph launches) against the same run synchronised after
+    every step: every step's losses bit for bit, and every step's SMALL gradients (biases, scales, the loss's mu / sigma --
+    the tensors the round-5 null-stream hazard returned stale) equal -- bit for bit except the handful the
+    loss kernel accumulates with float atomics (order-dependent in the last bit).  Replays run on GraphedStep's own stream."""
+    from vilco_amd.graph import GraphedStep
+    gold = load_golden("xl")
+    base = golden_inputs(gold)
+    batches = []
+    for r in range(3):
+        g = torch.Generator().manual_seed(100 + r)
+        batches.append([dict(x, feats=(x['feats'] + 0.05 * r * torch.randn(x['feats'].shape, generator=g)).to(dev),
+                             **({'prompt_feature': x['prompt_feature'].to(dev)} if 'prompt_feature' in x else {}))
+                        for x in base])
+    runs = []
+    for sync in (False, True):
+        model = build_hip_model(gold, dev).train()
+        for m in model.modules():                      # deterministic steps: the comparison is about ordering, not masks
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if hasattr(m, "drop_prob"):
+                m.drop_prob = 0.0
+        model.loss_normalizer = 100.0
+        small = [(n, p) for n, p in model.named_parameters() if p.numel() <= 4096]
+        gs = GraphedStep(model, None, eager_steps=1)
+        for i in range(3):
+            gs(batches[i % 3], task_id=gold['task_id'])
+        torch.cuda.synchronize()
+        losses, grads = [], []
+        for i in range(240):
+            out = gs(batches[(2 * i + 1) % 3], task_id=gold['task_id'])
+            losses.append(out['final_loss'])
+            if i % 8 == 0:                             # eager copy kernels between graph launches
+                grads.append([p.grad.detach().clone() for _, p in small if p.grad is not None])
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        assert gs.stats['replayed'] >= 240 and getattr(gs, "_own_stream", None) is not None
+        runs.append((torch.stack(losses).cpu(), [[t.cpu() for t in g] for g in grads],
+                     [n for n, p in small if p.grad is not None]))
+    (la, ga, names), (lb, gb, _) = runs
+    assert len(set(la.tolist())) >= 3                  # the rotating batches really differ
+    assert torch.equal(la, lb)
+    atomics = ("mu", "sigma", "scale")                 # loss.hip: dgauss / dscale accumulate with atomicAdd
+    for step, (a, b) in enumerate(zip(ga, gb)):
+        for n, x, y in zip(names, a, b):
+            if any(k in n for k in atomics):
+                assert torch.allclose(x, y, rtol=1e-5, atol=1e-9), (step, n)
+            else:
+                assert torch.equal(x, y), (step, n)

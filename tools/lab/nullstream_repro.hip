@@ -1,0 +1,83 @@
+// Round 6: is "graph launch -> small eager kernel -> graph launch" ordered on the NULL stream when the host
+// runs far ahead of the device?  Plain HIP, no torch, no RCCL.  The captured graph forks a side branch the way the captured
+// training step does (ops.fork_enabled); a device counter is bumped by every launch and both branches write it into a small
+// buffer after spinning; the eager copy behind the launch must read the value of THAT launch.
+//   build: hipcc --offload-arch=gfx950 -O2 -o nullstream_repro nullstream_repro.hip
+//   run:   ./nullstream_repro <stream: 0 null | 1 created | 2 created non-blocking> <pattern 0..3> [iters] [spin cycles]
+// patterns: 0 copy kernels on the launch stream; 1 hipMemcpyAsync D2D on the launch stream; 2 the copies on a SECOND stream ordered
+// by events both ways (what a collective's stream does); 3 as 0 with two graphs (stages) per iteration and a copy after each.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+
+__global__ void bump(unsigned* ctr) { if (threadIdx.x == 0) *ctr = *ctr + 1u; }
+__global__ void spin_write(float* g, const unsigned* ctr, int n, long spin) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while ((long)(__builtin_amdgcn_s_memtime() - t0) < spin) { }
+  if ((int)threadIdx.x < n) g[threadIdx.x] = (float)(*ctr);
+}
+__global__ void copy_k(const float* __restrict__ s, float* __restrict__ d, int n) { if ((int)threadIdx.x < n) d[threadIdx.x] = s[threadIdx.x]; }
+
+int main(int argc, char** argv) {
+  const int smode = argc > 1 ? atoi(argv[1]) : 0, pat = argc > 2 ? atoi(argv[2]) : 0;
+  const int iters = argc > 3 ? atoi(argv[3]) : 3000;
+  const long spin = argc > 4 ? atol(argv[4]) : 20000;       // 100 MHz counter: 20000 = 200 us per branch
+  const int n = 64;
+  unsigned* ctr; float *gA, *gB, *gC, *out;
+  CK(hipMalloc(&ctr, 4)); CK(hipMemset(ctr, 0, 4));
+  CK(hipMalloc(&gA, n * 4)); CK(hipMalloc(&gB, n * 4)); CK(hipMalloc(&gC, n * 4));
+  CK(hipMalloc(&out, (size_t)iters * 3 * n * 4)); CK(hipMemset(out, 0, (size_t)iters * 3 * n * 4));
+  hipStream_t cap, side, S = nullptr, C2;
+  CK(hipStreamCreate(&cap)); CK(hipStreamCreate(&side)); CK(hipStreamCreate(&C2));
+  if (smode == 1) CK(hipStreamCreate(&S));
+  if (smode == 2) CK(hipStreamCreateWithFlags(&S, hipStreamNonBlocking));
+  hipEvent_t f, j, e1, e2;
+  CK(hipEventCreateWithFlags(&f, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&j, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&e1, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+  // graph 1: bump -> { main: spin_write(gA) ; side: spin_write(gB), shorter } -> join.   graph 2 (pattern 3): spin_write(gC)
+  hipGraph_t g1, g2; hipGraphExec_t x1, x2;
+  CK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+  hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, cap, ctr);
+  CK(hipEventRecord(f, cap)); CK(hipStreamWaitEvent(side, f, 0));
+  hipLaunchKernelGGL(spin_write, dim3(1), dim3(64), 0, side, gB, ctr, n, spin / 2);
+  hipLaunchKernelGGL(spin_write, dim3(1), dim3(64), 0, cap, gA, ctr, n, spin);
+  CK(hipEventRecord(j, side)); CK(hipStreamWaitEvent(cap, j, 0));
+  CK(hipStreamEndCapture(cap, &g1)); CK(hipGraphInstantiate(&x1, g1, nullptr, nullptr, 0));
+  CK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+  hipLaunchKernelGGL(spin_write, dim3(1), dim3(64), 0, cap, gC, ctr, n, spin / 4);
+  CK(hipStreamEndCapture(cap, &g2)); CK(hipGraphInstantiate(&x2, g2, nullptr, nullptr, 0));
+  for (int it = 0; it < iters; ++it) {                       // no host wait anywhere in here
+    float* o = out + (size_t)it * 3 * n;
+    CK(hipGraphLaunch(x1, S));
+    if (pat == 0 || pat == 3) {
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, o, n);
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gB, o + n, n);
+    } else if (pat == 1) {
+      CK(hipMemcpyAsync(o, gA, n * 4, hipMemcpyDeviceToDevice, S));
+      CK(hipMemcpyAsync(o + n, gB, n * 4, hipMemcpyDeviceToDevice, S));
+    } else {
+      CK(hipEventRecord(e1, S)); CK(hipStreamWaitEvent(C2, e1, 0));
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, C2, gA, o, n);
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, C2, gB, o + n, n);
+      CK(hipEventRecord(e2, C2)); CK(hipStreamWaitEvent(S, e2, 0));
+    }
+    if (pat == 3) {
+      CK(hipGraphLaunch(x2, S));
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gC, o + 2 * n, n);
+    }
+  }
+  CK(hipDeviceSynchronize());
+  std::vector<float> h((size_t)iters * 3 * n);
+  CK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
+  long bad = 0; int first = -1;
+  for (int it = 0; it < iters; ++it)
+    for (int b = 0; b < (pat == 3 ? 3 : 2); ++b)
+      for (int k = 0; k < n; ++k)
+        if (h[((size_t)it * 3 + b) * n + k] != (float)(it + 1)) { ++bad; if (first < 0) first = it; }
+  int ver = 0; CK(hipRuntimeGetVersion(&ver));
+  printf("stream %s pattern %d iters %d spin %ld: %ld wrong values%s (first at iteration %d)  [HIP runtime %d]\n",
+         smode == 0 ? "NULL" : (smode == 1 ? "created" : "created-nonblocking"), pat, iters, spin, bad, bad ? "  <-- ORDER VIOLATED" : "", first, ver);
+  return bad ? 1 : 0;
+}

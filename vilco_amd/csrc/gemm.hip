@@ -1855,23 +1855,32 @@ extern "C" int vilco_gemm_group(const vilco_gemm_desc* descs, int32_t n, void* s
 // give the initial values.
 // split-K finish: 1 = inside the launch (tile counters), 0 = partial slabs + splitk_reduce_kernel (default; see
 // fixup_enabled()).  Both sum the splits in the same order: the results are bitwise equal (tests/test_ops_gpu.py).
+// every setter below bumps this generation: a captured hipGraph replays the plan it recorded, so vilco_amd/graph.py keys its
+// graphs on the value (a vilco_gemm_set_* call between replays used to replay the old kernels silently)
+static int64_t g_config_gen = 0;
+extern "C" int64_t vilco_gemm_config_gen(void) { return g_config_gen; }
+
 extern "C" int vilco_gemm_set_fixup(int32_t on) {
   fixup_enabled() = on != 0;
+  ++g_config_gen;
   return VILCO_OK;
 }
 
 extern "C" int vilco_gemm_set_gl(int32_t on) {
   gl_enabled() = on != 0;
+  ++g_config_gen;
   return VILCO_OK;
 }
 
 extern "C" int vilco_gemm_set_tail128(int32_t on) {
   tail128_enabled() = on != 0;
+  ++g_config_gen;
   return VILCO_OK;
 }
 
 extern "C" int vilco_gemm_force(int32_t bm, int32_t ks) {
   if (bm < 0 || ks < 0) return VILCO_ERR_BADARG;
   tune().bm = bm; tune().ks = ks;
+  ++g_config_gen;
   return VILCO_OK;
 }

@@ -173,6 +173,10 @@ class GraphedStep:
         blocks.reset_drop_pool()
         gc.collect()
         torch.cuda.synchronize()
+        if ops.range_check in ("warn", "auto"):
+            import warnings
+            warnings.warn("GraphedStep: VILCO_RANGE_CHECK=%s is a debug mode of the EAGER step (it reads gradients on the host); a "
+                          "captured step skips the check and runs every backward product in the default format" % ops.range_check)
         red = self.reducer if (self.reducer is not None and self.reducer.enabled) else None
         # at most two attempts: with the collectives inside the capture, then (this runtime refused) without them
         while True:
@@ -188,6 +192,7 @@ class GraphedStep:
             tape = ops.SegTape() if staged else None
             seg_graphs, seg_done = [], []
             forks = ops._FORKS
+            pins = ops._capture_pins = []    # persistent buffers the recorded kernels address: they live as long as the graph
             try:
                 ops.seg_tape = tape
                 if staged and os.environ.get("VILCO_DP_STAGE_FORKS", "1") == "0":
@@ -223,6 +228,7 @@ class GraphedStep:
                 failed = e
             finally:
                 ops.seg_tape = None
+                ops._capture_pins = None
                 ops._FORKS = forks
                 if self.reducer is not None:
                     self.reducer._capture_stream = None
@@ -236,6 +242,7 @@ class GraphedStep:
             for p in self.params:
                 p.grad = None
         ent['comm'] = comm
+        ent['pins'] = pins
         ent['seg_graphs'] = seg_graphs if staged else None
         ent['seg_marks'] = seg_done if staged else None
         del losses, tape                 # the cut leaves' .grad buffers stay where the stage graphs read and write them (pool)
@@ -347,11 +354,9 @@ class GraphedStep:
         moves to a stream of its own, ordered behind and in front of the caller's by events."""
         cur = torch.cuda.current_stream()
         own = cur
-        # (a bare forward + backward replay -- nothing queued between graph launches -- is verified exact on the null stream,
-        # tools/lab/replay_runahead_check.py, and stays there: the two event waits cost ~0.1 ms per step)
-        exposed = (self.optimizer is not None or self.between is not None or
-                   (self.reducer is not None and self.reducer.enabled))
-        if exposed and cur == torch.cuda.default_stream(cur.device) and _OWN_STREAM:
+        # (round 6: the bare forward + backward replay leaves the null stream too -- it was verified exact there, but a created
+        # stream is also 0.1-0.2 ms per step faster, tools/lab/stream_ab.py, and no replay depends on null-stream ordering)
+        if cur == torch.cuda.default_stream(cur.device) and _OWN_STREAM:
             if getattr(self, "_own_stream", None) is None:
                 self._own_stream = torch.cuda.Stream(device=cur.device)
             own = self._own_stream

@@ -150,7 +150,7 @@ class LayerNorm(nn.Module):
         """planes: "nat" / "seq" when the output goes straight into a Linear / a k=3 conv; row_mask: see ops.layernorm;
         skip: -> (y, x_skip), x_skip = x for the residual connection around the branch y feeds (ops.layernorm)"""
         assert x.shape[-1] == self.num_channels
-        return ops.layernorm(x, self.weight, self.bias, self.eps, relu, planes, row_mask, skip)
+        return ops.layernorm(x, self.weight, self.bias, self.eps, relu, planes, row_mask, skip, site=getattr(self, '_site', None))
 
     def forward(self, x):
         assert x.dim() == 3 and x.shape[1] == self.num_channels

@@ -55,7 +55,11 @@ def arithmetic_key():
     weak 2: flipping set_precision / dw_precision between replays used to replay the old arithmetic silently)."""
     return (int(_precision), -1 if dw_precision is None else int(dw_precision), int(DW_FAST_MIN_K), bool(producer_planes),
             bool(ln_planes), bool(attn_planes), bool(produce_amax), bool(conv_tap_planes), bool(defer_finish), bool(use_qkv_pre),
-            tuple(sorted(_FORKS)))
+            tuple(sorted(_FORKS)),
+            # (ADVICE r05) the remaining switches that change which kernels / roundings a step records, and the library's own
+            # configuration generation (vilco_gemm_force / _set_gl / _set_fixup / _set_tail128)
+            bool(fold_skip_grads), bool(xl_ds_planes), bool(xl_scores_kernel), bool(linear_group_enabled), bool(use_flash),
+            bool(_reuse_packs), bool(_weight_cache), str(range_check), int(_lib.load().vilco_gemm_config_gen()))
 
 
 def get_precision():
@@ -207,7 +211,10 @@ def _defer_flush(final=True):
             cur = torch.cuda.current_stream()
             for (name, dev), side in _side_streams.items():
                 if dev == cur.device_index and side != cur:
-                    cur.wait_stream(side)
+                    with torch.cuda.stream(side):       # only streams THIS capture forked into (a stage graph forks none):
+                        live = torch.cuda.is_current_stream_capturing()      # an event from outside a capture cannot be
+                    if live:                                                 # waited for inside it (join_side_streams)
+                        cur.wait_stream(side)
         _lib.check(_lib.load().vilco_defer_flush(_stream()))
     else:
         _lib.load().vilco_defer_set(0)
@@ -1079,7 +1086,12 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg.view_as(gamma), db.view_as(gamma), None, None, None, None, None
 
 
-def layernorm(x, gamma, beta, eps=1e-5, relu=False, planes=None, row_mask=None, skip=False):
+# parity tooling (tests/test_fullsize_gpu.py): a list -> every LayerNorm -> ReLU call appends (site, y > 0), the derivative mask the
+# backward kernel will use, so that an oracle run can be handed exactly the sign decisions this step took
+relu_log = None
+
+
+def layernorm(x, gamma, beta, eps=1e-5, relu=False, planes=None, row_mask=None, skip=False, site=None):
     """gamma/beta may have the reference's [1,C,1] shape (blocks.py:152-155) or [C].
     skip: return (y, x_skip) -- x_skip is x as an output of this op; use it for the residual connection around the branch
     that y feeds, and the backward kernel adds the skip gradient to dx itself (see _LayerNorm.forward).
@@ -1091,6 +1103,8 @@ def layernorm(x, gamma, beta, eps=1e-5, relu=False, planes=None, row_mask=None, 
     xs = x
     if isinstance(y, tuple):
         y, xs = y
+    if relu and relu_log is not None:
+        relu_log.append((site, y.detach() > 0))
     parts, n = _LayerNorm.last_amax
     _LayerNorm.last_amax = (None, 0)
     made, _LayerNorm.last_planes = _LayerNorm.last_planes, None
@@ -1440,16 +1454,25 @@ xl_scores_kernel = os.environ.get("VILCO_XL_SCORES", "1") != "0"
 _ds_plane_bufs = {}
 
 
+_capture_pins = None       # while graph.GraphedStep captures: the persistent buffers the recorded kernels address by raw pointer
+
+
 def _xl_ds_planes_buf(B, H, T, device):
+    """The persistent, zero-outside-the-band plane buffer of XLNet's dS (~1.4 GB at config P), one per (device, B, H, T).  At
+    most two stay cached; an evicted one is only DROPPED from this table -- a captured hipGraph that recorded its address holds
+    its own reference (`_capture_pins`, kept in the graph's entry by GraphedStep), so the memory stays the graph's until the
+    graph goes (a third shape used to free a buffer a live graph still wrote through)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), B, H, T)
     buf = _ds_plane_bufs.get(key)
     if buf is None:
         if torch.cuda.is_current_stream_capturing():
             return None                                      # never allocate-and-zero inside a capture: fall back for this call
         if len(_ds_plane_bufs) >= 2:
-            _ds_plane_bufs.clear()                           # shapes that keep changing: keep at most two buffers alive
+            _ds_plane_bufs.clear()                           # shapes that keep changing: keep at most two buffers cached
         buf = torch.zeros(int(_lib.load().vilco_attn_dsplanes_bytes(B, H, T)), dtype=torch.uint8, device=device)
         _ds_plane_bufs[key] = buf
+    if _capture_pins is not None and all(b is not buf for b in _capture_pins):
+        _capture_pins.append(buf)
     return buf
 
 
