@@ -226,19 +226,26 @@ def p_step_three_ways(dev, realisation, oracle_dtypes=(torch.float32, torch.floa
     cfg = bench.p_config()
     torch.manual_seed(0)
     model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet())).to(dev).train()
+    for name, mod in model.named_modules():          # names for the LayerNorm -> ReLU sign-decision log (ops.relu_log)
+        if isinstance(mod, blocks.LayerNorm):
+            mod._site = name
     batch = bench.synth_batch(2, dev)
     torch.cuda.manual_seed_all(1000 + realisation)
     blocks.reset_drop_pool()
     ops._drop_counter[0] = 7919 * realisation
     _lib.check(_lib.load().vilco_seed_word_set(realisation, None))
     ops.dropout_log = []
+    ops.relu_log = []
     try:
         losses = model(batch, is_training=True)
         losses['final_loss'].backward()
         log = list(ops.dropout_log)
+        relu_sites = [(site, m.cpu()) for site, m in ops.relu_log]
     finally:
         ops.dropout_log = None
+        ops.relu_log = None
     torch.cuda.synchronize()
+    level_T = [int(cfg['max_seq_len']) // int(cfg['scale_factor']) ** l for l in range(int(cfg['backbone_arch'][-1]) + 1)]
     hip_grads = {k: p.grad.detach().double().cpu() for k, p in model.named_parameters() if p.grad is not None}
     hip_losses = {k: float(v) for k, v in losses.items()}
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -251,21 +258,51 @@ def p_step_three_ways(dev, realisation, oracle_dtypes=(torch.float32, torch.floa
     masks = [(e[0], e[1]) if len(e) == 2 else (e[0], ops.dropout_mask(e[1], e[2], e[3], dev, e[0]).cpu()) for e in log]
     torch.cuda.synchronize()
     _lib.check(_lib.load().vilco_seed_word_set(0, None))
-    for dt in oracle_dtypes:
+    def run_oracle(dt, relu_masks=None):
+        """one oracle step under the HIP step's masks; relu_masks: the HIP step's LayerNorm -> ReLU sign decisions in the
+        oracle's layout (hip_relu_masks) -> the run takes the same sides and reports where its own would have differed"""
         p = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in state.items()}
         vl = [{k: ((v.cpu().to(dt) if v.is_floating_point() else v.cpu()) if torch.is_tensor(v) else v) for k, v in d.items()} for d in batch]
         ctx = mq_oracle.DropReplay(masks, None)
         mq_oracle.DROP = ctx
+        rr = mq_oracle.RELU = mq_oracle.ReluReplay(relu_masks) if relu_masks is not None else None
         try:
             want, _ = mq_oracle.forward_losses(p, cfg, vl)
             want['final_loss'].backward()
         finally:
             mq_oracle.DROP = None
+            mq_oracle.RELU = None
         assert ctx.leftover() == {}, ctx.leftover()
-        out[dt] = ({k: float(v) for k, v in want.items()},
-                   {k: v.grad.detach().double() for k, v in p.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None})
-        del p, want, ctx
+        res = ({k: float(v) for k, v in want.items()},
+               {k: v.grad.detach().double() for k, v in p.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None})
+        if rr is not None:
+            assert rr.seen == set(relu_masks), (sorted(set(relu_masks) - rr.seen))
+            res = res + (rr.events,)
+        return res
+
+    for dt in oracle_dtypes:
+        out[dt] = run_oracle(dt)
+    out['rerun'] = run_oracle
+    out['hip_relu'] = hip_relu_masks(relu_sites, level_T)
     return hip_losses, hip_grads, out
+
+
+def hip_relu_masks(relu_sites, level_T):
+    """(module name, y > 0 in the HIP layout) of every LayerNorm -> ReLU call of a step -> {oracle site: bool [B, C, T]}.
+    HIP layouts: token-major [B, T, C]; the heads run all pyramid levels of a clip as ONE token sequence with a zero row between
+    neighbours (vilco_amd/modeling/meta_archs.py: LevelCat) -- split back into the oracle's per-level calls 'norm.i@level'."""
+    out = {}
+    for site, m in relu_sites:
+        assert site is not None and m.dim() == 3, site
+        if site.startswith(('cls_head.norm.', 'reg_head.norm.')):
+            assert m.shape[1] == sum(level_T) + len(level_T) - 1, (site, tuple(m.shape), level_T)
+            o = 0
+            for l, T in enumerate(level_T):
+                out['%s@%d' % (site, l)] = m[:, o:o + T].permute(0, 2, 1).contiguous()
+                o += T + 1
+        else:
+            out[site] = m.permute(0, 2, 1).contiguous()
+    return out
 
 
 def tensor_distance(g, w):

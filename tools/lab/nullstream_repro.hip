@@ -3,9 +3,12 @@
 // training step does (ops.fork_enabled); a device counter is bumped by every launch and both branches write it into a small
 // buffer after spinning; the eager copy behind the launch must read the value of THAT launch.
 //   build: hipcc --offload-arch=gfx950 -O2 -o nullstream_repro nullstream_repro.hip
-//   run:   ./nullstream_repro <stream: 0 null | 1 created | 2 created non-blocking> <pattern 0..3> [iters] [spin cycles]
+//   run:   ./nullstream_repro <stream: 0 null | 1 created | 2 created non-blocking> <pattern 0..3> [iters] [spin cycles] [chain]
+// chain (default 1): kernel nodes per branch -- the captured step's graphs have hundreds of nodes in a few branches
 // patterns: 0 copy kernels on the launch stream; 1 hipMemcpyAsync D2D on the launch stream; 2 the copies on a SECOND stream ordered
-// by events both ways (what a collective's stream does); 3 as 0 with two graphs (stages) per iteration and a copy after each.
+// by events both ways (what a collective's stream does); 3 as 0 with two graphs (stages) per iteration and a copy after each;
+// 4 the graph holds what the stale gradients had in common (loss.hip:402 / eltwise.hip colsum): a MEMSET node, then 64 workgroups
+// adding the counter into the cleared buffer with device-scope float atomics; the eager copy must read 64 x (launch number).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -18,12 +21,18 @@ __global__ void spin_write(float* g, const unsigned* ctr, int n, long spin) {
   while ((long)(__builtin_amdgcn_s_memtime() - t0) < spin) { }
   if ((int)threadIdx.x < n) g[threadIdx.x] = (float)(*ctr);
 }
+__global__ void atomic_acc(float* acc, const unsigned* ctr, int n, long spin) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while ((long)(__builtin_amdgcn_s_memtime() - t0) < spin) { }
+  if ((int)threadIdx.x < n) atomicAdd(acc + threadIdx.x, (float)(*ctr));
+}
 __global__ void copy_k(const float* __restrict__ s, float* __restrict__ d, int n) { if ((int)threadIdx.x < n) d[threadIdx.x] = s[threadIdx.x]; }
 
 int main(int argc, char** argv) {
   const int smode = argc > 1 ? atoi(argv[1]) : 0, pat = argc > 2 ? atoi(argv[2]) : 0;
   const int iters = argc > 3 ? atoi(argv[3]) : 3000;
   const long spin = argc > 4 ? atol(argv[4]) : 20000;       // 100 MHz counter: 20000 = 200 us per branch
+  const int chain = argc > 5 ? atoi(argv[5]) : 1;
   const int n = 64;
   unsigned* ctr; float *gA, *gB, *gC, *out;
   CK(hipMalloc(&ctr, 4)); CK(hipMemset(ctr, 0, 4));
@@ -41,17 +50,26 @@ int main(int argc, char** argv) {
   CK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
   hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, cap, ctr);
   CK(hipEventRecord(f, cap)); CK(hipStreamWaitEvent(side, f, 0));
-  hipLaunchKernelGGL(spin_write, dim3(1), dim3(64), 0, side, gB, ctr, n, spin / 2);
-  hipLaunchKernelGGL(spin_write, dim3(1), dim3(64), 0, cap, gA, ctr, n, spin);
+  if (pat == 4) {
+    CK(hipMemsetAsync(gA, 0, n * 4, cap)); CK(hipMemsetAsync(gB, 0, n * 4, side));
+    for (int c = 0; c < chain; ++c) {
+      hipLaunchKernelGGL(atomic_acc, dim3(64 / chain > 0 ? 64 / chain : 1), dim3(64), 0, side, gB, ctr, n, spin / 2 / chain);
+      hipLaunchKernelGGL(atomic_acc, dim3(64 / chain > 0 ? 64 / chain : 1), dim3(64), 0, cap, gA, ctr, n, spin / chain);
+    }
+  } else
+  for (int c = 0; c < chain; ++c) {
+    hipLaunchKernelGGL(spin_write, dim3(1), dim3(64), 0, side, gB, ctr, n, spin / 2 / chain);
+    hipLaunchKernelGGL(spin_write, dim3(1), dim3(64), 0, cap, gA, ctr, n, spin / chain);
+  }
   CK(hipEventRecord(j, side)); CK(hipStreamWaitEvent(cap, j, 0));
   CK(hipStreamEndCapture(cap, &g1)); CK(hipGraphInstantiate(&x1, g1, nullptr, nullptr, 0));
   CK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
-  hipLaunchKernelGGL(spin_write, dim3(1), dim3(64), 0, cap, gC, ctr, n, spin / 4);
+  for (int c = 0; c < chain; ++c) hipLaunchKernelGGL(spin_write, dim3(1), dim3(64), 0, cap, gC, ctr, n, spin / 4 / chain);
   CK(hipStreamEndCapture(cap, &g2)); CK(hipGraphInstantiate(&x2, g2, nullptr, nullptr, 0));
   for (int it = 0; it < iters; ++it) {                       // no host wait anywhere in here
     float* o = out + (size_t)it * 3 * n;
     CK(hipGraphLaunch(x1, S));
-    if (pat == 0 || pat == 3) {
+    if (pat == 0 || pat == 3 || pat == 4) {
       hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, o, n);
       hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gB, o + n, n);
     } else if (pat == 1) {
@@ -75,9 +93,9 @@ int main(int argc, char** argv) {
   for (int it = 0; it < iters; ++it)
     for (int b = 0; b < (pat == 3 ? 3 : 2); ++b)
       for (int k = 0; k < n; ++k)
-        if (h[((size_t)it * 3 + b) * n + k] != (float)(it + 1)) { ++bad; if (first < 0) first = it; }
+        if (h[((size_t)it * 3 + b) * n + k] != (float)(it + 1) * (pat == 4 ? (float)((64 / chain > 0 ? 64 / chain : 1) * chain) : 1.f)) { ++bad; if (first < 0) first = it; }
   int ver = 0; CK(hipRuntimeGetVersion(&ver));
-  printf("stream %s pattern %d iters %d spin %ld: %ld wrong values%s (first at iteration %d)  [HIP runtime %d]\n",
-         smode == 0 ? "NULL" : (smode == 1 ? "created" : "created-nonblocking"), pat, iters, spin, bad, bad ? "  <-- ORDER VIOLATED" : "", first, ver);
+  printf("stream %s pattern %d iters %d spin %ld chain %d: %ld wrong values%s (first at iteration %d)  [HIP runtime %d]\n",
+         smode == 0 ? "NULL" : (smode == 1 ? "created" : "created-nonblocking"), pat, iters, spin, chain, bad, bad ? "  <-- ORDER VIOLATED" : "", first, ver);
   return bad ? 1 : 0;
 }
