@@ -236,26 +236,24 @@ def test_p_config_train_step_vs_oracles_over_mask_realisations(dev):
     0.1, single-part weight-gradient products active -- over THREE realisations of the masks, each compared with the oracle
     (the CPU restatement of the reference) replaying exactly the masks the HIP step drew, in fp32 AND in fp64 (~60 s each).
 
-    What "within 1e-3 of the reference" can mean at this size (round 4: profiles/r04_oracle_*.json; round 5:
-    profiles/r05_p_parity_realisations.json): the step contains discrete decisions -- the stride-2 max-pools route a gradient
-    element to one of two near-tied tokens, LayerNorm -> ReLU pre-activations sit within rounding of zero -- so the
-    reference's OWN fp32 arithmetic is far from an exact (fp64) run of itself on a quarter of the tensors under every
-    realisation (59 ... 102 of 355 tensors beyond 1e-3 of their maximum, worst 0.13 ... 0.30).  Three bars, per realisation:
-
-    (1) against the exact run, relative to the reference arithmetic's own uncertainty, per tensor:
-            d(HIP, fp64) <= max(1e-3, 2 d(fp32 oracle, fp64))   in the max norm and in the L2 norm,
-        d_max = max|g - w| / max|w|, d_l2 = ||g - w|| / ||w||; losses within 1e-5 of the fp64 losses.
-    (2) against the REFERENCE ARITHMETIC ITSELF (round 6, VERDICT r05 weak 1 / ADVICE r05): on every tensor where the fp32
-        oracle is within 1e-3 of the exact run in both norms -- where "the reference's answer" is defined to that accuracy --
-        HIP is within 1e-3 of the fp32 oracle in the L2 norm and within 2e-3 in the max norm (two arithmetics each within
-        1e-3 of the exact value); at most a quarter of the tensors may be outside that set.
-    A realisation meeting (1) and (2) on every tensor is "clean".
-    (3) a realisation that does not is accepted ONLY WITH A LOCATED CAUSE, never on a looser bound: the HIP step's LayerNorm ->
-        ReLU sign decisions (ops.relu_log: embeddings and head trunks, ~50 M elements) are replayed into a second fp64 oracle
-        run (oracle.mq_oracle.ReluReplay: y = x * [HIP took the positive side]).  That run reports every element where its
-        own sign differs from HIP's -- each must be a pre-activation within 1e-5 of its tensor's maximum of ZERO in exact
-        arithmetic (a coin flip for any arithmetic; the fp32 oracle loses such flips against fp64 too) -- and with those
-        decisions shared, every tensor must meet bar (1) against that run.  At most one realisation of three may need it.
+    (A) THE BAR (BASELINE.json: "within 1e-3 rel fp32"): every gradient tensor within 1e-3 of the REFERENCE ARITHMETIC -- the
+        fp32 oracle -- in the max norm (max|g - w| / max|w|) AND in the L2 norm (||g - w|| / ||w||); losses within 1e-5.
+        Measured over four realisations (round 6, profiles/r06_p_parity_decisions.json): worst 7.2e-4 / 3.3e-4, no tensor
+        beyond 1e-3 in either norm under any of them.
+    (B) sanity against exact arithmetic: d(HIP, fp64) <= max(1e-3, 2 d(fp32 oracle, fp64)) per tensor and norm.  (An fp64 run
+        is NOT the reference: the step contains discrete decisions -- stride-2 max-pools routing a gradient element to one of
+        two near-tied tokens, LayerNorm -> ReLU pre-activations within rounding of zero -- so the reference's own fp32 is
+        beyond 1e-3 of an fp64 run of itself on 88-100 (max norm) / 182-191 (L2) of the 355 tensors under every realisation,
+        worst 0.3; HIP sits at the same distances to 3-6 digits because it takes the fp32 oracle's side of those decisions.)
+    A realisation meeting (A) and (B) on every tensor is "clean".
+    (C) a realisation that does not is accepted ONLY WITH A LOCATED CAUSE, never on a looser bound (round 5
+        accepted one such realisation of three on 1e-2 / 5e-2).  The HIP step's LayerNorm -> ReLU sign decisions (ops.relu_log:
+        embeddings and head trunks, ~50 M elements) are replayed into a second fp32 oracle run (oracle.mq_oracle.ReluReplay:
+        y = x * [HIP took the positive side]).  That run reports every element where its own sign differs from HIP's -- 10-15
+        sites with 1-5 elements each under every realisation, all of them pre-activations within 6e-7 of their tensor's
+        maximum of zero: a coin flip for any arithmetic, and an element that happens to carry a large loss gradient moves
+        everything upstream by a discrete amount.  Each such element must be within 1e-5 of zero, and with the decisions
+        shared every tensor must meet (A) against that run.  At most one realisation of three may need (C).
     (Seeds fix the realisations; both arithmetics are bit-reproducible given the masks.)"""
     from parity_util import p_step_three_ways, tensor_distance
     from vilco_amd import ops
@@ -268,6 +266,7 @@ def test_p_config_train_step_vs_oracles_over_mask_realisations(dev):
         l32, g32 = orc[torch.float32]
         l64, g64 = orc[torch.float64]
         for k in ('cls_loss', 'reg_loss', 'final_loss'):
+            assert abs(hl[k] - l32[k]) <= 1e-5 * abs(l32[k]), (r, k, hl[k], l32[k], l64[k])
             assert abs(hl[k] - l64[k]) <= 1e-5 * abs(l64[k]), (r, k, hl[k], l32[k], l64[k])
         rows = []
         for k, w in g64.items():
@@ -276,38 +275,33 @@ def test_p_config_train_step_vs_oracles_over_mask_realisations(dev):
             dh, dr, dd = tensor_distance(hg[k], w), tensor_distance(g32[k], w), tensor_distance(hg[k], g32[k])
             rows.append((k, dh[0], dr[0], dh[1], dr[1], dd[0], dd[1]))
         assert len(rows) > 300
-        viol = [x for x in rows if x[1] > max(1e-3, 2 * x[2]) or x[3] > max(1e-3, 2 * x[4])]
-        defined = [x for x in rows if x[2] <= 1e-3 and x[4] <= 1e-3]          # the reference's fp32 answer is good to 1e-3 here
-        direct = [x for x in defined if x[6] > 1e-3 or x[5] > 2e-3]
-        report.append(dict(realisation=r, violations=len(viol), direct_violations=len(direct), defined=len(defined), tensors=len(rows),
-                           hip_beyond_1e3=sum(1 for x in rows if x[1] > 1e-3), ref_beyond_1e3=sum(1 for x in rows if x[2] > 1e-3),
-                           hip_worst_max=max(x[1] for x in rows), ref_worst_max=max(x[2] for x in rows),
-                           hip_worst_l2=max(x[3] for x in rows), ref_worst_l2=max(x[4] for x in rows),
-                           hip_vs_ref_worst_l2_on_defined=max(x[6] for x in defined), hip_vs_ref_worst_max_on_defined=max(x[5] for x in defined)))
-        assert len(defined) >= 0.75 * len(rows), report[-1]
-        if not viol and not direct:
+        direct = [x for x in rows if x[5] > 1e-3 or x[6] > 1e-3]                                           # (A)
+        viol = [x for x in rows if x[1] > max(1e-3, 2 * x[2]) or x[3] > max(1e-3, 2 * x[4])]              # (B)
+        report.append(dict(realisation=r, tensors=len(rows), beyond_bar_vs_fp32=len(direct), beyond_relative_bar_vs_fp64=len(viol),
+                           hip_vs_fp32_worst_max=max(x[5] for x in rows), hip_vs_fp32_worst_l2=max(x[6] for x in rows),
+                           hip_beyond_1e3_of_fp64=sum(1 for x in rows if x[1] > 1e-3), fp32_beyond_1e3_of_fp64=sum(1 for x in rows if x[2] > 1e-3)))
+        if not direct and not viol:
             kinds.append("clean")
             del hg, g32, g64, orc
             continue
-        # ---- (3) not clean: locate the cause or fail
+        # ---- (C) not clean: locate the cause or fail
         kinds.append("flip")
-        lf, gf, events = orc['rerun'](torch.float64, orc['hip_relu'])
-        assert events, ("realisation %d misses the bar without any ReLU sign difference between HIP and the exact run" % r,
-                        sorted(viol + direct, key=lambda x: -x[3])[:6])
+        lf, gf, events = orc['rerun'](torch.float32, orc['hip_relu'])
+        assert events, ("realisation %d misses the bar without any ReLU sign difference between HIP and the fp32 oracle" % r,
+                        sorted(direct + viol, key=lambda x: -x[6])[:6])
         for site, n, rel in events:
             assert rel <= 1e-5, ("a LayerNorm -> ReLU pre-activation that is NOT within rounding of zero changed sign", r, site, n, rel)
         for k in ('cls_loss', 'reg_loss', 'final_loss'):
             assert abs(hl[k] - lf[k]) <= 1e-5 * abs(lf[k]), (r, k, hl[k], lf[k])
-        by = {x[0]: x for x in rows}
         bad = []
         for k, w in gf.items():
             if k.endswith(zero_by_symmetry):
                 continue
             d = tensor_distance(hg[k], w)
-            if d[0] > max(1e-3, 2 * by[k][2]) or d[1] > max(1e-3, 2 * by[k][4]):
-                bad.append((k, d[0], by[k][2], d[1], by[k][4]))
-        report[-1].update(relu_sign_events=[(s_, n, rel) for s_, n, rel in events], after_replay_violations=len(bad))
-        assert not bad, (r, events, sorted(bad, key=lambda x: -x[3])[:8])
+            if d[0] > 1e-3 or d[1] > 1e-3:
+                bad.append((k, d[0], d[1]))
+        report[-1].update(relu_sign_events=[(s_, n, rel) for s_, n, rel in events], beyond_bar_after_replay=len(bad))
+        assert not bad, (r, events, sorted(bad, key=lambda x: -x[2])[:8])
         del hg, g32, g64, gf, orc
     print("full-size parity report:", report)
     assert kinds.count("clean") >= 2, (kinds, report)
