@@ -8,11 +8,22 @@
 // patterns: 0 copy kernels on the launch stream; 1 hipMemcpyAsync D2D on the launch stream; 2 the copies on a SECOND stream ordered
 // by events both ways (what a collective's stream does); 3 as 0 with two graphs (stages) per iteration and a copy after each;
 // 4 the graph holds what the stale gradients had in common (loss.hip:402 / eltwise.hip colsum): a MEMSET node, then 64 workgroups
-// adding the counter into the cleared buffer with device-scope float atomics; the eager copy must read 64 x (launch number).
+// adding the counter into the cleared buffer with device-scope float atomics; the eager copy must read 64 x (launch number);
+// 5 / 6 the data-parallel replay's own sequence (vilco_amd/graph.py: _replay_staged + dist.GradReducer): graph 1, gather copy on the
+// launch stream, an in-place "collective" on a SECOND stream behind an event (5: that stream blocking, 6: NON-BLOCKING, as torch's and
+// RCCL's streams are), graph 2 launched on the launch stream while the collective runs, then the wait for the collective, the copy
+// back into the gradient's own memory and the check;
+// 7 / 8 / 9 what the torch-level bisect left (tools/lab/dp_staged_dbg2.py with VILCO_DP_DEBUG_NO_COLLECTIVE=2 fails on the null stream
+// WITHOUT any RCCL call): as 6 but NOTHING runs on the second stream -- it only waits for the launch stream's event and records the end
+// event the launch stream then waits for; the second stream is high-priority non-blocking (torch's pool); 8: the two events are created
+// and destroyed every iteration, as torch.cuda.Event objects are; 9: as 7 with the end event queried from a second host thread while
+// the loop runs (what a collective's watchdog does).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <atomic>
+#include <thread>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
 __global__ void bump(unsigned* ctr) { if (threadIdx.x == 0) *ctr = *ctr + 1u; }
@@ -25,6 +36,12 @@ __global__ void atomic_acc(float* acc, const unsigned* ctr, int n, long spin) {
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   while ((long)(__builtin_amdgcn_s_memtime() - t0) < spin) { }
   if ((int)threadIdx.x < n) atomicAdd(acc + threadIdx.x, (float)(*ctr));
+}
+__global__ void slow_inplace(float* b, int n, long spin) {      // stands in for the all-reduce (one rank: identity), takes a while
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const float v = (int)threadIdx.x < n ? b[threadIdx.x] : 0.f;
+  while ((long)(__builtin_amdgcn_s_memtime() - t0) < spin) { }
+  if ((int)threadIdx.x < n) b[threadIdx.x] = v;
 }
 __global__ void copy_k(const float* __restrict__ s, float* __restrict__ d, int n) { if ((int)threadIdx.x < n) d[threadIdx.x] = s[threadIdx.x]; }
 
@@ -39,7 +56,13 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&gA, n * 4)); CK(hipMalloc(&gB, n * 4)); CK(hipMalloc(&gC, n * 4));
   CK(hipMalloc(&out, (size_t)iters * 3 * n * 4)); CK(hipMemset(out, 0, (size_t)iters * 3 * n * 4));
   hipStream_t cap, side, S = nullptr, C2;
-  CK(hipStreamCreate(&cap)); CK(hipStreamCreate(&side)); CK(hipStreamCreate(&C2));
+  CK(hipStreamCreate(&cap)); CK(hipStreamCreate(&side));
+  if (pat >= 7) CK(hipStreamCreateWithPriority(&C2, hipStreamNonBlocking, -1));
+  else if (pat == 6) CK(hipStreamCreateWithFlags(&C2, hipStreamNonBlocking)); else CK(hipStreamCreate(&C2));
+  std::atomic<hipEvent_t> watched{nullptr}; std::atomic<bool> stop{false};
+  std::thread watchdog;
+  if (pat == 9) watchdog = std::thread([&] { while (!stop.load()) { hipEvent_t e = watched.load(); if (e) (void)hipEventQuery(e); } });
+  float* bucket; CK(hipMalloc(&bucket, n * 4)); CK(hipMemset(bucket, 0, n * 4));
   if (smode == 1) CK(hipStreamCreate(&S));
   if (smode == 2) CK(hipStreamCreateWithFlags(&S, hipStreamNonBlocking));
   hipEvent_t f, j, e1, e2;
@@ -69,7 +92,30 @@ int main(int argc, char** argv) {
   for (int it = 0; it < iters; ++it) {                       // no host wait anywhere in here
     float* o = out + (size_t)it * 3 * n;
     CK(hipGraphLaunch(x1, S));
-    if (pat == 0 || pat == 3 || pat == 4) {
+    if (pat >= 7) {
+      hipEvent_t a = e1, b = e2;
+      if (pat == 8) { CK(hipEventCreateWithFlags(&a, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&b, hipEventDisableTiming)); }
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, bucket, n);                 // gather
+      CK(hipEventRecord(a, S)); CK(hipStreamWaitEvent(C2, a, 0));
+      CK(hipEventRecord(b, C2));                                                          // (nothing runs on C2)
+      if (pat == 9) watched.store(b);
+      CK(hipGraphLaunch(x2, S));
+      CK(hipStreamWaitEvent(S, b, 0));
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, bucket, gA, n);                 // copy back
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, o, n);
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gB, o + n, n);
+      if (pat == 8) { CK(hipEventDestroy(a)); CK(hipEventDestroy(b)); }
+    } else if (pat == 5 || pat == 6) {
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, bucket, n);                 // gather
+      CK(hipEventRecord(e1, S)); CK(hipStreamWaitEvent(C2, e1, 0));
+      hipLaunchKernelGGL(slow_inplace, dim3(1), dim3(64), 0, C2, bucket, n, spin / 2);   // the "collective"
+      CK(hipEventRecord(e2, C2));
+      CK(hipGraphLaunch(x2, S));                                                          // the next stage runs under it
+      CK(hipStreamWaitEvent(S, e2, 0));
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, bucket, gA, n);                 // copy back into the gradient itself
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, o, n);
+      hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gB, o + n, n);
+    } else if (pat == 0 || pat == 3 || pat == 4) {
       hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, o, n);
       hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gB, o + n, n);
     } else if (pat == 1) {
@@ -87,6 +133,7 @@ int main(int argc, char** argv) {
     }
   }
   CK(hipDeviceSynchronize());
+  if (pat == 9) { stop.store(true); watchdog.join(); }
   std::vector<float> h((size_t)iters * 3 * n);
   CK(hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost));
   long bad = 0; int first = -1;

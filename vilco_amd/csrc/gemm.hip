@@ -1301,6 +1301,35 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
     }
     if (ks < 1) ks = 1;
   }
+  // Round 6: the single-part products on gemm_pp_kernel's K2 loop (the weight gradients: M = Cout = 1024 rows, long K) were always
+  // planned at 128 rows (M < 2048).  A 128 x 128 tile of ONE part is bound by its staging traffic (a 64-k interval moves 32 KB for
+  // 128 MFMAs per CU); a 256-row tile does 2x the MFMAs for 1.5x the bytes, and the lost tile count is made up by split-K.  Measured
+  // per 64-k interval and round (tools/lab/dw_sweep.py, profiles/r06_dw_sweep_pp.txt): 0.70 us at 128 rows, 0.95 at 192, 1.02 at 256,
+  // + ~9 us per launch, + the slab traffic of a split.  The plan takes the cheapest of {128 as before, 192, 256 with the split count
+  // that fills one round}, and leaves 128 unless the model says >= 8 % (1024 x 3072 x 9082: 109.9 -> 81.5 us, 1024 x 6912 x 4608:
+  // 101.1 -> 78.3, 3072 x 1024 x 4608: 51.4 -> 46.0; the 1024 x 1024 and x 4096 shapes keep their plan).
+  static const bool dw_tall = [] { const char* e = getenv("VILCO_GEMM_DW_TALL"); return !(e && e[0] == '0'); }();
+  if (dw_tall && d->precision == 4 && p.k2 && !p.gl && nbatch == 1 && p.BM == 128) {
+    auto model = [&](int bm, int k, double c) {
+      const long t = ((d->M + bm - 1) / bm) * tn;
+      const long rounds = (t * k + 255) / 256;
+      const double split = k > 1 ? 3.0 + (double)d->M * d->N * 4.0 * (k + 1) / 5e6 : 0.0;
+      return 9.0 + (double)rounds * ((nk + k - 1) / k) * c + split;
+    };
+    const double base = model(128, ks, 0.70);
+    double best_t = base; int best_bm = 128, best_ks = ks;
+    const int bms[2] = {192, 256}; const double cs[2] = {0.95, 1.02};
+    for (int q = 0; q < 2; ++q) {
+      const long t = ((d->M + bms[q] - 1) / bms[q]) * tn;
+      int k = t >= 256 ? 1 : (int)(256 / t);
+      if (k > nk / 8) k = nk / 8;
+      if (k > 16) k = 16;
+      if (k < 1) k = 1;
+      const double m = model(bms[q], k, cs[q]);
+      if (m < best_t) { best_t = m; best_bm = bms[q]; best_ks = k; }
+    }
+    if (best_bm != 128 && best_t <= 0.92 * base) { p.BM = best_bm; ks = best_ks; }
+  }
   // tuning overrides (tools/gemm_tune.py): VILCO_GEMM_BM = 128|256, VILCO_GEMM_KS = forced split count
   // (read once per process: the plan is made twice per launch)
   const int force_bm = tune().bm, force_ks = tune().ks;

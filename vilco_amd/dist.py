@@ -38,7 +38,8 @@ import torch.distributed as dist
 
 DEFAULT_BUCKET_MB = 64      # xGMI rings are per-link bound: few large collectives beat many small ones
 import os as _os
-_DEBUG_NO_COLLECTIVE = _os.environ.get("VILCO_DP_DEBUG_NO_COLLECTIVE") == "1"      # one-rank debugging aid (tools/lab/dp_staged_dbg2.py)
+_DEBUG_NO_COLLECTIVE = _os.environ.get("VILCO_DP_DEBUG_NO_COLLECTIVE") in ("1", "2")      # one-rank debugging aid (tools/lab/dp_staged_dbg2.py)
+_DEBUG_EMULATE = _os.environ.get("VILCO_DP_DEBUG_NO_COLLECTIVE") == "2"
 
 
 _DEBUG_SLOW_COPY = _os.environ.get("VILCO_DP_DEBUG_SLOW_COPY") == "1"
@@ -54,6 +55,27 @@ def _copy_list(dst, src):
 
 class _NoWork:
     def wait(self):
+        return True
+
+
+class _EmulatedWork:
+    """debugging aid (VILCO_DP_DEBUG_NO_COLLECTIVE=2, one rank): the stream choreography of an asynchronous collective without the
+    collective -- an event of the caller's stream, a high-priority side stream waiting for it, an end event of the side stream the
+    caller waits for in wait() -- to tell torch's streams / events apart from RCCL in the null-stream hazard"""
+    _side = None
+
+    def __init__(self):
+        if _EmulatedWork._side is None:
+            _EmulatedWork._side = torch.cuda.Stream(priority=-1)
+        cur = torch.cuda.current_stream()
+        e = torch.cuda.Event()
+        e.record(cur)
+        _EmulatedWork._side.wait_event(e)
+        self.end = torch.cuda.Event()
+        self.end.record(_EmulatedWork._side)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.end)
         return True
 
 
@@ -184,7 +206,7 @@ class GradReducer:
             _copy_list(dst, src)
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if _DEBUG_NO_COLLECTIVE and self.world == 1:
-            b["work"] = _NoWork()
+            b["work"] = _EmulatedWork() if _DEBUG_EMULATE else _NoWork()
         else:
             b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
         self._pending.append(b)
