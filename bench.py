@@ -216,7 +216,7 @@ def pmc_traffic():
     """HBM bytes per GEMM-kernel launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the gfx950
     note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); None when the summary is absent."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # newest committed summary
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):          # newest committed summary
         try:
             d = json.load(open(os.path.join(prof, name)))
             return (d.get("gemm_kernels") or d["gemm_pp_kernel"])["hbm_bytes_per_launch"]
@@ -356,6 +356,19 @@ def main():
 
         def step():
             graphed(batch)
+        if distributed:
+            # Every rank must take the same path (replayed or eager) from the first timed step on: the capture is attempted here,
+            # outside any step (a staged capture issues no collective), and the ranks agree on the outcome -- a capture that this
+            # runtime refuses on ONE rank falls back to eager steps on ALL of them (all-reduce from autograd hooks) instead of
+            # leaving the ranks waiting in different collectives.
+            for _ in range(2):
+                graphed(batch)                    # eager: builds the bucket plan (collectives inside, every rank alike)
+            ok = torch.tensor([1 if graphed.try_capture(batch) else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                graphed.reset()
+                graphed = None
+                step = eager_step
     else:
         step = eager_step
 

@@ -2,10 +2,11 @@
 # Round 6: the same GEMM launches INSIDE an eager P step and BACK TO BACK -- elapsed cycles (GRBM_GUI_ACTIVE / 8),
 # L2 hit rate (TCC_HIT / (HIT + MISS)) and bytes requested from the fabric (FETCH_SIZE x 2 on gfx950) per dispatch, per SHAPE
 # (the step's launches are identified by their order: tools/lab/instep_gemm_step.py lists them).  Separate PMC passes, kernel-trace
-# only.  Under PMC every dispatch runs alone, so "in the step" here is the step's CACHE STATE, not its concurrency.
+# only; WRITE_SIZE tells the fused epilogues of the step (pre-activation stores, ...) from the plain ones of the back-to-back run.
+# Under PMC every dispatch runs alone, so "in the step" here is the step's CACHE STATE, not its concurrency.
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
-for pass in GRBM_GUI_ACTIVE "TCC_HIT_sum TCC_MISS_sum" FETCH_SIZE; do
+for pass in GRBM_GUI_ACTIVE "TCC_HIT_sum TCC_MISS_sum" FETCH_SIZE WRITE_SIZE; do
   tag=$(echo $pass | cut -c1-7 | tr ' ' '_')
   rm -rf /tmp/ig_s_$tag /tmp/ig_b_$tag
   INSTEP_RECORDS=/tmp/instep_records_$tag.json rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/ig_s_$tag -o s -- python3 $R/tools/lab/instep_gemm_step.py > /dev/null 2>&1
@@ -23,7 +24,7 @@ def gemm_rows(f):
 def med(v):
     v = sorted(v); return v[len(v) // 2] if v else float('nan')
 step = collections.defaultdict(lambda: collections.defaultdict(list))
-for tag in ("GRBM_GU", "TCC_HIT", "FETCH_S"):
+for tag in ("GRBM_GU", "TCC_HIT", "FETCH_S", "WRITE_S"):
     recs = json.load(open('/tmp/instep_records_%s.json' % tag))
     rows = gemm_rows(glob.glob('/tmp/ig_s_%s/*_counter_collection.csv' % tag)[0])[-len(recs):]
     assert len(rows) == len(recs), (len(rows), len(recs))
@@ -33,19 +34,20 @@ for tag in ("GRBM_GU", "TCC_HIT", "FETCH_S"):
 b2b = collections.defaultdict(lambda: collections.defaultdict(list))
 shapes = [(4608, 1024, 1024, 3, 0, 0), (4608, 1024, 1024, 3, 0, 1), (4608, 4096, 1024, 3, 0, 0), (4608, 1024, 4096, 3, 0, 0), (4608, 4096, 1024, 3, 0, 1),
           (4608, 1024, 4096, 3, 0, 1), (1024, 1024, 4608, 4, 1, 1), (1024, 4096, 4608, 4, 1, 1), (4096, 1024, 4608, 4, 1, 1), (2304, 1024, 1024, 3, 0, 0)]
-for tag in ("GRBM_GU", "TCC_HIT", "FETCH_S"):
+for tag in ("GRBM_GU", "TCC_HIT", "FETCH_S", "WRITE_S"):
     rows = gemm_rows(glob.glob('/tmp/ig_b_%s/*_counter_collection.csv' % tag)[0])
     per = len(rows) // len(shapes)                                # 12 launches per shape, in order
     for i, key in enumerate(shapes):
         for c in rows[i * per + 4:(i + 1) * per]:                 # (skip the first launches of a shape: they meet the pack's cache state)
             for k, v in c.items(): b2b[key][k].append(v)
-print("%-34s | %-40s | %-40s" % ("M x N x K (prec, A km, B km)", "in the step: n, cycles, L2 hit, fabric MB", "back to back: n, cycles, L2 hit, fabric MB"))
+print("%-34s | %-48s | %-48s" % ("M x N x K (prec, A km, B km)", "in the step: n, cycles, L2 hit, MB read, MB written", "back to back (plain epilogue): the same"))
 for key in shapes:
     if key not in step: continue
     cells = []
     for D in (step, b2b):
         c = D[key]
         h, m = med(c['TCC_HIT_sum']), med(c['TCC_MISS_sum'])
-        cells.append("%3d %9.0f  %5.1f %%  %8.1f" % (len(c['GRBM_GUI_ACTIVE']), med(c['GRBM_GUI_ACTIVE']) / 8, 100 * h / max(h + m, 1), med(c['FETCH_SIZE']) * 2 / 1024))
-    print("%-34s | %-40s | %-40s" % ("%d x %d x %d (%d, %d, %d)" % key, cells[0], cells[1]))
+        cells.append("%3d %9.0f  %5.1f %%  %8.1f %8.1f" % (len(c['GRBM_GUI_ACTIVE']), med(c['GRBM_GUI_ACTIVE']) / 8, 100 * h / max(h + m, 1),
+                                                          med(c['FETCH_SIZE']) * 2 / 1024, med(c['WRITE_SIZE']) / 1024))
+    print("%-34s | %-48s | %-48s" % ("%d x %d x %d (%d, %d, %d)" % key, cells[0], cells[1]))
 PY

@@ -130,6 +130,35 @@ class GraphedStep:
             self._capture(ent, inp, task_id)
         return self._replay(ent, inp)
 
+    def try_capture(self, video_list, task_id=0):
+        """Capture the graphs of this batch's signature NOW, without replaying them (no collective is issued: a staged capture
+        holds none), and report whether that worked instead of raising.  For callers that must agree ACROSS RANKS on replay vs
+        eager before the first replayed step (bench.py, N > 1): a capture that fails on one rank only would leave the ranks
+        issuing different collectives.  False also when the step is not capturable; the signature then stays eager."""
+        model = self.model
+        inp = model.prepare(video_list, True, gt_pad=self.gt_pad)
+        if not (self.enabled and model.training and model.capturable(inp, task_id, None)):
+            return False
+        if self.reducer is not None and self.reducer.enabled and self.reducer.planned() is None:
+            return False                         # (the bucket plan comes from an eager finish(): run an eager step first)
+        key = (inp.signature(), int(task_id), self._param_sig(), int(model.n_known > 0), ops.arithmetic_key())
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = {'seen': 0}
+        if 'graph' in ent and self._still_valid(ent):
+            return True
+        try:
+            self._capture(ent, inp, task_id)
+            return True
+        except Exception as e:                   # noqa: BLE001 -- reported, not raised: the caller falls back to eager steps
+            import warnings
+            warnings.warn("GraphedStep.try_capture failed (%s: %s): this signature stays eager" % (type(e).__name__, e))
+            self._graphs.pop(key, None)
+            torch.cuda.synchronize()
+            for p in self.params:
+                p.grad = None
+            return False
+
     def _eager(self, inp, video_list, task_id, prev):
         self.stats['eager'] += 1
         for p in self.params:
