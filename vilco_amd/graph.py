@@ -46,6 +46,25 @@ _OWN_STREAM = os.environ.get("VILCO_GRAPH_OWN_STREAM", "1") != "0"      # replay
 _DP_SEGMENTS = os.environ.get("VILCO_DP_SEGMENTS", "1") != "0"
 
 
+_replay_streams = {}
+_SHARED_STREAM = os.environ.get("VILCO_GRAPH_SHARED_STREAM", "1") != "0"
+
+
+def _replay_stream(device):
+    """The stream GraphedStep replays on: ONE per device for every instance of the process (VILCO_GRAPH_SHARED_STREAM=0: one per
+    instance, round 5's form).  Round 6: with a stream per instance, the first hipGraphLaunch on the stream of the 5th-6th instance of
+    a process that had also initialised and destroyed an RCCL group segfaulted inside the runtime (tests/test_dist_gpu.py followed by
+    tests/test_graph_gpu.py, deterministic; exact on the null stream and with one shared stream) -- replays are serial on the host
+    anyway, so nothing is lost by sharing."""
+    if not _SHARED_STREAM:
+        return torch.cuda.Stream(device=device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _replay_streams.get(key)
+    if st is None:
+        st = _replay_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _capture_kw():
     """with a process group alive, RCCL's watchdog thread polls the events of finished collectives; under the default
     ("global") capture error mode such a query from ANOTHER thread while this one captures kills the capture -- and the
@@ -387,7 +406,7 @@ class GraphedStep:
         # stream is also 0.1-0.2 ms per step faster, tools/lab/stream_ab.py, and no replay depends on null-stream ordering)
         if cur == torch.cuda.default_stream(cur.device) and _OWN_STREAM:
             if getattr(self, "_own_stream", None) is None:
-                self._own_stream = torch.cuda.Stream(device=cur.device)
+                self._own_stream = _replay_stream(cur.device)
             own = self._own_stream
             own.wait_stream(cur)
         with torch.cuda.stream(own):
