@@ -59,7 +59,7 @@ def arithmetic_key():
             #  the remaining switches that change which kernels / roundings a step records, and the library's own
             # configuration generation (vilco_gemm_force / _set_gl / _set_fixup / _set_tail128)
             bool(fold_skip_grads), bool(xl_ds_planes), bool(xl_scores_kernel), bool(linear_group_enabled), bool(use_flash),
-            bool(_reuse_packs), bool(_weight_cache), str(range_check), int(_lib.load().vilco_gemm_config_gen()))
+            bool(_reuse_packs), bool(_weight_cache), str(range_check), int(_lib.load().vilco_gemm_config_gen()), bool(pack_group_enabled))
 
 
 def get_precision():
@@ -606,6 +606,32 @@ def pack_many(items, precision=None, nbatch=1, relshift=False):
     return bufs
 
 
+pack_group_enabled = os.environ.get("VILCO_PACK_GROUP", "1") != "0"
+
+
+def pack_group(xs, rows, cols, precision=None):
+    """`[pack(x, rows, cols) for x in xs]` for 2..4 tensors of ONE shape that are packed back to back on one chain (the q / k / v
+    inputs of an attention block's projections, their three output gradients): one launch (vilco_pack_many) instead of len(xs),
+    the same planes bit for bit, remembered on the tensors like `pack`.  Falls back to per-tensor packs when any of them already
+    carries its planes (a cache hit must stay a hit), when the tensors repeat, or VILCO_PACK_GROUP=0."""
+    prec = _precision if precision is None else int(precision)
+    n = len(xs)
+    fresh = True
+    for x in xs:
+        hit = getattr(x, "_vilco_planes", None) if _pack_cache else None
+        if hit is not None and hit[1] == (int(rows), int(cols), prec, x._version):
+            fresh = False
+    if (not pack_group_enabled or not (2 <= n <= 4) or not fresh or len({x.data_ptr() for x in xs}) != n
+            or any(not x.is_contiguous() for x in xs)):
+        return [pack(x, rows, cols, precision) for x in xs]
+    bufs = pack_many([(x, rows, cols) for x in xs], precision=prec)
+    if _pack_cache:
+        mark = _cache_mark()
+        for x, buf in zip(xs, bufs):
+            x._vilco_planes = (buf, (int(rows), int(cols), prec, x._version), mark)
+    return bufs
+
+
 # packed operands are shared between forward, dX and dW (env VILCO_PACK_REUSE=0: every GEMM packs its own operands)
 _reuse_packs = os.environ.get("VILCO_PACK_REUSE", "1") != "0"
 # k=3 convs: x and dZ packed once each in the zero-padded per-sequence image, for all three products (VILCO_CONV_TAP_PLANES=0,
@@ -813,7 +839,7 @@ class _LinearGroup(torch.autograd.Function):
         K, N = xs[0].shape[-1], ws[0].shape[0]
         M = xs[0].numel() // K
         ys = [torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device) for x in xs]
-        pxs = [pack(x, M, K) for x in xs]
+        pxs = pack_group(xs, M, K)
         pws = [weight_planes(w, N, K) for w in ws]
         gemm_group([((x, w, y, M, N, K, 1, 1, K, K, N), dict(bias=b, a_planes=px, b_planes=pw, want_amax=True))
                     for x, w, b, y, px, pw in zip(xs, ws, bs, ys, pxs, pws)])
@@ -831,7 +857,7 @@ class _LinearGroup(torch.autograd.Function):
         M = xs[0].numel() // K
         dys = [dy.contiguous() for dy in dys]
         dbs = [colsum(dy.view(M, N), param=b) if ctx.needs_input_grad[1 + 2 * n + i] else None for i, (dy, b) in enumerate(zip(dys, bs))]
-        pzs = [pack(dy, M, N, ctx.prec) for dy in dys]
+        pzs = pack_group(dys, M, N, ctx.prec)
         need_dx = [ctx.needs_input_grad[1 + i] for i in range(n)]
         dxs = [torch.empty_like(x) if nd else None for x, nd in zip(xs, need_dx)]
         calls = [((dy, w, dx, M, K, N, 1, 0, N, K, K), dict(precision=ctx.prec, a_planes=pz, b_planes=pw, want_amax=True))
