@@ -235,6 +235,13 @@ int vilco_layernorm_bwd_res(const float* dy, const float* x, const float* y, con
                             const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
                             float* dbeta, int64_t rows, int32_t C, int32_t relu, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* Round 6: the same + partial maxima of |dx| (dx_amax_parts: device, >= 2048 floats; *n_parts = how many were written): dx is the
+ * output gradient of the layer in front of the LayerNorm, whose mask / activation-backward kernel turns it into operand planes
+ * (vilco_act_bwd_planes / _seq) from that bound. */
+int vilco_layernorm_bwd_res_amax(const float* dy, const float* x, const float* y, const float* gamma,
+                                 const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
+                                 float* dbeta, int64_t rows, int32_t C, int32_t relu, void* workspace,
+                                 size_t workspace_bytes, float* dx_amax_parts, int32_t* n_parts, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Depthwise k=3 conv, stride 1|2, zero pad 1, no bias, output masked: MaskedMHCA's query/key/   */
@@ -432,6 +439,17 @@ int vilco_act_bwd_planes(const float* dy, const float* aux, float* dz, float* db
                          void* workspace, size_t workspace_bytes, float* amax_parts, int32_t* n_parts,
                          const float* dy_amax, int32_t n_dy_amax, void* planes, size_t planes_bytes,
                          const float* row_mask, void* stream);      /* row_mask: as vilco_gemm_desc.row_mask (rows floats) or NULL */
+/* Round 6: the same with the planes in the k=3 convs' zero-padded per-sequence image when seq_len > 0 (vilco_pack_item.seq_len: row
+ * (b, t) at b * (seq_len + 2) + 1 + t, the pad rows and the slack zeroed here; C % 8 == 0, rows % seq_len == 0) -- the output gradient
+ * of a masked k=3 conv (MQ/libs/modeling/blocks.py:79-84: conv output * mask) goes from the mask multiply straight into the operand
+ * image of its dX and weight-gradient products, no fp32 dz, no vilco_pack_many.  seq_len = 0: vilco_act_bwd_planes.
+ * vilco_act_bwd_planes_bytes: size of `planes` for either layout. */
+size_t vilco_act_bwd_planes_bytes(int64_t rows, int32_t C, int32_t seq_len);
+int vilco_act_bwd_planes_seq(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
+                             const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p, uint32_t drop_seed,
+                             void* workspace, size_t workspace_bytes, float* amax_parts, int32_t* n_parts,
+                             const float* dy_amax, int32_t n_dy_amax, void* planes, size_t planes_bytes, int32_t seq_len,
+                             const float* row_mask, void* stream);
 /* out[c] = sum_r x[r][c] */
 int vilco_colsum(const float* x, float* out, int64_t rows, int32_t C, void* workspace,
                  size_t workspace_bytes, void* stream);

@@ -97,6 +97,8 @@ SIGNATURES = {
                                       i32, c_fp, sz, c_fp]),
     "vilco_layernorm_bwd_res": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32,
                                           i32, c_fp, sz, c_fp]),
+    "vilco_layernorm_bwd_res_amax": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i64, i32,
+                                               i32, c_fp, sz, c_fp, C.POINTER(i32), c_fp]),
     "vilco_dwconv3_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp]),
     "vilco_dwconv3_bwd_workspace": (sz, [i32, i32, i32, i32]),
     "vilco_dwconv3_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, i32, i32, i32, i32, c_fp, sz, c_fp]),
@@ -143,6 +145,9 @@ SIGNATURES = {
                                      C.POINTER(i32), c_fp]),
     "vilco_act_bwd_planes": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp,
                                        C.POINTER(i32), c_fp, i32, c_fp, sz, c_fp, c_fp]),
+    "vilco_act_bwd_planes_bytes": (sz, [i64, i32, i32]),
+    "vilco_act_bwd_planes_seq": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, c_fp, i32, i64, i32, f32, C.c_uint32, c_fp, sz, c_fp,
+                                           C.POINTER(i32), c_fp, i32, c_fp, sz, i32, c_fp, c_fp]),
     "vilco_colsum": (C.c_int, [c_fp, c_fp, i64, i32, c_fp, sz, c_fp]),
     "vilco_mask_rows": (C.c_int, [c_fp, c_fp, i32, i32, i32, c_fp]),
     "vilco_add_pe": (C.c_int, [c_fp, c_fp, c_fp, c_fp, i32, i32, i32, c_fp]),

@@ -197,8 +197,22 @@ struct PlaneOut {
   int n_in_amax;
   float bound_factor;
   float* inv_scale;          // {1/s, s} for the consumer kernel
-  long rows32;               // rows of a plane; rows .. rows32 - 1 are zeroed here
+  long rows32;               // rows of a plane; rows .. rows32 - 1 are zeroed here (natural layout)
+  int seqT;                  // 0: natural rows; T > 0 (round 6): the k=3 convs' zero-padded image, row (b, t) at b * (T + 2) + 1 + t
+  long rows_out;             // image: plane rows in all (vilco_tap_plane_rows); the pad rows of every sequence and the slack are zeroed here
 };
+
+__device__ __forceinline__ long plane_row(const PlaneOut& po, long r) {
+  return po.seqT ? (r / po.seqT) * (po.seqT + 2) + 1 + r % po.seqT : r;
+}
+// the k-th zero row of the image (k = 0 .. 2 nseq - 1: the pad rows around the sequences; then the slack below the last one), or -1
+__device__ __forceinline__ long plane_zero_row(const PlaneOut& po, long rows, long k) {
+  if (!po.seqT) return rows + k < po.rows32 ? rows + k : -1;
+  const long nseq = rows / po.seqT;
+  if (k < 2 * nseq) return (k >> 1) * (po.seqT + 2) + ((k & 1) ? po.seqT + 1 : 0);
+  const long rz = nseq * (po.seqT + 2) + (k - 2 * nseq);
+  return rz < po.rows_out ? rz : -1;
+}
 
 __device__ __forceinline__ float plane_scale_from_bound(const PlaneOut& po, bool writer) {
   __shared__ float red_[EW_THREADS / 64];
@@ -251,8 +265,9 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
       if (PLANES) {
         const float xs = g * fs;                        // exact (power of two)
         const _Float16 h0 = (_Float16)xs;
-        po.p0[r * C + c] = h0;
-        po.p0[po.plane_stride + r * C + c] = (_Float16)(xs - (float)h0);
+        const long pr = plane_row(po, r);
+        po.p0[pr * C + c] = h0;
+        po.p0[po.plane_stride + pr * C + c] = (_Float16)(xs - (float)h0);
       }
       acc += g;
       amax = fmaxf(amax, fabsf(g));
@@ -273,7 +288,11 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_kernel(
     for (; r < r1; ++r) one(r, dy[r * C + c], has_aux ? aux[r * C + c] : 0.f);
     if (ws) vilco_st_agent(ws + (long)blockIdx.x * C + c, acc);
     if (PLANES && blockIdx.x == gridDim.x - 1)          // the planes' zero rows (a k-major reader contracts over them)
-      for (long rz = rows; rz < po.rows32; ++rz) { po.p0[rz * C + c] = (_Float16)0.f; po.p0[po.plane_stride + rz * C + c] = (_Float16)0.f; }
+      for (long k = 0;; ++k) {
+        const long rz = plane_zero_row(po, rows, k);
+        if (rz < 0) break;
+        po.p0[rz * C + c] = (_Float16)0.f; po.p0[po.plane_stride + rz * C + c] = (_Float16)0.f;
+      }
   }
   if (amax_parts) {
     amax = wave_max(amax);
@@ -333,8 +352,9 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_vec_kernel(
         h0[e] = (_Float16)xs;
         h1[e] = (_Float16)(xs - (float)h0[e]);
       }
-      *reinterpret_cast<h4*>(po.p0 + r * C + c) = h0;
-      *reinterpret_cast<h4*>(po.p0 + po.plane_stride + r * C + c) = h1;
+      const long pr = plane_row(po, r);
+      *reinterpret_cast<h4*>(po.p0 + pr * C + c) = h0;
+      *reinterpret_cast<h4*>(po.p0 + po.plane_stride + pr * C + c) = h1;
     }
     acc.x += g[0]; acc.y += g[1]; acc.z += g[2]; acc.w += g[3];
   };
@@ -356,7 +376,9 @@ __global__ __launch_bounds__(EW_THREADS) void act_bwd_vec_kernel(
       one(r, *reinterpret_cast<const float4*>(dy + r * C + c), has_aux ? *reinterpret_cast<const float4*>(aux + r * C + c) : z4);
     if (PLANES && blockIdx.x == gridDim.x - 1) {          // the planes' zero rows (a k-major reader contracts over them)
       const h4 hz = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-      for (long rz = rows + wave; rz < po.rows32; rz += 4) {
+      for (long k = wave;; k += 4) {
+        const long rz = plane_zero_row(po, rows, k);
+        if (rz < 0) break;
         *reinterpret_cast<h4*>(po.p0 + rz * C + c) = hz;
         *reinterpret_cast<h4*>(po.p0 + po.plane_stride + rz * C + c) = hz;
       }
@@ -649,11 +671,40 @@ extern "C" int vilco_act_bwd_planes(const float* dy, const float* aux, float* dz
                                     uint32_t drop_seed, void* workspace, size_t workspace_bytes, float* amax_parts,
                                     int32_t* n_parts, const float* dy_amax, int32_t n_dy_amax, void* planes, size_t planes_bytes,
                                     const float* row_mask, void* stream) {
+  return vilco_act_bwd_planes_seq(dy, aux, dz, dbias, act, len, T, rows, C, drop_p, drop_seed, workspace, workspace_bytes, amax_parts,
+                                  n_parts, dy_amax, n_dy_amax, planes, planes_bytes, 0, row_mask, stream);
+}
+
+extern "C" size_t vilco_act_bwd_planes_bytes(int64_t rows, int32_t C, int32_t seq_len) {
+  if (rows < 0 || C <= 0 || seq_len < 0) return 0;
+  if (seq_len > 0) return (size_t)(VILCO_PACK_HDR + (vilco_tap_plane_rows(rows / seq_len, seq_len) * C + 7) / 8 * 8 * 4);
+  const long rows32 = (rows + 31) / 32 * 32;
+  return (size_t)(VILCO_PACK_HDR + (rows32 > 0 ? rows32 : 32) * (long)C * 4);
+}
+
+extern "C" int vilco_act_bwd_planes_seq(const float* dy, const float* aux, float* dz, float* dbias, int32_t act,
+                                        const int32_t* len, int32_t T, int64_t rows, int32_t C, float drop_p,
+                                        uint32_t drop_seed, void* workspace, size_t workspace_bytes, float* amax_parts,
+                                        int32_t* n_parts, const float* dy_amax, int32_t n_dy_amax, void* planes,
+                                        size_t planes_bytes, int32_t seq_len, const float* row_mask, void* stream) {
   if (n_parts) *n_parts = 0;
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return VILCO_ERR_BADARG;
-  if (!dy || (!dz && !planes) || rows < 0 || C <= 0 || act < 0 || act > 2) return VILCO_ERR_BADARG;
-  PlaneOut po = {nullptr, 0, nullptr, 0, 1.f, nullptr, 0};
-  if (planes) {
+  if (!dy || (!dz && !planes) || rows < 0 || C <= 0 || act < 0 || act > 2 || seq_len < 0) return VILCO_ERR_BADARG;
+  PlaneOut po = {nullptr, 0, nullptr, 0, 1.f, nullptr, 0, 0, 0};
+  if (planes && seq_len > 0) {
+    // the k=3 convs' zero-padded per-sequence image (vilco_pack_item.seq_len): C % 8 == 0, whole sequences
+    if (!dy_amax || n_dy_amax <= 0 || (C % 8) != 0 || (rows % seq_len) != 0 || !vilco_aligned(planes, 256)) return VILCO_ERR_BADARG;
+    if (planes_bytes < vilco_act_bwd_planes_bytes(rows, C, seq_len)) return VILCO_ERR_WORKSPACE;
+    unsigned char* u = reinterpret_cast<unsigned char*>(planes);
+    po.p0 = reinterpret_cast<_Float16*>(u + VILCO_PACK_HDR);
+    po.rows_out = vilco_tap_plane_rows(rows / seq_len, seq_len);
+    po.plane_stride = (po.rows_out * C + 7) / 8 * 8;
+    po.seqT = seq_len;
+    po.in_amax = dy_amax; po.n_in_amax = n_dy_amax;
+    po.bound_factor = (1.f / (1.f - drop_p)) * (act == VILCO_ACT_GELU ? 1.13f : 1.f);
+    po.inv_scale = reinterpret_cast<float*>(u) + VILCO_AMAX_MAX_BLOCKS;
+    po.rows32 = po.rows_out;
+  } else if (planes) {
     // the planes of dz in vilco_pack's layout (precision 3, [rows][C]); needs the partial maxima of |dy| for the scale bound
     if (!dy_amax || n_dy_amax <= 0 || (C % 32) != 0 || !vilco_aligned(planes, 256)) return VILCO_ERR_BADARG;
     const long rows32 = (rows + 31) / 32 * 32;

@@ -164,8 +164,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
     float* __restrict__ dx, float* __restrict__ ws, long rows, int C,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, unsigned* sync, const float* __restrict__ dres) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, unsigned* sync, const float* __restrict__ dres,
+    float* __restrict__ amax_parts) {          // amax_parts (round 6): max|dx| of this block, for the consumer's operand planes
   __shared__ float red[LN_WAVES][64 * 4];
+  float amax = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long wid = (long)blockIdx.x * LN_WAVES + wave;
   const long wstride = (long)gridDim.x * LN_WAVES;
@@ -222,6 +224,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
           const float4 r = *reinterpret_cast<const float4*>(dres + row * C + c);
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         *reinterpret_cast<float4*>(dx + row * C + c) = o;
       }
     }
@@ -247,6 +250,18 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
         float* o = wsb + which * C + c;         // crosses the in-launch barrier: write-through stores
         vilco_st_agent(o, a.x); vilco_st_agent(o + 1, a.y); vilco_st_agent(o + 2, a.z); vilco_st_agent(o + 3, a.w);
       }
+    }
+  }
+  if (amax_parts) {
+    amax = wave_max(amax);
+    __syncthreads();
+    if (lane == 0) red[0][wave] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = red[0][0];
+#pragma unroll
+      for (int w = 1; w < LN_WAVES; ++w) m = fmaxf(m, red[0][w]);
+      amax_parts[blockIdx.x] = m;
     }
   }
   // ws rows are [dgamma | dbeta] per block: finish the column sums in this launch (grid barrier), when the host could
@@ -417,6 +432,16 @@ extern "C" int vilco_layernorm_bwd_res(const float* dy, const float* x, const fl
                                        float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t C,
                                        int32_t relu, void* workspace, size_t workspace_bytes,
                                        void* stream) {
+  return vilco_layernorm_bwd_res_amax(dy, x, y, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, relu, workspace, workspace_bytes,
+                                      nullptr, nullptr, stream);
+}
+
+extern "C" int vilco_layernorm_bwd_res_amax(const float* dy, const float* x, const float* y,
+                                            const float* gamma, const float* mean, const float* rstd, const float* dres,
+                                            float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t C,
+                                            int32_t relu, void* workspace, size_t workspace_bytes,
+                                            float* dx_amax_parts, int32_t* n_parts, void* stream) {
+  if (n_parts) *n_parts = 0;
   if (!dy || !x || !mean || !rstd || !dx || rows < 0 || C <= 0) return VILCO_ERR_BADARG;
   if (relu && !y) return VILCO_ERR_BADARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return VILCO_ERR_BADARG;
@@ -429,8 +454,10 @@ extern "C" int vilco_layernorm_bwd_res(const float* dy, const float* x, const fl
   dim3 grid(nb);
   float* ws = reinterpret_cast<float*>(workspace);
   unsigned* sync = (dgamma && dbeta) ? vilco_sync_counter(s, VILCO_SITE_LN) : nullptr;   // nb <= 256 blocks: co-resident
-  if (relu) { LN_DISPATCH_B(nv, ln_bwd_kernel, true, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync, dres) }
-  else { LN_DISPATCH_B(nv, ln_bwd_kernel, false, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync, dres) }
+  float* ap = (dx_amax_parts && n_parts) ? dx_amax_parts : nullptr;       // one partial per block (nb <= 2048: ln_blocks)
+  if (ap) *n_parts = nb;
+  if (relu) { LN_DISPATCH_B(nv, ln_bwd_kernel, true, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync, dres, ap) }
+  else { LN_DISPATCH_B(nv, ln_bwd_kernel, false, dy, x, y, gamma, mean, rstd, dx, ws, (long)rows, (int)C, dgamma, dbeta, sync, dres, ap) }
   if (dgamma && dbeta && !sync) vilco_reduce_rows(ws, dgamma, dbeta, nb, 2 * C, C, s);  // ws rows: [dgamma | dbeta]
   return vilco_launch_status();
 }

@@ -59,7 +59,7 @@ def arithmetic_key():
             #  the remaining switches that change which kernels / roundings a step records, and the library's own
             # configuration generation (vilco_gemm_force / _set_gl / _set_fixup / _set_tail128)
             bool(fold_skip_grads), bool(xl_ds_planes), bool(xl_scores_kernel), bool(linear_group_enabled), bool(use_flash),
-            bool(_reuse_packs), bool(_weight_cache), str(range_check), int(_lib.load().vilco_gemm_config_gen()), bool(pack_group_enabled))
+            bool(_reuse_packs), bool(_weight_cache), str(range_check), int(_lib.load().vilco_gemm_config_gen()), bool(pack_group_enabled), bool(conv_dz_planes), bool(ln_bwd_amax))
 
 
 def get_precision():
@@ -607,6 +607,8 @@ def pack_many(items, precision=None, nbatch=1, relshift=False):
 
 
 pack_group_enabled = os.environ.get("VILCO_PACK_GROUP", "1") != "0"
+ln_bwd_amax = os.environ.get("VILCO_LN_BWD_AMAX", "1") != "0"                # LayerNorm backward leaves max|dx| partials
+conv_dz_planes = os.environ.get("VILCO_CONV_DZ_PLANES", "1") != "0"      # masked k=3 convs: dZ's operand image from the mask kernel itself
 
 
 def pack_group(xs, rows, cols, precision=None):
@@ -711,10 +713,13 @@ def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None, p
     planes=True -> (dz or None, dbias, operand planes of dz or None): when the planes come back, dz was never written."""
     lib = _lib.load()
     rows, Cn = dy.numel() // dy.shape[-1], dy.shape[-1]
-    dy_parts, dy_n = _amax_of(dy) if (planes and producer_planes and _precision == 3 and Cn % 32 == 0 and rows > 0) else (None, 0)
+    # planes == "seq" (round 6, the masked k=3 convs): the planes in the convs' zero-padded per-sequence image of T-row sequences
+    seq = int(T) if planes == "seq" else 0
+    fits = (Cn % 8 == 0 and seq > 0 and rows % seq == 0 and conv_tap_planes) if planes == "seq" else Cn % 32 == 0
+    dy_parts, dy_n = _amax_of(dy) if (planes and producer_planes and _precision == 3 and fits and rows > 0) else (None, 0)
     pz = None
     if dy_parts is not None:
-        nbytes = lib.vilco_pack_bytes(rows, Cn, 3)
+        nbytes = lib.vilco_act_bwd_planes_bytes(rows, Cn, seq)
         pz = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
     dz = torch.empty_like(dy) if pz is None else None
     db = torch.empty(Cn, dtype=torch.float32, device=dy.device) if want_bias else None
@@ -727,9 +732,10 @@ def _act_bwd(dy, aux, act, lens, T, want_bias, drop=(0.0, 0), bias_param=None, p
                                                 int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
                                                 _p(parts), C.byref(n), None, 0, None, 0, _p(row_mask), _stream()))
         else:
-            _lib.check(lib.vilco_act_bwd_planes(dy.data_ptr(), _p(aux), None, _p(db), act, _p(lens),
-                                                int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
-                                                None, None, dy_parts.data_ptr(), int(dy_n), pz.data_ptr(), pz.numel(), _p(row_mask), _stream()))
+            _lib.check(lib.vilco_act_bwd_planes_seq(dy.data_ptr(), _p(aux), None, _p(db), act, _p(lens),
+                                                    int(T or 0), rows, Cn, float(drop[0]), int(drop[1]), _p(ws), ws.numel() if ws is not None else 0,
+                                                    None, None, dy_parts.data_ptr(), int(dy_n), pz.data_ptr(), pz.numel(), seq,
+                                                    _p(row_mask), _stream()))
         dfr.hold(db)
     if parts is not None:
         _tag_amax(dz, parts, n.value)
@@ -1015,19 +1021,29 @@ class _Conv3(torch.autograd.Function):
         Cout = w.shape[0]
         dy = dy.contiguous()
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        want_planes = px is not None and Cout % 8 == 0 and ctx.prec == _precision
+        pz = None
         if lens is not None or row_mask is not None:
-            dz, db = _act_bwd(dy, None, ACT_NONE, lens, T, need_db, bias_param=b, row_mask=row_mask)
+            # (round 6) the mask multiply writes dZ straight into the convs' operand image when both backward products will read
+            # planes: no fp32 dz, no pack_tap launch (conv_dz_planes; needs dy's amax partials -- LayerNorm backward leaves them)
+            direct = (want_planes and conv_dz_planes and ctx.prec == 3 and range_check == "0" and _weight_cache
+                      and (not ctx.needs_input_grad[0] or _cached(w, "conv3_dx", lambda: _conv3_weight(w, (Cin, 3, Cout), 2, (3, -1, Cin * 3), Cin, 3 * Cout))[1] is not None))
+            if direct:
+                dz, db, pz = _act_bwd(dy, None, ACT_NONE, lens, T, need_db, bias_param=b, planes="seq", row_mask=row_mask)
+            else:
+                dz, db = _act_bwd(dy, None, ACT_NONE, lens, T, need_db, bias_param=b, row_mask=row_mask)
         else:
             dz, db = dy, (colsum(dy.view(B * T, Cout), param=b) if need_db else None)
         dx = dw = None
         # dZ in the convs' image: one pack for dX and the weight gradient (needs the format the forward planes were made in)
-        pz = pack_tap(dz, ctx.prec) if (px is not None and Cout % 8 == 0 and ctx.prec == _precision) else None
+        if pz is None:
+            pz = pack_tap(dz, ctx.prec) if want_planes else None
         if ctx.needs_input_grad[0]:
             # wt[ci][j'][co] = w[co][ci][2-j']: dX is the k=3 conv of dZ with flipped taps
             wt, pwt = _cached(w, "conv3_dx", lambda: _conv3_weight(w, (Cin, 3, Cout), 2, (3, -1, Cin * 3), Cin, 3 * Cout))
             dx = torch.empty_like(x)
             gemm(dz, wt, dx, B * T, Cin, 3 * Cout, 1, 1, Cout, 3 * Cout, Cin, tap=TAP_A, tapC=Cout,
-                 tapT=T, a_planes=pz if pwt is not None else None, b_planes=pwt, a_amax=_amax_of(dz),
+                 tapT=T, a_planes=pz if pwt is not None else None, b_planes=pwt, a_amax=_amax_of(dz) if dz is not None else None,
                  planes_seq=(pz is not None and pwt is not None, False))
         if ctx.needs_input_grad[1]:
             with _DwFork(w):
@@ -1104,11 +1120,18 @@ class _LayerNorm(torch.autograd.Function):
         db = torch.empty(Cn, dtype=torch.float32, device=x.device)
         with _Deferring(gamma) as dfr:           # the d-gamma / d-beta column sums may finish with the other deferred ones
             ws = _ws(lib.vilco_layernorm_bwd_workspace(rows, Cn), x.device)
-            _lib.check(lib.vilco_layernorm_bwd_res(dy.data_ptr(), x.data_ptr(), _p(y), _p(gamma),
-                                                   mean.data_ptr(), rstd.data_ptr(), _p(dskip), dx.data_ptr(),
-                                                   dg.data_ptr(), db.data_ptr(), rows, Cn, int(ctx.relu),
-                                                   ws.data_ptr(), ws.numel(), _stream()))
+            # (round 6) max|dx| partials ride along: dx is the output gradient of the layer in front (a masked k=3 conv of the heads /
+            # the embedding: its mask kernel then writes the operand image itself, _act_bwd(planes="seq"))
+            parts = (torch.empty(AMAX_PARTS, dtype=torch.float32, device=x.device)
+                     if (ln_bwd_amax and produce_amax and producer_planes and _precision == 3) else None)
+            n = C.c_int32(0)
+            _lib.check(lib.vilco_layernorm_bwd_res_amax(dy.data_ptr(), x.data_ptr(), _p(y), _p(gamma),
+                                                        mean.data_ptr(), rstd.data_ptr(), _p(dskip), dx.data_ptr(),
+                                                        dg.data_ptr(), db.data_ptr(), rows, Cn, int(ctx.relu),
+                                                        ws.data_ptr(), ws.numel(), _p(parts), C.byref(n), _stream()))
             dfr.hold(dg, db)
+            if parts is not None and n.value > 0:
+                _tag_amax(dx, parts, n.value)
         return dx, dg.view_as(gamma), db.view_as(gamma), None, None, None, None, None
 
 
