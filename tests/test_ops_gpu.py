@@ -992,6 +992,57 @@ def test_conv3_row_mask_equals_masking_afterwards(dev):
         assert rel(a, c) < 2e-6
 
 
+@pytest.mark.parametrize("masked_by", ["row_mask", "lens"])
+def test_conv3_backward_writes_dz_image_from_the_mask_kernel(dev, masked_by):
+    """Round 6 (vilco_act_bwd_planes_seq + vilco_layernorm_bwd_res_amax): conv k=3 -> LayerNorm -> ReLU, the heads' / embeddings'
+    pattern (MQ/libs/modeling/meta_archs.py:216-235).  LayerNorm backward leaves max|dx| partials, so the conv's mask kernel
+    writes dZ straight into the zero-padded operand image of the dX and weight-gradient products (no fp32 dZ, no pack_tap): the
+    decoded image equals the masked gradient to 22 bits with zero pad rows, and all gradients equal the VILCO_CONV_DZ_PLANES=0
+    path (same products on planes whose scale comes from a bound instead of the exact maximum)."""
+    from vilco_amd import _lib, ops
+    torch.manual_seed(5)
+    B, T, Cin, Cout = 2, 70, 64, 96
+    x0, w0 = torch.randn(B, T, Cin, device=dev), torch.randn(Cout, Cin, 3, device=dev) / 8
+    g0, b0 = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev) * 0.1
+    dy = torch.randn(B, T, Cout, device=dev)
+    mask = (torch.rand(B, T, 1, device=dev) > 0.3).float().contiguous() if masked_by == "row_mask" else None
+    lens = torch.tensor([T, T - 23], dtype=torch.int32, device=dev) if masked_by == "lens" else None
+    res, saved = [], ops.conv_dz_planes
+    try:
+        for direct in (True, False):
+            ops.conv_dz_planes = direct
+            x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+            g, b = g0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            z = ops.conv3(x, w, None, lens, row_mask=mask)
+            y = ops.layernorm(z, g, b, 1e-5, True)
+            y.backward(dy)
+            res.append((x.grad, w.grad, g.grad, b.grad))
+    finally:
+        ops.conv_dz_planes = saved
+    for a, c in zip(*res):
+        assert rel(a, c) < 2e-6
+    # the image itself: LayerNorm backward's dx, tagged, through the mask kernel alone
+    dz_in = torch.randn(B, T, Cout, device=dev)
+    parts = torch.zeros(ops.AMAX_PARTS, device=dev)
+    parts[0] = dz_in.abs().max()
+    ops._tag_amax(dz_in, parts, 1)
+    dz_none, _, pz = ops._act_bwd(dz_in, None, ops.ACT_NONE, lens, T, False, planes="seq", row_mask=mask)
+    assert dz_none is None and pz is not None
+    hdr = pz[:4096 + 512].view(torch.float32)
+    inv_s, s = float(hdr[1024]), float(hdr[1025])
+    assert inv_s * s == 1.0
+    rows_out = (B * (T + 2) + 31) // 32 * 32 + 64
+    stride = (rows_out * Cout + 7) // 8 * 8
+    body = pz[4096 + 512:].view(torch.float16)
+    dec = ((body[:rows_out * Cout].double() + body[stride:stride + rows_out * Cout].double()) / s).view(rows_out, Cout)
+    keep = mask.view(B, T, 1) if mask is not None else (torch.arange(T, device=dev)[None, :, None] < lens[:, None, None]).float()
+    want = torch.zeros(rows_out, Cout, dtype=torch.float64, device=dev)
+    for bi in range(B):
+        want[bi * (T + 2) + 1: bi * (T + 2) + 1 + T] = (dz_in[bi] * keep[bi]).double()
+    top = float(dz_in.abs().max())
+    assert bool(((dec - want).abs() <= want.abs() * 2.0 ** -21 + top * 2.0 ** -37).all())
+
+
 @pytest.mark.parametrize("B,Tq,Tk,H,lens", [(2, 300, 300, 2, [300, 211]), (1, 129, 77, 4, [77]), (2, 2304, 2304, 2, [2304, 1500])])
 def test_attention_writes_output_planes(dev, B, Tq, Tk, H, lens):
     """vilco_attn_fwd_planes (hd = 64 forward kernels): the attention output also leaves the kernel as the fp16 x2 operand planes
