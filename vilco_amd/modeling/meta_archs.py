@@ -637,7 +637,10 @@ class PtTransformer(nn.Module):
         if self.n_known > 0 and self.cl_name == 'bic':
             out_cls_logits = [self._bic_correct(x) for x in out_cls_logits]
 
-        fpn_masks = [lens_to_mask(l, T).squeeze(1) for l, T in zip(fpn_lens, level_T)]   # [B, T_l] bool
+        # [B, T_l] bool per level -- not needed by the fused training losses (they read the prefix lengths): 12 launches less on the
+        # chain of a captured step (round 6)
+        fpn_masks = (None if (is_training and fused and not get_emb)
+                     else [lens_to_mask(l, T).squeeze(1) for l, T in zip(fpn_lens, level_T)])
 
         if not is_training and self.use_adapt:
             # average with the prediction of every adapter EMA (meta_archs.py:854-881)
