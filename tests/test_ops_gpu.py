@@ -992,6 +992,27 @@ def test_conv3_row_mask_equals_masking_afterwards(dev):
         assert rel(a, c) < 2e-6
 
 
+def test_pack_group_equals_single_packs_and_keeps_the_cache(dev):
+    """ops.pack_group (round 6): three tensors of one shape through ONE vilco_pack_many launch -- the same plane bytes as three
+    ops.pack calls, each tensor tagged so that a later pack is a cache hit; a tensor that already carries its planes keeps them."""
+    from vilco_amd import ops
+    torch.manual_seed(3)
+    xs = [torch.randn(300, 96, device=dev) * (i + 1) for i in range(3)]
+    ys = [x.clone() for x in xs]
+    got = ops.pack_group(xs, 300, 96)
+    want = [ops.pack(y, 300, 96) for y in ys]
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    for x, g in zip(xs, got):
+        assert ops.pack(x, 300, 96) is g                   # remembered on the tensor
+    again = ops.pack_group(xs, 300, 96)                     # every tensor is a hit now: nothing is re-packed
+    assert all(a is g for a, g in zip(again, got))
+    zs = [torch.randn(300, 96, device=dev) for _ in range(3)]
+    first = ops.pack(zs[1], 300, 96)
+    mixed = ops.pack_group(zs, 300, 96)                     # one hit among them: per-tensor packs, the hit stays a hit
+    assert mixed[1] is first and torch.equal(mixed[0], ops.pack(zs[0].clone(), 300, 96))
+
+
 @pytest.mark.parametrize("masked_by", ["row_mask", "lens"])
 def test_conv3_backward_writes_dz_image_from_the_mask_kernel(dev, masked_by):
     """Round 6 (vilco_act_bwd_planes_seq + vilco_layernorm_bwd_res_amax): conv k=3 -> LayerNorm -> ReLU, the heads' / embeddings'
