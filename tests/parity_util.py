@@ -240,7 +240,7 @@ def p_step_three_ways(dev, realisation, oracle_dtypes=(torch.float32, torch.floa
         losses = model(batch, is_training=True)
         losses['final_loss'].backward()
         log = list(ops.dropout_log)
-        relu_sites = [(site, m.cpu()) for site, m in ops.relu_log]
+        relu_sites = [(e[0], e[1].cpu()) for e in ops.relu_log]
     finally:
         ops.dropout_log = None
         ops.relu_log = None

@@ -90,14 +90,30 @@ def test_w_config_step_properties(dev):
         out = model(b, is_training=True)
         out['final_loss'].backward()
         return {k: float(v) for k, v in out.items()}, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-    l1, g1 = run(batch)
-    assert all(np.isfinite(v) for v in l1.values())
-    assert all(torch.isfinite(g).all() for g in g1.values()) and len(g1) > 300
-    ops.use_flash = False
+    ops.relu_log, ops.relu_log_values = [], True          # the LayerNorm -> ReLU outputs of both runs: which side of zero, by how much
     try:
-        l2, g2 = run(batch)
+        l1, g1 = run(batch)
+        log_fused, ops.relu_log = ops.relu_log, []
+        assert all(np.isfinite(v) for v in l1.values())
+        assert all(torch.isfinite(g).all() for g in g1.values()) and len(g1) > 300
+        ops.use_flash = False
+        try:
+            l2, g2 = run(batch)
+        finally:
+            ops.use_flash = True
+        log_mat = ops.relu_log
     finally:
-        ops.use_flash = True
+        ops.relu_log, ops.relu_log_values = None, False
+    # where the two runs took different sides of a ReLU, and how far from zero the pre-activation that did pass was
+    assert len(log_fused) == len(log_mat) >= 6
+    flips = []
+    for i, ((_, ma, ya), (_, mb, yb)) in enumerate(zip(log_fused, log_mat)):
+        d = ma != mb
+        n = int(d.sum())
+        if n:
+            flips.append((i, n, float(torch.maximum(ya, yb)[d].max() / torch.maximum(ya.max(), yb.max()).clamp_min(1e-30))))
+    del log_fused, log_mat
+    print("W fused vs materialised: ReLU sign differences (call, elements, passed value / max):", flips)
     for k in l1:
         assert abs(l1[k] - l2[k]) <= 1e-5 * max(1.0, abs(l2[k])), (k, l1[k], l2[k])
     # Two arithmetics that differ in the last bits (flash vs materialised softmax) can put ONE LayerNorm -> ReLU pre-activation
@@ -106,12 +122,22 @@ def test_w_config_step_properties(dev):
     # behind it, a uniform ~1e-3 L2 shift of the trunk's gradients (median over the 322 tensors 1.0e-3, largest 2.3e-3) -- the
     # signature of one such flip (tests/test_fullsize_gpu.py::test_p_config_train_step_vs_oracles_over_mask_realisations sees
     # the same event between HIP and the oracle at config P under one of its realisations).  Bounds: 5e-3 in L2 and 5e-2 of
-    # the maximum on every tensor.
+    # the maximum on every tensor.  Round 6: the event is LOCATED, not assumed -- both runs log their LayerNorm -> ReLU outputs
+    # (ops.relu_log_values) and the loose bound applies only when elements really changed side, few of them, each a value within
+    # 1e-5 of zero (measured: 21 elements in the four head-trunk calls, <= 2.7e-7 of their tensor's maximum); without such an
+    # element the bar is 1e-3 in both norms.
     dist = sorted(((((g1[k] - g2[k]).abs().max() / g2[k].abs().max().clamp_min(1e-7)).item(),
                     ((g1[k] - g2[k]).norm() / g2[k].norm().clamp_min(1e-12)).item(), k) for k in g1
                    if not k.endswith(('key_norm.bias', '.key.bias'))), reverse=True)     # (analytically zero: softmax shift)
-    assert max(d[1] for d in dist) < 5e-3, sorted(dist, key=lambda d: -d[1])[:6]
-    assert dist[0][0] < 5e-2, dist[:8]
+    print("W fused vs materialised: worst max-norm / L2 distances:", dist[0][:2], max(d[1] for d in dist))
+    if flips:
+        # (round 6) the loose bound is only available WITH its cause located: a handful of elements changed side, every one of them a
+        # value within 1e-5 of zero relative to its tensor's maximum
+        assert sum(n for _, n, _ in flips) <= 64 and all(rel <= 1e-5 for _, _, rel in flips), flips
+        assert max(d[1] for d in dist) < 5e-3, sorted(dist, key=lambda d: -d[1])[:6]
+        assert dist[0][0] < 5e-2, dist[:8]
+    else:
+        assert max(d[1] for d in dist) < 1e-3 and dist[0][0] < 1e-3, dist[:8]
     del g2
     l3, _ = run(batch[::-1])
     for k in ('cls_loss', 'reg_loss', 'final_loss'):

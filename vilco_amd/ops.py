@@ -1138,6 +1138,7 @@ class _LayerNorm(torch.autograd.Function):
 # parity tooling (tests/test_fullsize_gpu.py): a list -> every LayerNorm -> ReLU call appends (site, y > 0), the derivative mask the
 # backward kernel will use, so that an oracle run can be handed exactly the sign decisions this step took
 relu_log = None
+relu_log_values = False      # True: the entries also carry y itself (site, y > 0, y) -- which side of zero, and by how much
 
 
 def layernorm(x, gamma, beta, eps=1e-5, relu=False, planes=None, row_mask=None, skip=False, site=None):
@@ -1153,7 +1154,7 @@ def layernorm(x, gamma, beta, eps=1e-5, relu=False, planes=None, row_mask=None, 
     if isinstance(y, tuple):
         y, xs = y
     if relu and relu_log is not None:
-        relu_log.append((site, y.detach() > 0))
+        relu_log.append((site, y.detach() > 0, y.detach().clone()) if relu_log_values else (site, y.detach() > 0))
     parts, n = _LayerNorm.last_amax
     _LayerNorm.last_amax = (None, 0)
     made, _LayerNorm.last_planes = _LayerNorm.last_planes, None
