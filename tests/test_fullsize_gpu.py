@@ -331,3 +331,48 @@ def test_p_config_train_step_vs_oracles_over_mask_realisations(dev):
         del hg, g32, g64, gf, orc
     print("full-size parity report:", report)
     assert kinds.count("clean") >= 2, (kinds, report)
+
+
+def test_p_config_replayed_steps_equal_eager_steps_on_changing_batches(dev):
+    """Round 6: at FULL size every replay of the captured step must produce the gradients of the batch it was handed -- checked
+    against eager steps of the same model on the same batches, over replays that alternate between two different batches.  (What
+    this pins: on torch 2.10 + ROCm 7 an ATen multi-block reduction captured in a hipGraph writes its result on the first replay
+    only -- tools/lab/sum_graph_probe.py -- and up to round 5 XLNet's r_w_bias / r_r_bias gradients, the backward of `q + bias`,
+    were such reductions: they stood still in replayed steps at this size and nowhere smaller.  No test compared a replayed
+    full-size step with an eager one on a DIFFERENT batch than the captured one.)"""
+    import bench
+    import vilco_amd.modeling as vm
+    from vilco_amd.graph import GraphedStep
+    cfg = bench.p_config(dropout=0.0, droppath=0.0)
+    torch.manual_seed(0)
+    model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet(dropout=0.0))).to(dev).train()
+    batches = [bench.synth_batch(2, dev, seed=s) for s in (0, 1)]
+
+    def grads():
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    want = []
+    for b in batches:
+        for p in model.parameters():
+            p.grad = None
+        model.loss_normalizer = cfg['train_cfg']['init_loss_norm']
+        model(b, is_training=True)['final_loss'].backward()
+        want.append(grads())
+    k = 'backbone.xlnet.layer.0.rel_attn.r_w_bias'
+    assert rel(want[0][k], want[1][k]) > 1e-3                    # the two batches really ask for different gradients
+    gs = GraphedStep(model, None, eager_steps=1)
+    order = [0, 0, 1, 0, 1, 1]                                   # eager, capture + replay, then replays on alternating batches
+    for call, bi in enumerate(order):
+        model.loss_normalizer = cfg['train_cfg']['init_loss_norm']
+        gs(batches[bi])
+        torch.cuda.synchronize()
+        got = grads()
+        assert set(got) == set(want[bi])
+        bad = [(n, rel(got[n], want[bi][n])) for n in got if not n.endswith(('key_norm.bias', '.key.bias'))
+               and not torch.equal(got[n], want[bi][n]) and rel(got[n], want[bi][n]) > 1e-5]
+        assert not bad, (call, bi, sorted(bad, key=lambda x: -x[1])[:6])
+    assert gs.stats['replayed'] == len(order) - 1
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()

@@ -992,6 +992,22 @@ def test_conv3_row_mask_equals_masking_afterwards(dev):
         assert rel(a, c) < 2e-6
 
 
+def test_bias_add_matches_the_plain_expression(dev):
+    """ops.bias_add (round 6): x + b with the bias gradient summed by vilco_colsum instead of ATen's multi-block `sum` (which does
+    not replay inside a hipGraph on the null stream with this torch / ROCm: tools/lab/sum_graph_probe.py)"""
+    from vilco_amd import ops
+    torch.manual_seed(2)
+    x0, b0, dy = torch.randn(2, 300, 128, device=dev), torch.randn(4, 32, device=dev), torch.randn(2, 300, 128, device=dev)
+    res = []
+    for ours in (True, False):
+        x, b = x0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = ops.bias_add(x, b) if ours else x + b.view(1, 1, -1)
+        y.backward(dy)
+        res.append((y.detach(), x.grad, b.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][2].shape == b0.shape and rel(res[0][2], res[1][2]) < 1e-6
+
+
 def test_pack_group_equals_single_packs_and_keeps_the_cache(dev):
     """ops.pack_group (round 6): three tensors of one shape through ONE vilco_pack_many launch -- the same plane bytes as three
     ops.pack calls, each tensor tagged so that a later pack is a cache hit; a tensor that already carries its planes keeps them."""

@@ -17,7 +17,10 @@
 // WITHOUT any RCCL call): as 6 but NOTHING runs on the second stream -- it only waits for the launch stream's event and records the end
 // event the launch stream then waits for; the second stream is high-priority non-blocking (torch's pool); 8: the two events are created
 // and destroyed every iteration, as torch.cuda.Event objects are; 9: as 7 with the end event queried from a second host thread while
-// the loop runs (what a collective's watchdog does).
+// the loop runs (what a collective's watchdog does);
+// 10: as 8, and the graph produces its value the way ATen's multi-block reductions do (the stale tensors of the real step -- XLNet's
+// r_w_bias / r_r_bias gradients -- are outputs of `aten::sum`): a MEMSET node clears a semaphore, 64 workgroups add to it, and only the
+// workgroup that sees itself last writes the result -- a semaphore that is not zero when the kernel starts leaves the OLD result.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +46,14 @@ __global__ void slow_inplace(float* b, int n, long spin) {      // stands in for
   while ((long)(__builtin_amdgcn_s_memtime() - t0) < spin) { }
   if ((int)threadIdx.x < n) b[threadIdx.x] = v;
 }
+__global__ void last_block_writes(float* g, unsigned* sem, const unsigned* ctr, int n, long spin) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while ((long)(__builtin_amdgcn_s_memtime() - t0) < spin) { }
+  __shared__ unsigned prev;
+  if (threadIdx.x == 0) prev = atomicAdd(sem, 1u);
+  __syncthreads();
+  if (prev == gridDim.x - 1 && (int)threadIdx.x < n) g[threadIdx.x] = (float)(*ctr);
+}
 __global__ void copy_k(const float* __restrict__ s, float* __restrict__ d, int n) { if ((int)threadIdx.x < n) d[threadIdx.x] = s[threadIdx.x]; }
 
 int main(int argc, char** argv) {
@@ -63,6 +74,7 @@ int main(int argc, char** argv) {
   std::thread watchdog;
   if (pat == 9) watchdog = std::thread([&] { while (!stop.load()) { hipEvent_t e = watched.load(); if (e) (void)hipEventQuery(e); } });
   float* bucket; CK(hipMalloc(&bucket, n * 4)); CK(hipMemset(bucket, 0, n * 4));
+  unsigned* sems; CK(hipMalloc(&sems, 8)); CK(hipMemset(sems, 0, 8));
   if (smode == 1) CK(hipStreamCreate(&S));
   if (smode == 2) CK(hipStreamCreateWithFlags(&S, hipStreamNonBlocking));
   hipEvent_t f, j, e1, e2;
@@ -73,7 +85,11 @@ int main(int argc, char** argv) {
   CK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
   hipLaunchKernelGGL(bump, dim3(1), dim3(64), 0, cap, ctr);
   CK(hipEventRecord(f, cap)); CK(hipStreamWaitEvent(side, f, 0));
-  if (pat == 4) {
+  if (pat == 10) {
+    CK(hipMemsetAsync(sems, 0, 4, cap)); CK(hipMemsetAsync(sems + 1, 0, 4, side));
+    hipLaunchKernelGGL(last_block_writes, dim3(64), dim3(64), 0, side, gB, sems + 1, ctr, n, spin / 2);
+    hipLaunchKernelGGL(last_block_writes, dim3(64), dim3(64), 0, cap, gA, sems, ctr, n, spin);
+  } else if (pat == 4) {
     CK(hipMemsetAsync(gA, 0, n * 4, cap)); CK(hipMemsetAsync(gB, 0, n * 4, side));
     for (int c = 0; c < chain; ++c) {
       hipLaunchKernelGGL(atomic_acc, dim3(64 / chain > 0 ? 64 / chain : 1), dim3(64), 0, side, gB, ctr, n, spin / 2 / chain);
@@ -94,7 +110,7 @@ int main(int argc, char** argv) {
     CK(hipGraphLaunch(x1, S));
     if (pat >= 7) {
       hipEvent_t a = e1, b = e2;
-      if (pat == 8) { CK(hipEventCreateWithFlags(&a, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&b, hipEventDisableTiming)); }
+      if (pat == 8 || pat == 10) { CK(hipEventCreateWithFlags(&a, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&b, hipEventDisableTiming)); }
       hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, bucket, n);                 // gather
       CK(hipEventRecord(a, S)); CK(hipStreamWaitEvent(C2, a, 0));
       CK(hipEventRecord(b, C2));                                                          // (nothing runs on C2)
@@ -104,7 +120,7 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, bucket, gA, n);                 // copy back
       hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, o, n);
       hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gB, o + n, n);
-      if (pat == 8) { CK(hipEventDestroy(a)); CK(hipEventDestroy(b)); }
+      if (pat == 8 || pat == 10) { CK(hipEventDestroy(a)); CK(hipEventDestroy(b)); }
     } else if (pat == 5 || pat == 6) {
       hipLaunchKernelGGL(copy_k, dim3(1), dim3(64), 0, S, gA, bucket, n);                 // gather
       CK(hipEventRecord(e1, S)); CK(hipStreamWaitEvent(C2, e1, 0));

@@ -13,6 +13,9 @@ from torch import nn
 
 from .. import ops
 from ..ops import ACT_GELU
+import os as _os
+
+_ATEN_BIAS = _os.environ.get("VILCO_XL_BIAS_ATEN") == "1"      # q + bias through ATen (the stale-sum bug, ops._BiasAdd)
 
 
 class XLNetConfig:
@@ -60,8 +63,12 @@ class XLNetRelativeAttention(nn.Module):
     def forward_tm(self, h, pos_emb, lens):
         """h [B,T,D] token-major, pos_emb [2T, D], lens int32 [B] -> LayerNorm(attn_out + h)."""
         q = ops.linear_kn(h, self.q)                         # ONE projection; the reference's two streams differ by a bias
-        q_w = q + self.r_w_bias.view(1, 1, -1)               # q + r_w_bias (content stream, modeling_xlnet_x.py:284)
-        q_r = q + self.r_r_bias.view(1, 1, -1)               # q + r_r_bias (position stream, :287)
+        # (ops.bias_add, not `q + bias`: the bias gradient must not be an ATen multi-block `sum` inside a captured step, ops._BiasAdd)
+        if _ATEN_BIAS:                                       # (rounds 1-5, kept as the demonstration of the stale-sum bug)
+            q_w, q_r = q + self.r_w_bias.view(1, 1, -1), q + self.r_r_bias.view(1, 1, -1)
+        else:
+            q_w = ops.bias_add(q, self.r_w_bias)             # q + r_w_bias (content stream, modeling_xlnet_x.py:284)
+            q_r = ops.bias_add(q, self.r_r_bias)             # q + r_r_bias (position stream, :287)
         k = ops.linear_kn(h, self.k)
         v = ops.linear_kn(h, self.v)
         k_r = ops.linear_kn(pos_emb, self.r)                 # [2T, H*hd] ([B, 2T, H*hd] under dropout)

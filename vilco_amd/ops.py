@@ -755,6 +755,35 @@ def colsum(x2d, param=None):
     return out
 
 
+class _BiasAdd(torch.autograd.Function):
+    """x [..., C] + b (C elements, any shape).  The backward of the plain expression `x + b.view(1, 1, -1)` is ATen's `sum` over
+    all rows -- a multi-block reduction whose semaphores are cleared by a memset INSIDE the op; on torch 2.10 + ROCm 7 that kernel
+    writes its result on the first replay of a captured hipGraph only and leaves the output untouched afterwards
+    (tools/lab/sum_graph_probe.py, profiles/r06_sum_graph_probe.txt: every later replay returns the first one's sum) -- the cause
+    of round 5's "null-stream hazard": XLNet's r_w_bias / r_r_bias gradients stood still in replayed steps at full size.  Here the
+    bias gradient is a column sum by this library's own kernels (vilco_colsum; deferred finish like every other bias gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        _chk(x, b)
+        ctx.bshape = b.shape
+        ctx.save_for_backward(b)
+        return x + b.reshape(*([1] * (x.dim() - 1)), -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (b,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cn = dy.shape[-1]
+        db = colsum(dy.view(-1, Cn), param=b).view(ctx.bshape) if ctx.needs_input_grad[1] else None
+        return (dy if ctx.needs_input_grad[0] else None), db
+
+
+def bias_add(x, b):
+    """x + b broadcast over the rows, with the bias gradient summed by vilco_colsum instead of ATen (see _BiasAdd)"""
+    return _BiasAdd.apply(x, b)
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) * rowmask.  x [..., K] token-major, W [N, K] (conv1x1 / nn.Linear weight)."""
     last_amax = (None, 0)
