@@ -114,7 +114,11 @@ __device__ __forceinline__ float store_out4(const GArgs& g, long idx, int n, con
   const Epi& e = g.e;
   f32x4 v = acc * e.alpha;
   if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+#ifndef VILCO_GEMM_NO_NT_C
+  if (e.preact) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(e.preact + idx));      // (read again only in backward)
+#else
   if (e.preact) *reinterpret_cast<f32x4*>(e.preact + idx) = v;
+#endif
   if (e.act == VILCO_ACT_RELU) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
@@ -132,7 +136,15 @@ __device__ __forceinline__ float store_out4(const GArgs& g, long idx, int n, con
   }
   if (e.residual && (valid || !e.res_masked)) v += *reinterpret_cast<const f32x4*>(e.residual + idx);
   if (e.beta != 0.f) v += *reinterpret_cast<const f32x4*>(g.cfinal + idx) * e.beta;
+  // Round 6: C leaves as STREAMING (nontemporal) stores.  The output of a launch is 9-75 MB written once by the whole grid and read
+  // next by another kernel through the memory-side cache; keeping it out of the L2 write path measured -0.1 ... -0.15 ms on the
+  // replayed P step (five same-box alternations, profiles/r06_ab_nt_c.txt: 20.51 -> 20.37 ms; GEMM family 12.07 -> 11.85 ms).
+  // -DVILCO_GEMM_NO_NT_C: ordinary stores.
+#ifndef VILCO_GEMM_NO_NT_C
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g.cfinal + idx));
+#else
   *reinterpret_cast<f32x4*>(g.cfinal + idx) = v;
+#endif
   return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
