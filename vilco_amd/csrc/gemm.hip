@@ -311,7 +311,11 @@ __device__ __forceinline__ void gemm_epilogue(const GArgs& g, f32x4 (&acc)[MI][4
     if (m >= g.M || n >= g.N) continue;
     const long idx = coff + (long)m * g.ldc + n;
     if (partial) {
+#ifndef VILCO_GEMM_NO_NT_C      // (split-K slabs stream out too: the deferred sums read them at the end of backward; R6.11)
+      if (g.vec_out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(cp + idx));
+#else
       if (g.vec_out) *reinterpret_cast<f32x4*>(cp + idx) = v;
+#endif
       else
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[idx + e] = v[e];
