@@ -376,3 +376,31 @@ def test_p_config_replayed_steps_equal_eager_steps_on_changing_batches(dev):
 
 def rel(a, b):
     return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+def test_p_config_replayed_training_follows_eager_training(dev):
+    """Round 6: 40 TRAINING iterations at full size (forward + backward + clip + AdamW; replayed as two hipGraphs vs launched eagerly)
+    from the same initial state over four rotating batches, dropout off: the same loss trajectory -- every loss within 1e-4
+    (relative; bit-equal in practice until the float atomics of the loss kernel's mu / sigma gradients have gone through Adam a few
+    times) -- and falling.  tools/lab/train_soak.py is the 300-iteration form (profiles/r06_train_soak.txt)."""
+    import bench
+    import vilco_amd.modeling as vm
+    from vilco_amd.graph import GraphedStep
+    from vilco_amd.utils.train_utils import make_optimizer
+    cfg = bench.p_config(dropout=0.0, droppath=0.0)
+    batches = [bench.synth_batch(2, dev, seed=s) for s in range(4)]
+    runs = []
+    for replay in (True, False):
+        torch.manual_seed(0)
+        model = vm.make_meta_arch('LocPointTransformer', **dict(cfg, xlnet_config=bench.p_xlnet(dropout=0.0))).to(dev).train()
+        opt = make_optimizer(model, dict(type="AdamW", momentum=0.9, weight_decay=0.05, learning_rate=1e-4))
+        gs = GraphedStep(model, opt, clip_grad_l2norm=1.0, eager_steps=1, enabled=replay)
+        losses = [gs(batches[it % 4])['final_loss'] for it in range(40)]
+        torch.cuda.synchronize()
+        assert (gs.stats['replayed'] == 39) if replay else (gs.stats['replayed'] == 0)
+        runs.append(torch.stack(losses).float().cpu())
+        del model, opt, gs
+        torch.cuda.empty_cache()
+    a, b = runs
+    assert bool(torch.isfinite(a).all()) and float(a[-4:].mean()) < 0.7 * float(a[:4].mean())
+    assert float(((a - b).abs() / b.abs()).max()) < 1e-4, ((a - b).abs() / b.abs()).max()
