@@ -53,5 +53,5 @@ out = {"what": "config P train step: per mask realisation and tensor, max = max 
                "oracle taking them); relu events = (site, elements whose sign differed, largest |pre-activation| among them / max |pre-activation|)",
        "realisations": res}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "r06_p_parity_decisions.json"), "w") as f:
+with open(os.path.join(ROOT, "gpurun_out", os.environ.get("VILCO_DIAG_OUT", "r06_p_parity_decisions.json")), "w") as f:
     json.dump(out, f)

@@ -59,7 +59,7 @@ def arithmetic_key():
             #  the remaining switches that change which kernels / roundings a step records, and the library's own
             # configuration generation (vilco_gemm_force / _set_gl / _set_fixup / _set_tail128)
             bool(fold_skip_grads), bool(xl_ds_planes), bool(xl_scores_kernel), bool(linear_group_enabled), bool(use_flash),
-            bool(_reuse_packs), bool(_weight_cache), str(range_check), int(_lib.load().vilco_gemm_config_gen()), bool(pack_group_enabled), bool(conv_dz_planes), bool(ln_bwd_amax))
+            bool(_reuse_packs), bool(_weight_cache), str(range_check), int(_lib.load().vilco_gemm_config_gen()), bool(pack_group_enabled), bool(conv_dz_planes), bool(ln_bwd_amax), bool(_lab_w1part))
 
 
 def get_precision():
@@ -668,8 +668,23 @@ def _cached(w, tag, build):
     if ent is not None and ent[0] == ver:
         return ent[1]
     val = build()
+    if _lab_w1part:
+        _lab_zero_low_part(val)
     store[key] = (ver, val)
     return val
+
+
+# lab only (tools/lab/r6_w1part.sh): the stored weights' SECOND fp16 part zeroed in their cached planes -- numerically the
+# 2-MFMA product (22-bit activations x 11-bit weights) on the 3-MFMA kernels, to price that arithmetic against the parity bar
+_lab_w1part = os.environ.get("VILCO_LAB_W1PART") == "1"
+
+
+def _lab_zero_low_part(val):
+    hdr = int(_lib.load().vilco_pack_bytes(32, 32, 3)) - 32 * 32 * 2 * 2
+    for t in (val if isinstance(val, (tuple, list)) else (val,)):
+        if isinstance(t, torch.Tensor) and t.dtype == torch.uint8 and t.numel() > hdr:
+            body = t.numel() - hdr
+            t[hdr + body // 2:].zero_()
 
 
 def tag_weight_amax(p, parts, n):
