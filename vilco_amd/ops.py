@@ -59,7 +59,7 @@ def arithmetic_key():
             #  the remaining switches that change which kernels / roundings a step records, and the library's own
             # configuration generation (vilco_gemm_force / _set_gl / _set_fixup / _set_tail128)
             bool(fold_skip_grads), bool(xl_ds_planes), bool(xl_scores_kernel), bool(linear_group_enabled), bool(use_flash),
-            bool(_reuse_packs), bool(_weight_cache), str(range_check), int(_lib.load().vilco_gemm_config_gen()), bool(pack_group_enabled), bool(conv_dz_planes), bool(ln_bwd_amax), bool(_lab_w1part))
+            bool(_reuse_packs), bool(_weight_cache), str(range_check), int(_lib.load().vilco_gemm_config_gen()), bool(pack_group_enabled), bool(conv_dz_planes), bool(ln_bwd_amax), bool(_lab_w1part), bool(_lab_a1part))
 
 
 def get_precision():
@@ -552,6 +552,8 @@ def pack(x, rows, cols, precision=None):
         it.planes, it.planes_bytes, it.nbatch, it.batch_stride, it.relshift = buf.data_ptr(), nbytes, 1, 0, 0
         it.amax, it.namax = parts.data_ptr(), n
         _lib.check(lib.vilco_pack_many(C.byref(it), 1, prec, _stream()))
+    if _lab_a1part and prec == 3 and not getattr(x, "_vilco_is_weight", False):
+        _lab_zero_low_part(buf)
     if _pack_cache:
         x._vilco_planes = (buf, key, _cache_mark())
     return buf
@@ -578,6 +580,8 @@ def pack_tap(x, precision=None):
     buf = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     it.planes, it.planes_bytes = buf.data_ptr(), nbytes
     _lib.check(lib.vilco_pack_many(C.byref(it), 1, prec, _stream()))
+    if _lab_a1part and prec == 3:
+        _lab_zero_low_part(buf)
     if _pack_cache:
         x._vilco_tap_planes = (buf, key, _cache_mark())
     return buf
@@ -603,6 +607,8 @@ def pack_many(items, precision=None, nbatch=1, relshift=False):
         it.planes, it.planes_bytes = buf.data_ptr(), nbytes
         bufs.append(buf)
     _lib.check(lib.vilco_pack_many(arr, len(items), prec, _stream()))
+    if _lab_a1part and prec == 3 and nbatch == 1 and not relshift:      # (the attention kernels' operands keep both parts)
+        _lab_zero_low_part(bufs)
     return bufs
 
 
@@ -677,6 +683,10 @@ def _cached(w, tag, build):
 # lab only (tools/lab/r6_w1part.sh): the stored weights' SECOND fp16 part zeroed in their cached planes -- numerically the
 # 2-MFMA product (22-bit activations x 11-bit weights) on the 3-MFMA kernels, to price that arithmetic against the parity bar
 _lab_w1part = os.environ.get("VILCO_LAB_W1PART") == "1"
+# the mirror image: every ACTIVATION / gradient operand packed through pack / pack_tap / pack_many as one part (run with the
+# producer-written planes off -- VILCO_PRODUCER_PLANES=0 VILCO_LN_PLANES=0 VILCO_ATTN_PLANES=0 VILCO_CONV_DZ_PLANES=0 -- so that
+# everything comes through here), the stored weights keep both
+_lab_a1part = os.environ.get("VILCO_LAB_A1PART") == "1"
 
 
 def _lab_zero_low_part(val):
@@ -709,9 +719,15 @@ def _weight_src(w, src):
     return src if parts is None else _tag_amax(src, parts, n)
 
 
+def _lab_mark_weight(t):
+    if _lab_a1part:
+        t._vilco_is_weight = True
+    return t
+
+
 def weight_planes(w, rows, cols):
     """operand planes of the stored matrix w [rows][cols] (a Linear / 1x1-conv weight, an XLNet projection)"""
-    return _cached(w, ("planes", rows, cols), lambda: pack(_weight_src(w, w.detach()), rows, cols))
+    return _cached(w, ("planes", rows, cols), lambda: pack(_lab_mark_weight(_weight_src(w, w.detach())), rows, cols))
 
 
 # dz of a layer goes nowhere but into its two backward products: `_act_bwd(planes=True)` has the kernel write dz as operand planes
@@ -1028,7 +1044,7 @@ def permute3(src, dims, off, strides, out=None):
 
 def _conv3_weight(w, dims, off, strides, rows, cols):
     """(re-laid conv weight, its operand planes or None when the conv's GEMM packs for itself)"""
-    wp = _weight_src(w, permute3(w.detach(), dims, off, strides))
+    wp = _lab_mark_weight(_weight_src(w, permute3(w.detach(), dims, off, strides)))
     planes = pack(wp, rows, cols) if _reuse_packs else None
     return wp, planes
 
