@@ -1294,6 +1294,18 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
     else if ((d->precision == 3 || d->precision == 4) && c192 < best) { p.BM = 192; best = c192; }
     if (!p.gl && c128 < best) { p.BM = 128; best = c128; }
   }
+  // Round 6 (tools/lab/fwd_sweep.py, profiles/r06_fwd_sweep.txt): two sub-round cases the rules above sent to 128 rows.
+  // (a) M < 2048 with more than one round of 128-row tiles but at most one of 192-row tiles (1152 x 4096 x 1024: 288 vs 192
+  //     tiles): 47.4 -> 31.7 us (NT), 51.7 -> 33.0 (NN);
+  // (b) 128..175 tiles of 128 rows and a long K (2304 x 1024 x 4096: 144 tiles x 3 splits = 432 workgroups, 1.7 rounds): 96 tiles
+  //     of 192 rows x 2 splits fill ONE round with half the slab traffic: 68.1 -> 59.9 us (NT), 74.5 -> 62.7 (NN).
+  static const bool sub192 = [] { const char* e = getenv("VILCO_GEMM_SUB192"); return !(e && e[0] == '0'); }();
+  int sub192_ks = 0;
+  if (sub192 && p.gl && d->precision == 3 && p.BM == 128 && nbatch == 1) {
+    const int nk64 = (p.Kp / BK + 1) / 2;
+    if (tiles128 > 256 && tiles192 <= 256 && tiles192 >= 176) p.BM = 192;
+    else if (tiles128 >= 128 && tiles128 < 176 && nk64 >= 48 && tiles192 * 2 <= 256 && tiles192 * 2 >= 176) { p.BM = 192; sub192_ks = 2; }
+  }
   const long tiles = p.BM == 256 ? tiles256 : (p.BM == 192 ? tiles192 : tiles128);
   const int nk32p = p.Kp / BK;
   // barrier intervals of the K loop: gemm_gl_kernel 64 k (two parts) / 128 k (single part), gemm_pp_kernel 32 k (K2: 64)
@@ -1316,6 +1328,7 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
       if (ks > 16) ks = 16;
     }
     if (ks < 1) ks = 1;
+    if (sub192_ks) ks = sub192_ks;
   }
   // Round 6: the single-part products on gemm_pp_kernel's K2 loop (the weight gradients: M = Cout = 1024 rows, long K) were always
   // planned at 128 rows (M < 2048).  A 128 x 128 tile of ONE part is bound by its staging traffic (a 64-k interval moves 32 KB for
