@@ -151,7 +151,14 @@ int vilco_gemm_set_gl(int32_t on);
 /* of 192-row tiles over its first rows + one round of 128-row tiles over the rest (same arithmetic per tile, disjoint rows).   */
 /* 0 (default: measured, no gain in the step) / 1; env VILCO_GEMM_TAIL128.                                                     */
 int vilco_gemm_set_tail128(int32_t on);
-/* Generation of the process-wide GEMM configuration: bumped by vilco_gemm_force / _set_fixup / _set_gl / _set_tail128.  The host
+/* Round 6: few-row NT products of the default precision (M <= 640 token rows: the pyramid levels at T' <= 288, the 77 text tokens, every
+ * level of BASELINE configs[0]; reference: the nn.Linear / 1x1 MaskedConv1D calls of blocks.py:191-269 at those levels) run as ONE
+ * launch of gemm_skinny_kernel (the eight waves of a workgroup split K, fragments straight from the operand planes, partial tiles
+ * summed through LDS) instead of a split-K plan of the tiled kernel + its reduce launch.  1 (default) / 0; env VILCO_GEMM_SKINNY,
+ * VILCO_GEMM_SKINNY_M = the largest M that takes it (640).  Same arithmetic per product (two fp16 parts, three MFMAs, fp32
+ * accumulation); the summation order over K differs from the tiled kernels'. */
+int vilco_gemm_set_skinny(int32_t on);
+/* Generation of the process-wide GEMM configuration: bumped by vilco_gemm_force / _set_fixup / _set_gl / _set_tail128 / _set_skinny.  The host
  * side keys captured hipGraphs on it (a replay runs the plan that was recorded, not the current configuration). */
 int64_t vilco_gemm_config_gen(void);
 /* floats written to desc->amax_out by vilco_gemm(desc) (depends on the tile / split-K plan); 0: not available */

@@ -726,6 +726,50 @@ def test_gemm_output_amax_partials(dev, M, N, K, act):
     assert ops._amax_of(C)[0] is None and ops.pack(C, M, N) is not planes
 
 
+@pytest.mark.parametrize("M,N,K", [(288, 1024, 768), (154, 1024, 768), (144, 1024, 512), (576, 512, 512), (640, 512, 512), (16, 512, 512),
+                                   (17, 100, 100), (33, 64, 64), (161, 130, 96), (320, 72, 700), (288, 1024, 1024)])
+@pytest.mark.parametrize("act", [0, 2])
+def test_few_row_kernel_against_tiled_kernel_and_float64(dev, M, N, K, act):
+    """Round 6 (gemm_skinny_kernel, vilco_gemm_set_skinny): NT products with M <= 640 rows as ONE launch whose eight waves split K.
+    Against float64, against the tiled kernels' plan for the same call (same arithmetic per product, another summation order:
+    agreement to fp32 rounding of the sum, not bit for bit), with bias / GELU + pre-activation / residual / row lengths / fused
+    dropout (the mask is a function of the element index: the same in both) and exact max|C| partials; ragged M, N, K."""
+    from vilco_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(M * 7 + N)
+    A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) / math.sqrt(K)
+    bias, resid = torch.randn(N, device=dev), torch.randn(M, N, device=dev)
+    T = M // 2 if M % 2 == 0 else M
+    lens = torch.tensor([T, T - 3] if M % 2 == 0 else [M - 2], dtype=torch.int32, device=dev)
+    out = {}
+    try:
+        for on in (1, 0):
+            _lib.check(lib.vilco_gemm_set_skinny(on))
+            assert int(lib.vilco_gemm_config_gen()) > 0
+            C = torch.empty(M, N, device=dev)
+            pre = torch.empty_like(C) if act == 2 else None
+            ops.gemm(A, B, C, M, N, K, 1, 1, K, K, N, bias=bias, preact=pre, act=act, residual=resid, row_len=lens, rowT=T,
+                     drop=(0.25, 1234), want_amax=True)
+            parts, n = ops._amax_of(C)
+            assert parts is not None and n > 0 and float(parts[:n].max()) == float(C.abs().max()), on
+            out[on] = (C.clone(), None if pre is None else pre.clone(), n)
+    finally:
+        _lib.check(lib.vilco_gemm_set_skinny(1))
+    if K <= 768 and N <= 1024:      # (the shapes the plan sends to the few-row kernel: one max|C| partial per workgroup of ITS grid)
+        assert out[1][2] == ((N + 63) // 64) * ((M + (16 if M <= 32 else 32) - 1) // (16 if M <= 32 else 32))
+    z = A.double() @ B.double().t() + bias.double()
+    if act == 2:
+        assert rel(out[1][1].cpu(), z.float().cpu()) < TOL_GEMM
+        assert rel(out[1][1], out[0][1]) < 2e-6
+    assert rel(out[1][0], out[0][0]) < 2e-6
+    keep = out[0][0] != resid                                   # (where dropout or the row mask zeroed the product, C == residual)
+    zz = (F.gelu(z) if act == 2 else z).float()
+    rows = torch.arange(M, device=dev)
+    valid = ((rows % T) < lens[rows // T])[:, None]
+    want = torch.where(valid & keep, zz / 0.75, torch.zeros_like(zz)) + resid
+    assert rel(out[1][0].cpu(), want.cpu()) < TOL_GEMM
+
+
 @pytest.mark.parametrize("M,N,K,form", [(154, 1024, 1024, "nt"), (154, 1024, 4096, "nt"), (288, 1024, 1024, "nn"), (1024, 1024, 4608, "tn"),
                                         (77, 333, 2000, "nt"), (1152, 1024, 4096, "nn"), (130, 64, 640, "tn")])
 def test_split_k_fixup_equals_reduce_kernel(dev, M, N, K, form):

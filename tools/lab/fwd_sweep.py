@@ -14,6 +14,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "2":      # second set: the other sub-ro
     shapes = [(4608, 2048, 1024), (2304, 4096, 1024), (2304, 2048, 1024), (1152, 2048, 1024), (576, 4096, 1024), (288, 4096, 1024),
               (288, 1024, 4096), (288, 1024, 1024), (144, 1024, 1024), (154, 1024, 1024), (154, 4096, 1024), (154, 1024, 4096),
               (154, 1024, 768), (9082, 1024, 1024), (4541, 1024, 1024)]
+if len(sys.argv) > 1 and sys.argv[1] == "3":      # profiling run: the default plan only, one tiny shape
+    shapes = [(288, 1024, 1024)]
 for M, N, K in shapes:
     for tb, name in ((1, "NT"), (0, "NN")):
         A = torch.randn(M, K, device=dev)
@@ -25,7 +27,7 @@ for M, N, K in shapes:
         def run():
             ops.gemm(A, B, Cc, M, N, K, 1, tb, K, K if tb else N, N, a_planes=pa, b_planes=pb)
         res = []
-        for bm in (0, 128, 192):
+        for bm in ((0,) if (len(sys.argv) > 1 and sys.argv[1] == "3") else (0, 128, 192)):
             for ks in (0, 1, 2, 3, 4, 6, 8, 12, 16):
                 if bm == 0 and ks != 0:
                     continue

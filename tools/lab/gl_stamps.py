@@ -17,8 +17,14 @@ else:
 C = torch.empty(M, N, device=dev)
 prec = 4 if form == "TN" else None
 pa, pb = ops.pack(A, A.shape[0], A.shape[1]), ops.pack(B, B.shape[0], B.shape[1])
+epi = set(x for x in os.environ.get("EPI", "").split(",") if x)          # EPI=bias,res,gelu,amax: epilogue features of the timed call
+kw = {}
+if "bias" in epi: kw["bias"] = torch.randn(N, device=dev)
+if "res" in epi: kw["residual"] = torch.randn(M, N, device=dev)
+if "gelu" in epi: kw.update(act=2, preact=torch.empty(M, N, device=dev))
+if "amax" in epi: kw["want_amax"] = True
 for _ in range(5):
-    ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N, a_planes=pa, b_planes=pb, precision=prec)
+    ops.gemm(A, B, C, M, N, K, a_kc, b_kc, lda, ldb, N, a_planes=pa, b_planes=pb, precision=prec, **kw)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (2 * 64 * 8))()
 lib = _lib.load()

@@ -79,6 +79,7 @@ SIGNATURES = {
     "vilco_gemm_set_fixup": (C.c_int, [i32]),
     "vilco_gemm_set_gl": (C.c_int, [i32]),
     "vilco_gemm_set_tail128": (C.c_int, [i32]),
+    "vilco_gemm_set_skinny": (C.c_int, [i32]),
     "vilco_gemm_config_gen": (i64, []),
     "vilco_gemm_profile_begin": (C.c_int, []),
     "vilco_gemm_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -303,6 +303,11 @@ __device__ __forceinline__ void gemm_epilogue(const GArgs& g, f32x4 (&acc)[MI][4
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) stg[(i * 16 + (lane >> 4) * 4 + rr) * EPI_LD + j * 16 + (lane & 15)] = acc[i][j][rr];
+  // (Round 6, in-kernel stamps of one workgroup, tools/lab/r6_epi.sh: this loop takes 11 k cycles plain, 13 k with a bias, 24 k with
+  // GELU + pre-activation and 28 k with bias + residual, against 65 k for the K loop of a 4608 x 1024 x 1024 tile.  It is the
+  // chip's write path, not a latency chain: the 192 workgroups of a single-round launch finish together and put 18.9 MB of C --
+  // plus 18.9 MB of residual reads / pre-activation writes -- through the fabric at once, 4-5 TB/s.  Requesting a row's residual
+  // one iteration ahead and loading bias / column scale once: 28 k -> 24 k with the residual, 11 k -> 14 k without, step +0.3 ms.)
 #pragma unroll 1
   for (int it = 0; it < MI * 4; ++it) {
     const int row = it * 4 + (lane >> 4);                       // row inside the wave tile (block it >> 2)
@@ -1062,6 +1067,130 @@ __global__ __launch_bounds__(512) void gemm_gl_group_kernel(GArgsN gg) {
 // 16-byte partial stores require): a thread finishes four consecutive columns, and the partials of up to four splits
 // are requested before the first one is added -- a scalar loop over the splits is one memory round trip per split.
 // The sum keeps the split order either way (bitwise the same result).
+// ------------------------------------------------------------------------------------------ few-row products
+// gemm_skinny_kernel (round 6): y = x W^T with FEW token rows (M <= 640: the pyramid levels at T' <= 288, the 77-token text
+// branch, every level of cfg1) -- shapes on which the tiled kernels above are all latency: 24-96 workgroups whose 4-chunk K
+// loops expose one DMA round trip per chunk (in-kernel stamps, 288 x 1024 x 1024: 3.5 k cycles of set-up, 13.7 k for FOUR
+// chunks, 3.9 k of epilogue = 11.4 us) and then need a second launch to sum the split-K slabs (4.1 us + the node gap): ~17 us
+// for 0.6 GFLOP.  Here ONE launch, no LDS staging, no barrier in the K loop: a workgroup owns BMS x 64 outputs, its eight waves
+// split K between them (contiguous eighths), every lane fetches its MFMA fragments straight from the operand planes (16 bytes =
+// 8 consecutive k of one row: two consecutive k32 steps of a wave use the two halves of the same 128-byte lines), four steps
+// per memory round trip, and the eight partial tiles are summed in wave order through LDS by the
+// epilogue, which is the tiled kernels' own (store_out4: bias, activation, pre-activation, row masks, dropout, residual, beta,
+// max|C|).  Both operands k-contiguous (NT), precision 3 (two fp16 parts, three MFMAs per fragment pair), unbatched.
+constexpr int SK_LD = 68;                                       // floats per row of a wave's partial tile in LDS (EPI_LD's reasons)
+template <int BMS>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(GArgs g) {
+  constexpr int MB = BMS / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* part = reinterpret_cast<float*>(smem_raw);             // [8 waves][BMS][SK_LD]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + 63) >> 6;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * BMS, n0 = tn * 64;
+  const int nk32 = g.Kp / BK;
+  const int per = (nk32 + 7) >> 3;
+  const int s0 = wave * per;
+  int s1 = s0 + per;
+  if (s1 > nk32) s1 = nk32;
+  const int r16 = lane & 15, kq = (lane >> 4) * 8;
+  const __bf16* ap[MB];
+  const __bf16* bp[4];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) ap[i] = g.a.p + row_off(g.a, m0 + 16 * i + r16) + kq;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bp[j] = g.b.p + row_off(g.b, n0 + 16 * j + r16) + kq;
+  const long pa1 = g.a.plane_stride, pb1 = g.b.plane_stride;
+
+  f32x4 acc[MB][4];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // up to FOUR k32 steps are requested at once (all of a wave's share at K <= 1024): one memory round trip per group of four, not
+  // one per step -- with one step in flight a 4-step share took 4 exposed latencies (144 x 1024 x 1024: 11.9 us against 12.3 tiled)
+  constexpr int NB = 4;
+  bf16x8 fa[NB][2][MB], fb[NB][2][4];                           // [buffer][part][block]
+  for (int st = s0; st < s1; st += NB) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      if (st + u < s1) {
+        const int k = (st + u) * BK;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+          fa[u][0][i] = *reinterpret_cast<const bf16x8*>(ap[i] + k);
+          fa[u][1][i] = *reinterpret_cast<const bf16x8*>(ap[i] + pa1 + k);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          fb[u][0][j] = *reinterpret_cast<const bf16x8*>(bp[j] + k);
+          fb[u][1][j] = *reinterpret_cast<const bf16x8*>(bp[j] + pb1 + k);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      if (st + u < s1) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mma<true>(fa[u][0][i], fb[u][0][j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mma<true>(fa[u][0][i], fb[u][1][j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mma<true>(fa[u][1][i], fb[u][0][j], acc[i][j]);
+      }
+    }
+  }
+
+  // ---- the eight partial tiles -> LDS (row-major, one region per wave), summed in wave order, finished like any other tile
+  float* mine = part + wave * (BMS * SK_LD);
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) mine[(16 * i + (lane >> 4) * 4 + rr) * SK_LD + 16 * j + r16] = acc[i][j][rr];
+  __syncthreads();
+  const float inv = g.inv_a[0] * g.inv_b[0];
+  float am = 0.f;
+#pragma unroll 1
+  for (int q = tid; q < BMS * 16; q += 512) {
+    const int row = q >> 4, c4 = (q & 15) * 4;
+    const float* src = part + row * SK_LD + c4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v += *reinterpret_cast<const f32x4*>(src + w * (BMS * SK_LD));
+    v *= inv;
+    const int m = m0 + row, n = n0 + c4;
+    if (m >= g.M || n >= g.N) continue;
+    const long idx = (long)m * g.ldc + n;
+    bool valid = g.e.row_len ? (m % g.e.rowT) < g.e.row_len[m / g.e.rowT] : true;
+    if (g.e.row_mask) valid = valid && g.e.row_mask[m] != 0.f;
+    if (g.vec_out) am = fmaxf(am, store_out4(g, idx, n, v, valid));
+    else
+#pragma unroll 1
+      for (int e = 0; e < 4; ++e) if (n + e < g.N) am = fmaxf(am, store_out(g, idx + e, n + e, v[e], valid));
+  }
+  if (g.amax_out) {
+    am = wave_max(am);
+    __syncthreads();
+    if (lane == 0) part[wave] = am;
+    __syncthreads();
+    if (tid == 0) {
+      float m = part[0];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, part[w]);
+      g.amax_out[blockIdx.x] = m;
+    }
+  }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GArgs g, int nz) {
   constexpr int V = VEC ? 4 : 1;
@@ -1149,6 +1278,7 @@ struct Plan {
   bool k2;                        // precision 4: a barrier interval of the kernel covers two K-steps (64 elements of K)
   bool fixup;                     // split-K finished inside the launch (tile counters) instead of by splitk_reduce_kernel
   bool gl;                        // gemm_gl_kernel (LDS-DMA staging, 64-element chunks): the fp16 x2 products
+  bool skinny;                    // gemm_skinny_kernel (few rows, NT, precision 3): BM = its rows per workgroup (16 | 32)
 };
 
 // Arrival counters of the split-K fix-up: persistent, zero at load, reset by each tile's last arriver.  One region per
@@ -1160,6 +1290,14 @@ __device__ unsigned vilco_tile_counters[FIX_STREAMS * FIX_TILES];
 // 10.43 ms.  The chain sc1 stores -> vmcnt(0) -> atomic round trip -> sc1 loads costs the last arriver ~6 us, a dependent
 // second launch ~5 us: device-scope hand-offs go through the memory side of the 8 XCDs (DESIGN_LOG.md 3.6 found the same for
 // grid barriers).  Kept (tested bit-exact against the reduce kernel) behind VILCO_GEMM_FIXUP=1 / vilco_gemm_set_fixup.
+inline bool& skinny_enabled() {
+  static bool on = [] { const char* e = getenv("VILCO_GEMM_SKINNY"); return !(e && e[0] == '0'); }();
+  return on;
+}
+inline int skinny_max_rows() {
+  static const int v = [] { const char* e = getenv("VILCO_GEMM_SKINNY_M"); const int x = e ? atoi(e) : 640; return x > 0 ? x : 640; }();
+  return v;
+}
 inline bool& fixup_enabled() {
   static bool on = [] { const char* e = getenv("VILCO_GEMM_FIXUP"); return e && e[0] == '1'; }();
   return on;
@@ -1364,6 +1502,19 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   const int force_bm = tune().bm, force_ks = tune().ks;
   if (force_bm == 128 || (force_bm == 256 && !p.gl) || (force_bm == 192 && d->precision >= 3)) p.BM = force_bm;
   if (force_ks >= 1 && force_ks <= nk) ks = force_ks;
+  // few-row NT products of the default precision: one launch of gemm_skinny_kernel instead of a split-K plan + its reduce launch
+  p.skinny = false;
+  if (skinny_enabled() && force_bm == 0 && force_ks < 1 && d->precision == 3 && gl_enabled() && !p.a_tr && !p.b_tr && !p.a_km && !p.b_km &&
+      d->tap_operand == VILCO_TAP_NONE && d->band == 0 && nbatch == 1 && d->M <= skinny_max_rows() && d->K >= 64 && d->K <= 768 &&
+      d->N <= 1024) {
+    // (tools/lab/skinny_ab.py, hipGraph replays: 16..512 x 512 x 512 7.3-8.8 us against 10.7-12.2 tiled, 154 x 1024 x 768 9.8 against
+    // 12.5; from K = 1024 or N = 2048 on the 16..32-row tiles' re-reads of B cost more than the second launch: 288 x 1024 x 1024 14.3
+    // against 13.3, 576 x 1024 x 4096 91 against 28)
+    p.skinny = true;
+    p.gl = false;
+    p.BM = d->M <= 32 ? 16 : 32;       // (64 rows per workgroup spill at two waves per SIMD)
+    ks = 1;
+  }
   p.kchunk = (nk + ks - 1) / ks;
   p.ksplit = (nk + p.kchunk - 1) / p.kchunk;
   long out_span = 0;
@@ -1435,6 +1586,19 @@ extern "C" int vilco_lab_read(unsigned long long* out) {
 
 // ---- optional timing of the MFMA kernel alone (bench.py's roofline line): HIP events on the caller's stream
 namespace {
+template <int BMS>
+static void launch_skinny(const GArgs& g, hipStream_t s) {
+  constexpr size_t lds = (size_t)8 * BMS * SK_LD * 4;
+  static const bool once = [] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<BMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    return true;
+  }();
+  (void)once;
+  const int tiles = ((g.N + 63) / 64) * ((g.M + BMS - 1) / BMS);
+  hipLaunchKernelGGL((gemm_skinny_kernel<BMS>), dim3(tiles), dim3(512), lds, s, g);
+}
+
 struct ProfRec { int64_t v[10]; };   // M, N, K, batch, BM, ksplit, precision, a_km, b_km, tap
 struct ProfState {
   bool on = false;
@@ -1452,6 +1616,7 @@ static long amax_out_parts(const vilco_gemm_desc* d, const Plan& p) {
     long blocks = ((long)d->M * d->N * nz + 255) / 256;
     return blocks > 2048 ? 2048 : blocks;
   }
+  if (p.skinny) return (long)((d->N + 63) / 64) * ((d->M + p.BM - 1) / p.BM);
   const long n = (long)((d->N + BN - 1) / BN) * ((d->M + p.BM - 1) / p.BM) * nz;
   return n <= 8192 ? n : 0;
 }
@@ -1801,7 +1966,9 @@ static int gemm_impl(const vilco_gemm_desc* d, void* stream, GArgs* gout, Plan* 
   if (prof().on) { hipEventCreate(&ev0); hipEventCreate(&ev1); hipEventRecord(ev0, s); }
   {
     const bool ak = p.a_km, bk = p.b_km;
-    if (p.gl) {
+    if (p.skinny) {
+      if (p.BM == 16) launch_skinny<16>(g, s); else launch_skinny<32>(g, s);
+    } else if (p.gl) {
       const bool single = d->precision == 4;
       if (p.BM == 192) { if (single) launch_gl<192, true>(g, grid, s, ak, bk); else launch_gl<192, false>(g, grid, s, ak, bk); }
       else { if (single) launch_gl<128, true>(g, grid, s, ak, bk); else launch_gl<128, false>(g, grid, s, ak, bk); }
@@ -1926,6 +2093,12 @@ extern "C" int vilco_gemm_set_fixup(int32_t on) {
 
 extern "C" int vilco_gemm_set_gl(int32_t on) {
   gl_enabled() = on != 0;
+  ++g_config_gen;
+  return VILCO_OK;
+}
+
+extern "C" int vilco_gemm_set_skinny(int32_t on) {
+  skinny_enabled() = on != 0;
   ++g_config_gen;
   return VILCO_OK;
 }

@@ -55,7 +55,7 @@ def arithmetic_key():
     weak 2: flipping set_precision / dw_precision between replays used to replay the old arithmetic silently)."""
     return (int(_precision), -1 if dw_precision is None else int(dw_precision), int(DW_FAST_MIN_K), bool(producer_planes),
             bool(ln_planes), bool(attn_planes), bool(produce_amax), bool(conv_tap_planes), bool(defer_finish), bool(use_qkv_pre),
-            tuple(sorted(_FORKS)),
+            tuple(sorted(_FORKS)), int(_dw_fork_rows),
             # (ADVICE r05) the remaining switches that change which kernels / roundings a step records, and the library's own
             # configuration generation (vilco_gemm_force / _set_gl / _set_fixup / _set_tail128)
             bool(fold_skip_grads), bool(xl_ds_planes), bool(xl_scores_kernel), bool(linear_group_enabled), bool(use_flash),
@@ -137,13 +137,18 @@ def join_side_streams():
     _dw_seen.clear()
 
 
+# "dw" forks only the weight-gradient products whose contraction runs over at most this many token rows (0: all of them): the
+# products of the small pyramid levels, which sit on a chain that leaves most of the chip idle anyway
+_dw_fork_rows = int(os.environ.get("VILCO_DW_FORK_ROWS", "0"))
+
+
 class _DwFork:
     """context for one weight-gradient product: on the "dw" side stream when forking is on and this weight has not been
     seen in the current backward (a weight used twice accumulates its gradients on the main stream: keep those ordered)"""
 
-    def __init__(self, w):
+    def __init__(self, w, rows=0):
         key = w.data_ptr()          # inside autograd the weight arrives as a fresh saved-tensor alias per use: id() never repeats
-        self.on = fork_enabled("dw") and key not in _dw_seen
+        self.on = fork_enabled("dw") and key not in _dw_seen and (_dw_fork_rows <= 0 or 0 < rows <= _dw_fork_rows)
         if fork_enabled("dw"):
             _dw_seen.add(key)
         self.ctx = None
@@ -886,7 +891,7 @@ class _Linear(torch.autograd.Function):
             dx = torch.empty_like(x)
             gemm(dz, w, dx, M, K, N, 1, 0, N, K, K, precision=prec, a_planes=pz, b_planes=pw, want_amax=True)   # dX = dZ W     (NN)
         if ctx.needs_input_grad[1]:
-            with _DwFork(w), _Deferring(w):          # (a split-K slab sum of this product may finish with the deferred ones)
+            with _DwFork(w, M), _Deferring(w):       # (a split-K slab sum of this product may finish with the deferred ones)
                 dw = _grad_out(w)
                 gemm(dz, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(prec, M), a_planes=pz, b_planes=px)   # dW = dZ^T X   (TN)
         return dx, dw, db, None, None, None, None, None, None
@@ -936,7 +941,7 @@ class _LinearGroup(torch.autograd.Function):
         dws = []
         for i, (dy, x, w, pz, px) in enumerate(zip(dys, xs, ws, pzs, pxs)):
             if ctx.needs_input_grad[1 + n + i]:
-                with _DwFork(w), _Deferring(w):
+                with _DwFork(w, M), _Deferring(w):
                     dw = _grad_out(w)
                     gemm(dy, x, dw, N, K, M, 0, 0, N, K, K, precision=_dw_prec(ctx.prec, M), a_planes=pz, b_planes=px)   # dW = dY^T X
                 dws.append(dw)
@@ -1020,7 +1025,7 @@ class _LinearKN(torch.autograd.Function):
             dx = torch.empty_like(x)
             gemm(dy, w, dx, M, K, N, 1, 1, N, N, K, precision=prec, a_planes=pz, b_planes=pw)   # dX = dY W^T   (NT)
         if ctx.needs_input_grad[1]:
-            with _DwFork(w), _Deferring(w):
+            with _DwFork(w, M), _Deferring(w):
                 dw = _grad_out(w)
                 gemm(x, dy, dw, K, N, M, 0, 0, K, N, N, precision=_dw_prec(prec, M), a_planes=px, b_planes=pz)   # dW = X^T dY   (TN)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -1106,7 +1111,7 @@ class _Conv3(torch.autograd.Function):
                  tapT=T, a_planes=pz if pwt is not None else None, b_planes=pwt, a_amax=_amax_of(dz) if dz is not None else None,
                  planes_seq=(pz is not None and pwt is not None, False))
         if ctx.needs_input_grad[1]:
-            with _DwFork(w):
+            with _DwFork(w, B * T):
                 dwp = torch.empty(Cout, 3 * Cin, dtype=torch.float32, device=x.device)
                 if pz is not None:          # k-major x k-major over the padded token rows: no operand pack at all (gemm.hip: make_plan)
                     gemm(dz, x, dwp, Cout, 3 * Cin, B * T, 0, 0, Cout, Cin, 3 * Cin, tap=TAP_B, tapC=Cin,
