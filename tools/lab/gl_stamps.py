@@ -43,3 +43,6 @@ x = st[:, 63, :]
 for grp in range(2):
     print("group", grp, "entry->first DMAs issued %d | ->chunk 0 landed + barrier %d | loop %d | epilogue %d cycles" %
           (x[grp, 4] - x[grp, 0], x[grp, 1] - x[grp, 4], x[grp, 2] - x[grp, 1], x[grp, 3] - x[grp, 2]))
+    if x[grp, 5]:
+        print("   prologue: entry -> tile + descriptors %d | -> DMA piece addresses %d | -> fragment addresses + acc %d | -> K range + first issue %d" %
+              (x[grp, 5] - x[grp, 0], x[grp, 6] - x[grp, 5], x[grp, 7] - x[grp, 6], x[grp, 4] - x[grp, 7]))

@@ -826,6 +826,7 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
       rsB[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pb + (SINGLE ? 0 : q * g.b.plane_stride)), 0, nb, 0x00020000);
     }
   }
+  STAMPX(5);
   // ---- this wave's DMA pieces: source byte offset of this lane, LDS offset of the piece inside a slot
   unsigned voff[NP0];
   int ldso[NP0];
@@ -856,6 +857,7 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
       ldso[j] = (isB ? A_BYTES : 0) + p * 1024;
     }
   }
+  STAMPX(6);
   const int kstepA = AKM ? (int)(2 * KSLOT * g.a.row_stride) : 2 * KSLOT;     // bytes per 64 k
   const int kstepB = BKM ? (int)(2 * KSLOT * g.b.row_stride) : 2 * KSLOT;
 
@@ -890,6 +892,7 @@ __device__ __forceinline__ void gemm_gl_body(const GArgs& g, const int z) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  STAMPX(7);
   // ---- K range of this workgroup, in intervals of KINT
   const int nk32 = g.Kp / BK;
   constexpr int SUB = KINT / 32;                              // k32 sub-steps per interval
