@@ -129,9 +129,11 @@ def test_p_config_staged_dp_replay_follows_eager_dp_training(dev, one_rank_group
     a, b = runs
     assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
     d = (a - b).abs() / b.abs()
-    # measured (tools/lab/dp_soak.py): 2e-6 over the first 13 iterations, then the rounding-order difference grows with the training
-    # dynamics (6e-2 at iteration 20, where every mode's loss spikes); the one-graph replay and the plain replay are bit-equal to eager
-    assert float(d[:12].max()) < 1e-4 and float(d.max()) < 0.15, d
+    # measured (tools/lab/dp_soak.py and this test on three library builds): bit-equal over the first 6 iterations, <= 1e-6 up to the
+    # 8th, then the rounding-order difference grows with the training dynamics by ~5x per iteration (2e-6 ... 2e-4 at iteration 11
+    # depending on the build's GEMM plans, 4e-2 at 15); from iteration ~18 on every mode's loss spikes at this learning rate and
+    # the comparison means nothing.  The one-graph replay and the plain replay are bit-equal to eager.
+    assert float(d[:8].max()) < 1e-5 and float(d[:12].max()) < 2e-3 and float(d[:16].max()) < 0.2, d
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -394,7 +394,9 @@ def test_deferred_finish_with_existing_grads(dev, name):
     assert recorded[False] == (0, 0), recorded
     assert recorded[True][0] >= 60 and recorded[True][1] == 0, recorded     # pass 1 deferred, pass 2 (grads in place) did not
     for k in grads[True]:
-        if k.startswith(('mu', 'sigma')):
+        if k.startswith(('mu', 'sigma')) or (k.startswith('reg_head.scale.') and k.endswith('.scale')):
+            # (float atomics of the loss backward kernel, loss.hip: dgauss and the per-level regression scales -- the order of
+            # the adds is not fixed from one launch to the next; seen differing in the last bit once in ~10 suite runs)
             assert rel_err(grads[True][k], grads[False][k], 1e-7) < 1e-5, k
         else:
             assert torch.equal(grads[True][k], grads[False][k]), k
@@ -433,7 +435,8 @@ def test_deferred_finish_is_bitwise_the_individual_launches(dev, name):
         assert len(counts[True]) >= 2, counts                                # ... and a twice-used parameter flushed early
     assert grads[True].keys() == grads[False].keys()
     for k in grads[True]:
-        if k.startswith(('mu', 'sigma')):          # the loss kernels' gaussian-parameter gradients: float atomics, not bitwise
-            assert rel_err(grads[True][k], grads[False][k], 1e-7) < 1e-5, k         # reproducible from run to run either way
+        if k.startswith(('mu', 'sigma')) or (k.startswith('reg_head.scale.') and k.endswith('.scale')):
+            # the loss kernels' gaussian-parameter and per-level regression-scale gradients: float atomics, not bitwise
+            assert rel_err(grads[True][k], grads[False][k], 1e-7) < 1e-5, k
         else:
             assert torch.equal(grads[True][k], grads[False][k]), k
