@@ -76,7 +76,10 @@ def test_graphed_training_equals_eager_training(dev, seed_word_zero):
         for k in a:
             assert a[k] == b[k], (i, k, a[k], b[k])
     for k in sa:
-        assert torch.equal(sa[k], sb[k]), k
+        # (loss.hip accumulates the gaussian-weight and regression-scale gradients with float atomics: bit-equal whenever one
+        # workgroup does all the adds, as on this model; otherwise equal up to the order of the adds)
+        assert torch.equal(sa[k], sb[k]) or (any(t in k for t in ("mu", "sigma", "scale")) and
+                                             torch.allclose(sa[k], sb[k], rtol=1e-5, atol=1e-9)), k
 
 
 def test_replays_draw_fresh_dropout_masks_and_match_eager(dev, seed_word_zero):
