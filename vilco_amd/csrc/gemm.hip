@@ -1301,6 +1301,16 @@ inline int skinny_max_rows() {
   static const int v = [] { const char* e = getenv("VILCO_GEMM_SKINNY_M"); const int x = e ? atoi(e) : 640; return x > 0 ? x : 640; }();
   return v;
 }
+// largest M that takes 16-row workgroups (more workgroups, more re-reads of B).  Inside the planned range (K <= 768, N <= 1024) 16 rows
+// are never slower (profiles/r06_skinny_bm16.txt: 154 x 1024 x 768 9.8 us against 11.4 at 32 rows, 512 x 512 x 512 7.6 against 8.6).
+inline int skinny_bm16_rows() {
+  static const int v = [] { const char* e = getenv("VILCO_GEMM_SKINNY_BM16"); const int x = e ? atoi(e) : 640; return x >= 0 ? x : 640; }();
+  return v;
+}
+inline int skinny_max_k() {
+  static const int v = [] { const char* e = getenv("VILCO_GEMM_SKINNY_K"); const int x = e ? atoi(e) : 768; return x > 0 ? x : 768; }();
+  return v;
+}
 inline bool& fixup_enabled() {
   static bool on = [] { const char* e = getenv("VILCO_GEMM_FIXUP"); return e && e[0] == '1'; }();
   return on;
@@ -1508,14 +1518,14 @@ void make_plan(const vilco_gemm_desc* d, Plan& p) {
   // few-row NT products of the default precision: one launch of gemm_skinny_kernel instead of a split-K plan + its reduce launch
   p.skinny = false;
   if (skinny_enabled() && force_bm == 0 && force_ks < 1 && d->precision == 3 && gl_enabled() && !p.a_tr && !p.b_tr && !p.a_km && !p.b_km &&
-      d->tap_operand == VILCO_TAP_NONE && d->band == 0 && nbatch == 1 && d->M <= skinny_max_rows() && d->K >= 64 && d->K <= 768 &&
+      d->tap_operand == VILCO_TAP_NONE && d->band == 0 && nbatch == 1 && d->M <= skinny_max_rows() && d->K >= 64 && d->K <= skinny_max_k() &&
       d->N <= 1024) {
     // (tools/lab/skinny_ab.py, hipGraph replays: 16..512 x 512 x 512 7.3-8.8 us against 10.7-12.2 tiled, 154 x 1024 x 768 9.8 against
     // 12.5; from K = 1024 or N = 2048 on the 16..32-row tiles' re-reads of B cost more than the second launch: 288 x 1024 x 1024 14.3
     // against 13.3, 576 x 1024 x 4096 91 against 28)
     p.skinny = true;
     p.gl = false;
-    p.BM = d->M <= 32 ? 16 : 32;       // (64 rows per workgroup spill at two waves per SIMD)
+    p.BM = d->M <= skinny_bm16_rows() ? 16 : 32;       // (64 rows per workgroup spill at two waves per SIMD)
     ks = 1;
   }
   p.kchunk = (nk + ks - 1) / ks;
