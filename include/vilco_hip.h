@@ -568,6 +568,9 @@ typedef struct vilco_loss_desc {
 size_t vilco_mq_loss_workspace(int32_t B, int32_t R, int32_t C);
 int vilco_mq_loss_fwd(const vilco_loss_desc* d, float* out, float* saved, void* almax_state, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* backward: `workspace` is the forward's (its last region, B*R*8 floats, is scratch of THIS call: every row's share of the gradients of
+ * the per-level regression scales and the gaussian-weight parameters, summed in a fixed order by a second launch -- no float atomics:
+ * all gradients of a step are the same bits on every launch, round 6) */
 int vilco_mq_loss_bwd(const vilco_loss_desc* d, const float* g_cls, const float* g_reg, const float* g_al,
                       const float* g_final, const float* saved, const void* workspace, float* d_logits,
                       float* d_offsets, float* d_level_scale, float* d_gauss, void* stream);

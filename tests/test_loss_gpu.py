@@ -143,3 +143,27 @@ def test_model_fused_equals_tensor_expression_path(dev):
     for k in ga:
         if not k.endswith(('key_norm.bias', '.key.bias')):          # analytically zero: 1e-11-level noise both ways
             assert rel_err(ga[k], gb[k], GRAD_FLOOR) < 1e-4, k
+
+
+def test_parameter_gradients_of_the_loss_are_the_same_bits_on_every_launch(dev):
+    """Round 6: the gradients of the per-level regression scales and of the gaussian-weight parameters (mu / sigma) leave
+    vilco_mq_loss_bwd through per-row shares and a fixed-order second launch (loss_bwd_finish_kernel) instead of float atomicAdds --
+    the last sums of a step whose order changed from launch to launch.  Eight backward passes of the golden model from one state:
+    every gradient tensor bit-equal to the first pass's, the atomics' former targets included."""
+    from parity_util import build_hip_model, golden_cfg, golden_inputs, load_golden
+    gold = load_golden("xl")
+    model = build_hip_model(gold)
+    ref = None
+    for it in range(8):
+        model.zero_grad(set_to_none=True)
+        model.loss_normalizer = golden_cfg(gold)['train_cfg']['init_loss_norm']
+        model(golden_inputs(gold), task_id=gold['task_id'], is_training=True)['final_loss'].backward()
+        g = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        if ref is None:
+            ref = g
+            assert any(k.startswith(('mu', 'sigma')) for k in g) and any(k.startswith('reg_head.scale.') for k in g)
+            assert any(float(g[k].abs().max()) > 0 for k in g if k.startswith('reg_head.scale.'))      # (levels without a positive point: 0)
+        else:
+            assert sorted(g) == sorted(ref)
+            for k in g:
+                assert torch.equal(g[k], ref[k]), (it, k)

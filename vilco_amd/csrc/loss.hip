@@ -245,9 +245,14 @@ __global__ __launch_bounds__(LT) void loss_bwd_kernel(LossArgs a, GradOut go, fl
                                                       float al_weight, const float* __restrict__ saved,
                                                       const int* __restrict__ al_row, const float* __restrict__ al_score,
                                                       int use_al, float* __restrict__ dlogits, float* __restrict__ doffsets,
-                                                      float* __restrict__ dscale, float* __restrict__ dgauss) {
+                                                      float* __restrict__ contrib) {
+  // contrib[(b R + r) * 8 ..]: this row's share of the PARAMETER gradients -- {key, d level_scale, 6 x d gauss} with key =
+  // 256 * level + class for a positive row, -1 otherwise -- summed in a fixed order by loss_bwd_finish_kernel (round 6: these
+  // were float atomicAdds, the only sums of the step whose order changed from launch to launch)
   const int b = blockIdx.y, r = blockIdx.x * LT + threadIdx.x;
   if (r >= a.R) return;
+  float* crow = contrib + ((long)b * a.R + r) * 8;
+  crow[0] = -1.f;
   const float inv_norm = 1.f / saved[0];
   const float gf = go.g[3] ? go.g[3][0] : 0.f;
   const float g_cls = ((go.g[0] ? go.g[0][0] : 0.f) + gf) * inv_norm;
@@ -327,20 +332,60 @@ __global__ __launch_bounds__(LT) void loss_bwd_kernel(LossArgs a, GradOut go, fl
     if (a.level_scale) {
       const float ml = sc * o[0] > 0.f ? 1.f : 0.f, mr = sc * o[1] > 0.f ? 1.f : 0.f;
       dofs[0] = gl * ml * sc; dofs[1] = gr * mr * sc;
-      atomicAdd(&dscale[lvl], gl * ml * o[0] + gr * mr * o[1]);
+      crow[1] = gl * ml * o[0] + gr * mr * o[1];
     } else {
       dofs[0] = gl; dofs[1] = gr;
+      crow[1] = 0.f;
     }
     // d w_cls = cls: g_cls * focal sum ; reg: g_reg * diou * wlr.   dw/dmu = w (rel - mu) / s^2, dw/ds = w (rel - mu)^2 / s^3
     const float dwc = g_cls * fsum + g_reg * di * wlr;
     const float dwl = g_reg * di * wc * 0.5f;
     const float dc = rel - mu_c, dL = rel - mu_l, dR = rel - mu_r;
-    atomicAdd(&dgauss[cg], dwc * wc * dc / (sg_c * sg_c));
-    atomicAdd(&dgauss[a.C + cg], dwc * wc * dc * dc / (sg_c * sg_c * sg_c));
-    atomicAdd(&dgauss[2 * a.C + cg], dwl * wl * dL / (sg_l * sg_l));
-    atomicAdd(&dgauss[3 * a.C + cg], dwl * wl * dL * dL / (sg_l * sg_l * sg_l));
-    atomicAdd(&dgauss[4 * a.C + cg], dwl * wr * dR / (sg_r * sg_r));
-    atomicAdd(&dgauss[5 * a.C + cg], dwl * wr * dR * dR / (sg_r * sg_r * sg_r));
+    crow[2] = dwc * wc * dc / (sg_c * sg_c);
+    crow[3] = dwc * wc * dc * dc / (sg_c * sg_c * sg_c);
+    crow[4] = dwl * wl * dL / (sg_l * sg_l);
+    crow[5] = dwl * wl * dL * dL / (sg_l * sg_l * sg_l);
+    crow[6] = dwl * wr * dR / (sg_r * sg_r);
+    crow[7] = dwl * wr * dR * dR / (sg_r * sg_r * sg_r);
+    crow[0] = (float)(256 * lvl + cg);
+  }
+}
+
+// One workgroup per class c (blockIdx.x < C: the six gaussian-weight gradients of class c) or per pyramid level (blockIdx.x - C:
+// the gradient of that level's regression scale): thread t adds the matching rows t, t + 256, ... in increasing order, the 256
+// partial sums are folded by a fixed tree -- the same bits on every launch.
+__global__ __launch_bounds__(LT) void loss_bwd_finish_kernel(const float* __restrict__ contrib, long rows, int C, int L,
+                                                             float* __restrict__ dscale, float* __restrict__ dgauss) {
+  __shared__ float red[6][LT];
+  const int blk = blockIdx.x, t = threadIdx.x;
+  const bool cls = blk < C;
+  const int want = cls ? blk : blk - C;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long i = t; i < rows; i += LT) {
+    const float key = contrib[i * 8];
+    if (key < 0.f) continue;
+    const int k = (int)key;
+    if (cls) {
+      if ((k & 255) == want) {
+        const float4 lo = *reinterpret_cast<const float4*>(contrib + i * 8 + 4);
+        acc[0] += contrib[i * 8 + 2]; acc[1] += contrib[i * 8 + 3];
+        acc[2] += lo.x; acc[3] += lo.y; acc[4] += lo.z; acc[5] += lo.w;
+      }
+    } else if ((k >> 8) == want) {
+      acc[0] += contrib[i * 8 + 1];
+    }
+  }
+  const int nv = cls ? 6 : 1;
+  for (int v = 0; v < nv; ++v) red[v][t] = acc[v];
+  __syncthreads();
+  for (int w = LT / 2; w > 0; w >>= 1) {
+    if (t < w)
+      for (int v = 0; v < nv; ++v) red[v][t] += red[v][t + w];
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (cls) { for (int v = 0; v < 6; ++v) dgauss[v * C + want] = red[v][0]; }
+    else if (dscale) dscale[want] = red[0][0];
   }
 }
 
@@ -361,9 +406,9 @@ bool bad_desc(const vilco_loss_desc* d) {
 }  // namespace
 
 extern "C" size_t vilco_mq_loss_workspace(int32_t B, int32_t R, int32_t C) {
-  // [partials: B * ceil(R/256) * 3 floats][al rows: B*C int][al scores: B*C float], 16-byte aligned pieces
+  // [partials: B * ceil(R/256) * 3 floats][al rows: B*C int][al scores: B*C float][contrib: B*R*8 floats], 16-byte aligned pieces
   const size_t parts = (size_t)B * ((R + LT - 1) / LT) * 3 * sizeof(float);
-  return ((parts + 15) / 16) * 16 + 2 * (((size_t)B * C * 4 + 15) / 16) * 16;
+  return ((parts + 15) / 16) * 16 + 2 * (((size_t)B * C * 4 + 15) / 16) * 16 + (size_t)B * R * 8 * sizeof(float);      // + backward's per-row parameter-gradient shares
 }
 
 extern "C" int vilco_mq_loss_fwd(const vilco_loss_desc* d, float* out, float* saved, void* almax_state, void* workspace,
@@ -399,9 +444,11 @@ extern "C" int vilco_mq_loss_bwd(const vilco_loss_desc* d, const float* g_cls, c
   const size_t parts = (((size_t)d->B * gx * 3 * sizeof(float)) + 15) / 16 * 16;
   const int* al_row = reinterpret_cast<const int*>(reinterpret_cast<const char*>(workspace) + parts);
   const float* al_score = reinterpret_cast<const float*>(reinterpret_cast<const char*>(al_row) + (((size_t)d->B * d->C * 4 + 15) / 16) * 16);
-  if (hipMemsetAsync(d_gauss, 0, sizeof(float) * 6 * d->C, s) != hipSuccess) return VILCO_ERR_LAUNCH;
-  if (d->level_scale && hipMemsetAsync(d_level_scale, 0, sizeof(float) * d->L, s) != hipSuccess) return VILCO_ERR_LAUNCH;
+  // (the workspace is the forward's: its last region is written here -- the `const` of the signature predates it)
+  float* contrib = const_cast<float*>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(al_score) + (((size_t)d->B * d->C * 4 + 15) / 16) * 16));
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(gx, d->B), dim3(LT), 0, s, a, grad_out, d->loss_weight, d->al_weight, saved,
-                     al_row, al_score, d->use_al ? 1 : 0, d_logits, d_offsets, d_level_scale, d_gauss);
+                     al_row, al_score, d->use_al ? 1 : 0, d_logits, d_offsets, contrib);
+  hipLaunchKernelGGL(loss_bwd_finish_kernel, dim3(d->C + (d->level_scale ? d->L : 0)), dim3(LT), 0, s, contrib, (long)d->B * d->R, d->C,
+                     d->L, d->level_scale ? d_level_scale : nullptr, d_gauss);
   return vilco_launch_status();
 }
